@@ -1,0 +1,82 @@
+"""ctypes binding of the C ABI declared in include/ieee_amd.h.
+
+This is exactly the binding a maintainer of the reference would add to call the
+library from Python.  The library is built in-tree by
+`__graft_entry__.build()` / `make -C ieee_amd/csrc`; it is never pip-installed.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libieee_amd.so")
+_lib = None
+
+c_void_p, c_int, c_int64, c_float, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                               ctypes.c_float, ctypes.c_double)
+
+IEEE_F32, IEEE_BF16 = 0, 1
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+_SIGNATURES = {
+    "ieee_last_error": [],
+    "ieee_version": [],
+    "ieee_device_is_gfx950": [],
+    "ieee_sqeuclid_distmat": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int64,
+                              c_void_p, c_void_p],
+    "ieee_rank_market1501": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                             c_void_p, c_void_p, c_void_p, c_void_p],
+}
+_RESTYPE = {"ieee_last_error": ctypes.c_char_p}
+
+
+class IeeeAmdError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Loads libieee_amd.so; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IeeeAmdError(
+            "ieee_amd HIP library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C ieee_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().ieee_last_error()
+        raise IeeeAmdError((msg or b"").decode("utf-8", "replace") or "ieee_amd error %d" % status)
+
+
+def require_gpu():
+    """The product path needs a gfx950 GPU; fail loudly otherwise."""
+    import torch
+    if not torch.cuda.is_available():
+        raise IeeeAmdError("ieee_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False and there "
+                           "is no CPU fallback.")
+    lib = load()
+    if not lib.ieee_device_is_gfx950():
+        raise IeeeAmdError("ieee_amd kernels are built for gfx950 only; current device is not gfx950.")
+    return lib
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,493 @@
+// LDS-tiled MFMA GEMM cores for gfx950 (wave64, 256-thread workgroups = 2x2 waves).
+//
+// Two cores share one accumulate/epilogue convention:
+//   gemm_nt : C[m][n] = sum_k A[m][k] * B[n][k]   (both operands K-contiguous)
+//             conv forward / dgrad (implicit GEMM over NHWC), distmat, linear
+//   gemm_tn : C[m][n] = sum_k At[k][m] * Bt[k][n] (both operands K-major)
+//             conv wgrad (K = output pixels); fragments come out of LDS through
+//             ds_read_b64_tr_b16 (bf16) so no register transpose is needed
+//
+// dtypes: bf16 -> v_mfma_f32_16x16x32_bf16, fp32 -> v_mfma_f32_16x16x4_f32
+// (exact fp32 fma chain; the parity mode and the fp32 distmat run on it).
+//
+// The MFMA is issued as D = Nfrag x Mfrag, so a lane ends up holding FOUR
+// CONSECUTIVE n (channels) of ONE m (pixel): m = lane&15, n = (lane>>4)*4 + r.
+// That makes the NHWC epilogue store 8 B (bf16) / 16 B (fp32) per lane.
+//
+// Global->LDS staging goes through registers (the im2col gather, zero padding
+// and the transposed TN image cannot be expressed as a lane-linear LDS-DMA);
+// next-tile loads are issued before the MFMA block and written after it.
+#pragma once
+#include "common.h"
+
+namespace ieee {
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ LDS images
+// NT image: [rows][128 bytes of K]; 16-byte chunks XOR-swizzled so that the
+// fragment reads below are bank-conflict free (ds_read_b128: 4 lane groups of
+// 16 over a 256-B bank row; ds_read_b32: 2 groups of 32 over a 128-B bank row).
+template <typename T> struct ImgNT;
+
+template <> struct ImgNT<bf16> {
+  static constexpr int BK = 64, KSTEPS = 2;
+  typedef bf16x8 Frag;
+  __device__ static __forceinline__ void store(char* tile, int row, int c, uint4 v) {
+    *(uint4*)(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+  }
+  __device__ static __forceinline__ Frag frag(const char* tile, int row16, int kk, int lane) {
+    const int row = row16 + (lane & 15);
+    const int c = kk * 4 + (lane >> 4);
+    const uint4 v = *(const uint4*)(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+
+template <> struct ImgNT<float> {
+  static constexpr int BK = 32, KSTEPS = 8;
+  typedef float Frag;
+  __device__ static __forceinline__ void store(char* tile, int row, int c, uint4 v) {
+    if ((row >> 3) & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+    *(uint4*)(tile + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+  }
+  __device__ static __forceinline__ Frag frag(const char* tile, int row16, int kk, int lane) {
+    const int row = row16 + (lane & 15);
+    const int p = (lane >> 4) ^ (((row >> 3) & 1) << 1);
+    return *(const float*)(tile + row * 128 + ((kk ^ (row & 7)) << 4) + (p << 2));
+  }
+};
+
+// TN image: [BK k-rows][128 columns]; columns contiguous (as they are in HBM).
+template <typename T> struct ImgTN;
+
+template <> struct ImgTN<bf16> {
+  static constexpr int BK = 64, KSTEPS = 2, CPR = 16;  // 16 chunks (of 8 bf16) per 256-B k-row
+  typedef bf16x8 Frag;
+  __device__ static __forceinline__ int hsw(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+  __device__ static __forceinline__ void store(char* tile, int kr, int c, uint4 v) {
+    *(uint4*)(tile + kr * 256 + ((((c >> 1) ^ hsw(kr))) << 5) + ((c & 1) << 4)) = v;
+  }
+  __device__ static __forceinline__ Frag frag(const char* tile, int col16, int kk, int lane) {
+    // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(col) block, delivered column-major:
+    // lane 4q+p supplies the address of row q, columns 4p..4p+3; lane i receives column i.
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int k0 = kk * 32 + 8 * g + q;
+    const int w = col16 >> 4;
+    const char* a0 = tile + k0 * 256 + ((w ^ hsw(k0)) << 5) + p * 8;
+    const char* a1 = a0 + 4 * 256;  // rows k0+4..: same swizzle key (k&3 and (k>>3)&1 unchanged)
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+
+template <> struct ImgTN<float> {
+  static constexpr int BK = 32, KSTEPS = 8, CPR = 32;  // 32 chunks (of 4 fp32) per 512-B k-row
+  typedef float Frag;
+  __device__ static __forceinline__ void store(char* tile, int kr, int c, uint4 v) {
+    *(uint4*)(tile + kr * 512 + ((((c >> 2) ^ (kr & 1))) << 6) + ((c & 3) << 4)) = v;
+  }
+  __device__ static __forceinline__ Frag frag(const char* tile, int col16, int kk, int lane) {
+    const int k = kk * 4 + (lane >> 4);
+    return *(const float*)(tile + k * 512 + ((((col16 >> 4) ^ (k & 1))) << 6) + ((lane & 15) << 2));
+  }
+};
+
+// ------------------------------------------------------------------ cores
+// Loader contract:  uint4 load(int slot)  -> 16 bytes of the CURRENT k-tile for
+// this thread's slot (zero-filled when out of range);  void next()  -> advance
+// one k-tile.  NT slots: row = (t>>3) + 32*slot, chunk = t&7.
+// TN slots: k-row = t/CPR + (256/CPR)*slot, chunk = t%CPR.
+// Epilogue contract: epi(m, n, f32x4 v): v[r] is C[m][n+r] (global indices).
+
+template <typename T, int BM, int BN, class LA, class LB, class Epi>
+__device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem) {
+  typedef ImgNT<T> Img;
+  constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;
+  constexpr int FM = BM / 32, FN = BN / 32;
+  constexpr int STAGE = (BM + BN) * 128;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int srow = t >> 3, sc = t & 7;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[ACH], rb[BCH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) ra[i] = la.load(i);
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) rb[i] = lb.load(i);
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) Img::store(smem, srow + 32 * i, sc, ra[i]);
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) Img::store(smem + BM * 128, srow + 32 * i, sc, rb[i]);
+  __syncthreads();
+
+  for (int kt = 0; kt < ktiles; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE;
+    const bool has_next = (kt + 1) < ktiles;
+    if (has_next) {
+      la.next();
+      lb.next();
+#pragma unroll
+      for (int i = 0; i < ACH; ++i) ra[i] = la.load(i);
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) rb[i] = lb.load(i);
+    }
+    const char* At = cur + (wm * (BM / 2)) * 128;
+    const char* Bt = cur + BM * 128 + (wn * (BN / 2)) * 128;
+#pragma unroll
+    for (int kk = 0; kk < Img::KSTEPS; ++kk) {
+      typename Img::Frag fa[FM], fb[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa[i] = Img::frag(At, i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb[j] = Img::frag(Bt, j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+    if (has_next) {
+#pragma unroll
+      for (int i = 0; i < ACH; ++i) Img::store(nxt, srow + 32 * i, sc, ra[i]);
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) Img::store(nxt + BM * 128, srow + 32 * i, sc, rb[i]);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      epi(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, acc[i][j]);
+}
+
+// TN core: 128x128 tile only.
+template <typename T, class LA, class LB, class Epi>
+__device__ __forceinline__ void gemm_tn(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem) {
+  typedef ImgTN<T> Img;
+  constexpr int CPR = Img::CPR;
+  constexpr int RPP = 256 / CPR;                 // k-rows covered per pass of 256 threads
+  constexpr int NCH = Img::BK / RPP;             // slots per thread per operand (=4)
+  constexpr int TILE = Img::BK * 128 * (int)sizeof(T);
+  constexpr int STAGE = 2 * TILE;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int skr = t / CPR, sc = t % CPR;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[NCH], rb[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) ra[i] = la.load(i);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) rb[i] = lb.load(i);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) Img::store(smem, skr + RPP * i, sc, ra[i]);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) Img::store(smem + TILE, skr + RPP * i, sc, rb[i]);
+  __syncthreads();
+
+  for (int kt = 0; kt < ktiles; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE;
+    const bool has_next = (kt + 1) < ktiles;
+    if (has_next) {
+      la.next();
+      lb.next();
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) ra[i] = la.load(i);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) rb[i] = lb.load(i);
+    }
+#pragma unroll
+    for (int kk = 0; kk < Img::KSTEPS; ++kk) {
+      typename Img::Frag fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = Img::frag(cur, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = Img::frag(cur + TILE, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+    if (has_next) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) Img::store(nxt, skr + RPP * i, sc, ra[i]);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) Img::store(nxt + TILE, skr + RPP * i, sc, rb[i]);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      epi(m0 + wm * 64 + i * 16 + (lane & 15), n0 + wn * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+}
+
+// ------------------------------------------------------------------ loaders
+// Plain row-major [rows][ld] matrix, K contiguous (weights, features, linear inputs).
+template <typename T, int NCH> struct LoaderPlainNT {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int BK = ImgNT<T>::BK;
+  const T* p[NCH];
+  int kcol, K;
+  __device__ __forceinline__ void init(const T* base, int64_t ld, int row0, int nrows, int K_) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int row = row0 + (t >> 3) + 32 * i;
+      p[i] = row < nrows ? base + (int64_t)row * ld : nullptr;
+    }
+    kcol = (t & 7) * VEC;
+    K = K_;
+  }
+  __device__ __forceinline__ uint4 load(int i) const {
+    if (p[i] == nullptr || kcol >= K) return make_uint4(0, 0, 0, 0);
+    return *(const uint4*)(p[i] + kcol);
+  }
+  __device__ __forceinline__ void next() { kcol += BK; }
+};
+
+// Gather geometry shared by conv forward and dgrad:
+//   source row  h = (hb + sgn*r) / div  where hb = p*mul + off   (same for w)
+// forward: mul=stride, off=-pad, sgn=+1, div=1, source = X   [N,Hs,Ws,Cs]
+// dgrad  : mul=1, off=+pad, sgn=-1, div=stride, source = dY  [N,Hs,Ws,Cs]
+struct GatherGeom {
+  int Hs, Ws, Cs;      // source tensor spatial dims / channels
+  int Ho, Wo;          // pixel grid that indexes the GEMM rows
+  int R, S;            // taps
+  int mul, off, sgn, div;
+  int npix;            // N*Ho*Wo
+};
+
+// Fast path: Cs % BK == 0, so one k-tile stays inside one tap.
+template <typename T, int NCH> struct LoaderIm2colNT {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int BK = ImgNT<T>::BK;
+  const T* p[NCH];
+  int hb[NCH], wb[NCH];
+  int r, s, ci0;
+  GatherGeom g;
+  __device__ __forceinline__ void init(const T* src, const GatherGeom& g_, int m0) {
+    g = g_;
+    const int t = threadIdx.x;
+    const int hw = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int m = m0 + (t >> 3) + 32 * i;
+      if (m < g.npix) {
+        const int n = m / hw, rem = m - n * hw;
+        const int pp = rem / g.Wo, qq = rem - pp * g.Wo;
+        p[i] = src + (int64_t)n * g.Hs * g.Ws * g.Cs + (t & 7) * VEC;
+        hb[i] = pp * g.mul + g.off;
+        wb[i] = qq * g.mul + g.off;
+      } else {
+        p[i] = nullptr; hb[i] = 0; wb[i] = 0;
+      }
+    }
+    r = 0; s = 0; ci0 = 0;
+  }
+  __device__ __forceinline__ uint4 load(int i) const {
+    if (p[i] == nullptr || r >= g.R) return make_uint4(0, 0, 0, 0);
+    int h = hb[i] + g.sgn * r, w = wb[i] + g.sgn * s;
+    if (g.div == 2) {
+      if ((h | w) & 1) return make_uint4(0, 0, 0, 0);
+      h >>= 1; w >>= 1;
+    }
+    if ((unsigned)h >= (unsigned)g.Hs || (unsigned)w >= (unsigned)g.Ws) return make_uint4(0, 0, 0, 0);
+    return *(const uint4*)(p[i] + ((int64_t)h * g.Ws + w) * g.Cs + ci0);
+  }
+  __device__ __forceinline__ void next() {
+    ci0 += BK;
+    if (ci0 >= g.Cs) { ci0 = 0; if (++s == g.S) { s = 0; ++r; } }
+  }
+};
+
+// Generic (slow) path: any Cs (the 3-channel stem); element-wise gather.
+template <typename T, int NCH> struct LoaderIm2colSlowNT {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int BK = ImgNT<T>::BK;
+  const T* p[NCH];
+  int hb[NCH], wb[NCH];
+  int kcol, K;
+  GatherGeom g;
+  __device__ __forceinline__ void init(const T* src, const GatherGeom& g_, int m0) {
+    g = g_;
+    const int t = threadIdx.x;
+    const int hw = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int m = m0 + (t >> 3) + 32 * i;
+      if (m < g.npix) {
+        const int n = m / hw, rem = m - n * hw;
+        const int pp = rem / g.Wo, qq = rem - pp * g.Wo;
+        p[i] = src + (int64_t)n * g.Hs * g.Ws * g.Cs;
+        hb[i] = pp * g.mul + g.off;
+        wb[i] = qq * g.mul + g.off;
+      } else {
+        p[i] = nullptr; hb[i] = 0; wb[i] = 0;
+      }
+    }
+    kcol = (t & 7) * VEC;
+    K = g.R * g.S * g.Cs;
+  }
+  __device__ __forceinline__ uint4 load(int i) const {
+    float f[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int k = kcol + e;
+      float v = 0.f;
+      if (p[i] != nullptr && k < K) {
+        const int tap = k / g.Cs, ci = k - tap * g.Cs;
+        const int rr = tap / g.S, ss = tap - rr * g.S;
+        int h = hb[i] + g.sgn * rr, w = wb[i] + g.sgn * ss;
+        bool ok = true;
+        if (g.div == 2) { ok = !((h | w) & 1); h >>= 1; w >>= 1; }
+        if (ok && (unsigned)h < (unsigned)g.Hs && (unsigned)w < (unsigned)g.Ws)
+          v = to_f32(p[i][((int64_t)h * g.Ws + w) * g.Cs + ci]);
+      }
+      f[e] = v;
+    }
+    return Vec16<T>::pack(f);
+  }
+  __device__ __forceinline__ void next() { kcol += BK; }
+};
+
+// TN: plain [K][ld] matrix, columns contiguous (dY for wgrad).
+template <typename T> struct LoaderColsTN {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int BK = ImgTN<T>::BK, CPR = ImgTN<T>::CPR, RPP = 256 / CPR, NCH = BK / RPP;
+  const T* base;  // already offset to this thread's column chunk, or nullptr if the chunk is out of range
+  int64_t ld;
+  int k0, kend;
+  __device__ __forceinline__ void init(const T* mat, int64_t ld_, int col0, int ncols, int kbeg, int kend_) {
+    const int t = threadIdx.x;
+    const int col = col0 + (t % CPR) * VEC;
+    base = col < ncols ? mat + col : nullptr;
+    ld = ld_;
+    k0 = kbeg + t / CPR;
+    kend = kend_;
+  }
+  __device__ __forceinline__ uint4 load(int i) const {
+    const int k = k0 + RPP * i;
+    if (base == nullptr || k >= kend) return make_uint4(0, 0, 0, 0);
+    return *(const uint4*)(base + (int64_t)k * ld);
+  }
+  __device__ __forceinline__ void next() { k0 += BK; }
+};
+
+// TN: im2col columns (tap, channel) of the forward geometry, rows = output pixels.
+template <typename T> struct LoaderIm2colTN {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int BK = ImgTN<T>::BK, CPR = ImgTN<T>::CPR, RPP = 256 / CPR, NCH = BK / RPP;
+  const T* src;
+  GatherGeom g;
+  int k0, kend;
+  int r, s, ci;       // this thread's (fixed) column chunk
+  bool colok;
+  int lw, lhw;        // log2(Wo), log2(Ho*Wo) or -1
+  __device__ __forceinline__ void init(const T* src_, const GatherGeom& g_, int col0, int kbeg, int kend_) {
+    g = g_;
+    src = src_;
+    const int t = threadIdx.x;
+    const int tc = col0 + (t % CPR) * VEC;
+    const int ncols = g.R * g.S * g.Cs;
+    colok = tc < ncols;
+    const int tap = tc / g.Cs;
+    ci = tc - tap * g.Cs;
+    r = tap / g.S;
+    s = tap - r * g.S;
+    k0 = kbeg + t / CPR;
+    kend = kend_;
+    const int hw = g.Ho * g.Wo;
+    lw = (g.Wo & (g.Wo - 1)) == 0 ? __builtin_ctz(g.Wo) : -1;
+    lhw = (hw & (hw - 1)) == 0 ? __builtin_ctz(hw) : -1;
+  }
+  __device__ __forceinline__ uint4 load(int i) const {
+    const int m = k0 + RPP * i;
+    if (!colok || m >= kend) return make_uint4(0, 0, 0, 0);
+    int n, pp, qq;
+    if (lw >= 0 && lhw >= 0) {
+      n = m >> lhw;
+      const int rem = m & ((1 << lhw) - 1);
+      pp = rem >> lw;
+      qq = rem & ((1 << lw) - 1);
+    } else {
+      const int hw = g.Ho * g.Wo;
+      n = m / hw;
+      const int rem = m - n * hw;
+      pp = rem / g.Wo;
+      qq = rem - pp * g.Wo;
+    }
+    const int h = pp * g.mul + g.off + r, w = qq * g.mul + g.off + s;
+    if ((unsigned)h >= (unsigned)g.Hs || (unsigned)w >= (unsigned)g.Ws) return make_uint4(0, 0, 0, 0);
+    return *(const uint4*)(src + (((int64_t)n * g.Hs + h) * g.Ws + w) * g.Cs + ci);
+  }
+  __device__ __forceinline__ void next() { k0 += BK; }
+};
+
+// TN slow path (stem): per-element column decode.
+template <typename T> struct LoaderIm2colSlowTN {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int BK = ImgTN<T>::BK, CPR = ImgTN<T>::CPR, RPP = 256 / CPR, NCH = BK / RPP;
+  const T* src;
+  GatherGeom g;
+  int k0, kend, tc0, ncols;
+  __device__ __forceinline__ void init(const T* src_, const GatherGeom& g_, int col0, int kbeg, int kend_) {
+    g = g_;
+    src = src_;
+    const int t = threadIdx.x;
+    tc0 = col0 + (t % CPR) * VEC;
+    ncols = g.R * g.S * g.Cs;
+    k0 = kbeg + t / CPR;
+    kend = kend_;
+  }
+  __device__ __forceinline__ uint4 load(int i) const {
+    const int m = k0 + RPP * i;
+    float f[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) f[e] = 0.f;
+    if (m < kend && tc0 < ncols) {
+      const int hw = g.Ho * g.Wo;
+      const int n = m / hw, rem = m - n * hw;
+      const int pp = rem / g.Wo, qq = rem - pp * g.Wo;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int tc = tc0 + e;
+        if (tc < ncols) {
+          const int tap = tc / g.Cs, ci = tc - tap * g.Cs;
+          const int rr = tap / g.S, ss = tap - rr * g.S;
+          const int h = pp * g.mul + g.off + rr, w = qq * g.mul + g.off + ss;
+          if ((unsigned)h < (unsigned)g.Hs && (unsigned)w < (unsigned)g.Ws)
+            f[e] = to_f32(src[(((int64_t)n * g.Hs + h) * g.Ws + w) * g.Cs + ci]);
+        }
+      }
+    }
+    return Vec16<T>::pack(f);
+  }
+  __device__ __forceinline__ void next() { k0 += BK; }
+};
+
+}  // namespace ieee

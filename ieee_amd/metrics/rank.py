@@ -1,0 +1,61 @@
+"""CMC / mAP on MI355X.  Mirrors torchreid/metrics/rank.py:246-287 (evaluate_rank ->
+evaluate_py -> eval_market1501 :103-171); the per-query ranking runs in
+ieee_rank_market1501 (no sort: each true match's rank is counted with a
+binary-search histogram over the streamed distance row)."""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _i32(x, name, device):
+    x = np.asarray(x.cpu() if isinstance(x, torch.Tensor) else x)
+    if x.size and (x.max() > np.iinfo(np.int32).max or x.min() < np.iinfo(np.int32).min):
+        raise ValueError("%s does not fit int32" % name)
+    return torch.from_numpy(np.ascontiguousarray(x.astype(np.int32))).to(device)
+
+
+def eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
+    """rank.py:103-171.  distmat: numpy array (as the reference's caller passes, engine.py:400) or a
+    CUDA tensor (on-device hand-off)."""
+    lib = _lib.require_gpu()
+    if isinstance(distmat, torch.Tensor):
+        d = distmat if distmat.is_cuda else distmat.cuda()
+    else:
+        d = torch.from_numpy(np.ascontiguousarray(distmat, dtype=np.float32)).cuda()
+    d = d.to(torch.float32)
+    if d.stride(-1) != 1:
+        d = d.contiguous()
+    num_q, num_g = d.shape
+    if num_g < max_rank:
+        max_rank = num_g
+        print('Note: number of gallery samples is quite small, got {}'.format(num_g))
+    dev = d.device
+    qp, gp = _i32(q_pids, "q_pids", dev), _i32(g_pids, "g_pids", dev)
+    qc, gc = _i32(q_camids, "q_camids", dev), _i32(g_camids, "g_camids", dev)
+    assert qp.numel() == num_q and qc.numel() == num_q and gp.numel() == num_g and gc.numel() == num_g
+    ap = torch.empty(num_q, dtype=torch.float64, device=dev)
+    first = torch.empty(num_q, dtype=torch.int32, device=dev)
+    summary = torch.empty(max_rank + 2, dtype=torch.int64, device=dev)
+    _lib.check(lib.ieee_rank_market1501(_lib.ptr(d), d.stride(0), num_q, num_g, _lib.ptr(qp), _lib.ptr(gp),
+                                        _lib.ptr(qc), _lib.ptr(gc), max_rank, _lib.ptr(ap), _lib.ptr(first),
+                                        _lib.ptr(summary), _lib.stream()))
+    s = summary.cpu().numpy()          # the evaluator's single read-back (22 words)
+    num_valid_q = float(s[max_rank])
+    assert num_valid_q > 0, 'Error: all query identities do not appear in gallery'
+    all_cmc = s[:max_rank].astype(np.float32) / np.float32(num_valid_q)     # rank.py:167-168
+    mAP = float(s[max_rank + 1:max_rank + 2].view(np.float64)[0] / num_valid_q)   # rank.py:169
+    return all_cmc, mAP
+
+
+def evaluate_py(distmat, q_pids, g_pids, q_camids, g_camids, max_rank, use_metric_cuhk03):
+    if use_metric_cuhk03:
+        # the reference's cuhk03 branch is itself broken (rank.py:237-239 passes 6 of 8 arguments)
+        raise NotImplementedError("cuhk03 single-gallery-shot protocol is out of scope (SURVEY.md §2 row 8)")
+    return eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank)
+
+
+def evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=20, use_metric_cuhk03=False,
+                  use_cython=True):
+    """rank.py:246-287.  `use_cython` is accepted and ignored, as in the reference (:278-287)."""
+    return evaluate_py(distmat, q_pids, g_pids, q_camids, g_camids, max_rank, use_metric_cuhk03)

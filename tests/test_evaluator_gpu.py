@@ -1,0 +1,135 @@
+"""GPU parity: ieee_sqeuclid_distmat / ieee_rank_market1501 (through the reference-shaped Python
+surface, which calls the C ABI) against the reference goldens and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import evaluator as ev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "evaluator_golden.npz"))
+
+
+def detie(d):
+    return (d + (np.arange(d.shape[1], dtype=np.float32) / 1024.0)[None, :]).astype(np.float32)
+
+
+@pytest.mark.parametrize("tag", ["B", "C"])
+def test_distmat_bit_exact_on_integer_grid(G, tag):
+    from ieee_amd.metrics import compute_distance_matrix
+    q = torch.from_numpy(G[tag + "_qf"].astype(np.float32))
+    g = torch.from_numpy(G[tag + "_gf"].astype(np.float32))
+    dm = compute_distance_matrix(q, g, "euclidean")
+    assert dm.device.type == "cpu" and dm.dtype == torch.float32       # CPU in -> CPU out, like the reference
+    assert np.array_equal(dm.numpy(), G[tag + "_dist"])
+    dm2 = compute_distance_matrix(q.cuda(), g.cuda())
+    assert dm2.is_cuda and np.array_equal(dm2.cpu().numpy(), G[tag + "_dist"])
+
+
+def test_distmat_float_and_cosine_tolerance(G):
+    from ieee_amd.metrics import compute_distance_matrix
+    q = torch.from_numpy(G["F_qf"].astype(np.float32))
+    g = torch.from_numpy(G["F_gf"].astype(np.float32))
+    dm = compute_distance_matrix(q, g).numpy()
+    np.testing.assert_allclose(dm, G["F_dist"], rtol=1e-5, atol=1e-3)   # tolerance: SURVEY §8c, 1e-5 rel
+    dc = compute_distance_matrix(q, g, "cosine").numpy()
+    np.testing.assert_allclose(dc, G["F_cos"], rtol=0, atol=2e-6)
+    with pytest.raises(ValueError):
+        compute_distance_matrix(q, g, "manhattan")
+    with pytest.raises(AssertionError):
+        compute_distance_matrix(q[0], g)
+
+
+@pytest.mark.parametrize("m,n,d", [(1, 1, 8), (5, 130, 24), (129, 257, 100), (300, 77, 2304), (64, 512, 772)])
+def test_distmat_ragged_shapes_vs_oracle(m, n, d):
+    from ieee_amd.metrics import compute_distance_matrix
+    rng = np.random.RandomState(m * 1000 + n)
+    q = rng.randint(-3, 4, size=(m, d)).astype(np.float32)
+    g = rng.randint(-3, 4, size=(n, d)).astype(np.float32)
+    dm = compute_distance_matrix(torch.from_numpy(q), torch.from_numpy(g)).numpy()
+    assert np.array_equal(dm, ev.sqeuclid_np(q, g))      # integer features: exact in any summation order
+
+
+def test_distmat_bf16_inputs():
+    from ieee_amd.metrics import compute_distance_matrix
+    rng = np.random.RandomState(3)
+    q = torch.from_numpy(np.abs(rng.randn(200, 768)).astype(np.float32)).cuda().bfloat16()
+    g = torch.from_numpy(np.abs(rng.randn(333, 768)).astype(np.float32)).cuda().bfloat16()
+    dm = compute_distance_matrix(q, g).cpu().numpy()
+    ref = ev.sqeuclid_np(q.float().cpu().numpy(), g.float().cpu().numpy())
+    np.testing.assert_allclose(dm, ref, rtol=1e-5, atol=2e-3)
+
+
+CASES = [("A", 5, False), ("B", 20, True), ("C", 20, True), ("D", 20, False), ("E", 20, False)]
+
+
+@pytest.mark.parametrize("tag,max_rank,tie", CASES)
+def test_rank_matches_reference_golden(G, tag, max_rank, tie):
+    from ieee_amd.metrics import evaluate_rank
+    d = G[tag + "_dist"]
+    if tie:
+        d = detie(d)
+    cmc, m_ap = evaluate_rank(d, G[tag + "_qp"], G[tag + "_gp"], G[tag + "_qc"], G[tag + "_gc"], max_rank=max_rank)
+    assert cmc.dtype == np.float32 and isinstance(m_ap, float)
+    assert np.array_equal(cmc, G[tag + "_cmc"])          # CMC bit-exact
+    assert abs(m_ap - float(G[tag + "_map"])) < 1e-12
+
+
+def test_rank_no_valid_query_raises(G):
+    from ieee_amd.metrics import evaluate_rank
+    with pytest.raises(AssertionError, match=str(G["G_msg"])):
+        evaluate_rank(G["E_dist"], G["E_qp"] + 100, G["E_gp"], G["E_qc"], G["E_gc"])
+
+
+@pytest.mark.parametrize("nq,ng,nid,seed", [(300, 3000, 150, 0), (64, 10007, 13, 1), (2000, 20000, 1000, 2)])
+def test_rank_vs_oracle_random(nq, ng, nid, seed):
+    from ieee_amd.metrics import evaluate_rank
+    rng = np.random.RandomState(seed)
+    d = (rng.rand(nq, ng) * 20).astype(np.float32)
+    qp, gp = rng.randint(0, nid, nq), rng.randint(0, nid, ng)
+    qc, gc = rng.randint(0, 4, nq), rng.randint(0, 4, ng)
+    cmc_o, map_o, ap_o = ev.rank_market1501_c(d, qp, gp, qc, gc, 20, return_all_ap=True)
+    cmc, m_ap = evaluate_rank(torch.from_numpy(d).cuda(), qp, gp, qc, gc)
+    assert np.array_equal(cmc, cmc_o)
+    assert abs(m_ap - map_o) < 1e-12
+
+
+def test_rank_many_matches_multibatch_and_ties():
+    """one identity owns 5000 gallery rows (> the 2048-key LDS batch) and distances have exact ties
+    (tie order = gallery index, the order the oracle's stable sort defines)."""
+    from ieee_amd.metrics import evaluate_rank
+    rng = np.random.RandomState(5)
+    nq, ng = 16, 9000
+    d = rng.randint(0, 50, size=(nq, ng)).astype(np.float32)
+    gp = rng.randint(1, 6, ng)
+    gp[:5000] = 0
+    rng.shuffle(gp)
+    qp = np.array([0, 1, 2, 3] * 4)
+    qc, gc = rng.randint(0, 3, nq), rng.randint(0, 3, ng)
+    cmc_o, map_o = ev.rank_market1501_c(d, qp, gp, qc, gc, 20)
+    cmc, m_ap = evaluate_rank(d, qp, gp, qc, gc)
+    assert np.array_equal(cmc, cmc_o)
+    assert abs(m_ap - map_o) < 1e-12
+
+
+def test_distmat_then_rank_device_pipeline_properties():
+    """size-independent properties at a larger size: every query also sits in the gallery under another
+    camera at distance 0 -> rank-1 = 1 and AP >= 1/n_match; distmat symmetric & zero diagonal."""
+    from ieee_amd.metrics import compute_distance_matrix, evaluate_rank
+    rng = np.random.RandomState(11)
+    ng, d = 4096, 768
+    gf = torch.from_numpy(rng.randint(0, 4, size=(ng, d)).astype(np.float32)).cuda()
+    gp = rng.randint(0, 500, ng)
+    gc = np.ones(ng, np.int64)
+    qf, qp, qc = gf[:512], gp[:512], np.zeros(512, np.int64)
+    dm = compute_distance_matrix(qf, gf)
+    assert torch.equal(dm[:, :512], dm[:, :512].t())
+    assert float(dm[:, :512].diagonal().abs().max()) == 0.0
+    cmc, m_ap = evaluate_rank(dm, qp, gp, qc, gc)
+    assert cmc[0] == 1.0 and np.all(np.diff(cmc) >= 0) and 0 < m_ap <= 1.0

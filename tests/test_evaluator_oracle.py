@@ -1,0 +1,78 @@
+"""CPU: the evaluator oracle against the golden vectors captured from the imported reference
+(tests/golden/gen_evaluator_golden.py) and against oracle/_ref (the reference's own Cython
+evaluator) when that has been built."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from oracle import evaluator as ev
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "evaluator_golden.npz"))
+
+
+def detie(d):
+    return (d + (np.arange(d.shape[1], dtype=np.float32) / 1024.0)[None, :]).astype(np.float32)
+
+
+CASES = [("A", 5, False), ("B", 20, True), ("C", 20, True), ("D", 20, False), ("E", 20, False)]
+
+
+@pytest.mark.parametrize("tag,max_rank,tie", CASES)
+@pytest.mark.parametrize("impl", ["np", "c"])
+def test_rank_oracle_matches_reference_golden(G, tag, max_rank, tie, impl):
+    d = G[tag + "_dist"]
+    if tie:
+        d = detie(d)
+    f = ev.rank_market1501_np if impl == "np" else ev.rank_market1501_c
+    cmc, m_ap = f(d, G[tag + "_qp"], G[tag + "_gp"], G[tag + "_qc"], G[tag + "_gc"], max_rank)
+    assert cmc.dtype == np.float32
+    assert np.array_equal(cmc, G[tag + "_cmc"])          # bit-exact CMC
+    assert abs(m_ap - float(G[tag + "_map"])) < 1e-12
+
+
+def test_rank_oracle_no_valid_query_raises(G):
+    with pytest.raises(AssertionError, match=str(G["G_msg"])):
+        ev.rank_market1501_c(G["E_dist"], G["E_qp"] + 100, G["E_gp"], G["E_qc"], G["E_gc"])
+    with pytest.raises(AssertionError):
+        ev.rank_market1501_np(G["E_dist"], G["E_qp"] + 100, G["E_gp"], G["E_qc"], G["E_gc"])
+
+
+@pytest.mark.parametrize("tag", ["B", "C"])
+def test_distmat_oracle_exact_on_integer_grid(G, tag):
+    dm = ev.sqeuclid_np(G[tag + "_qf"].astype(np.float32), G[tag + "_gf"].astype(np.float32))
+    assert np.array_equal(dm, G[tag + "_dist"])
+    assert np.array_equal(np.argsort(detie(dm)[0], kind="stable").astype(np.int32), G[tag + "_argsort0"])
+
+
+def test_distmat_oracle_float_tolerance(G):
+    q, g = G["F_qf"].astype(np.float32), G["F_gf"].astype(np.float32)
+    dm = ev.sqeuclid_np(q, g)
+    np.testing.assert_allclose(dm, G["F_dist"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(ev.cosine_np(q, g), G["F_cos"], rtol=0, atol=1e-6)
+
+
+def test_oracle_vs_reference_native_evaluator():
+    """oracle/_ref/rank_cy*.so is the reference's Cython evaluator built from its own source."""
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    so = [f for f in (os.listdir(here) if os.path.isdir(here) else []) if f.startswith("rank_cy") and f.endswith(".so")]
+    if not so:
+        pytest.skip("oracle/_ref not built (needs /root/reference; see oracle/build_ref.sh)")
+    spec = importlib.util.spec_from_file_location("rank_cy", os.path.join(here, so[0]))
+    rank_cy = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rank_cy)
+    rng = np.random.RandomState(7)
+    nq, ng = 120, 1500
+    d = (rng.rand(nq, ng) * 20).astype(np.float32)
+    qp, gp = rng.randint(0, 60, nq), rng.randint(0, 60, ng)
+    qc, gc = rng.randint(0, 4, nq), rng.randint(0, 4, ng)
+    cmc_ref, map_ref = rank_cy.evaluate_cy(d, qp, gp, qc, gc, 20, False)
+    cmc, m_ap = ev.rank_market1501_c(d, qp, gp, qc, gc, 20)
+    assert np.array_equal(cmc, cmc_ref)
+    assert abs(m_ap - float(map_ref)) < 1e-6      # the Cython path accumulates AP in float32
+    cmc32, map32 = ev.rank_market1501_c(d, qp, gp, qc, gc, 20, f32_accum=True)
+    assert abs(map32 - float(map_ref)) < 1e-6
