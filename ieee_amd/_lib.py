@@ -25,8 +25,16 @@ _SIGNATURES = {
                               c_void_p, c_void_p],
     "ieee_rank_market1501": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                              c_void_p, c_void_p, c_void_p, c_void_p],
+    "ieee_conv_packed_ld": [c_int, c_int64, c_int64, c_int64],
+    "ieee_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                              c_int64, c_void_p],
+    "ieee_conv2d_fwd": [c_void_p, c_void_p, c_void_p, c_int] + [c_int64] * 13 + [c_void_p],
+    "ieee_conv2d_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_int64] * 13 + [c_void_p],
+    "ieee_conv2d_wgrad_workspace_bytes": [c_int] + [c_int64] * 8,
+    "ieee_conv2d_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_int64] * 13 + [c_int, c_void_p],
 }
-_RESTYPE = {"ieee_last_error": ctypes.c_char_p}
+_RESTYPE = {"ieee_last_error": ctypes.c_char_p, "ieee_conv_packed_ld": c_int64,
+            "ieee_conv2d_wgrad_workspace_bytes": c_int64}
 
 
 class IeeeAmdError(RuntimeError):

@@ -1,0 +1,364 @@
+// Convolution as implicit GEMM over NHWC activations.
+//   forward : Y[pix][co]  = sum_{r,s,ci} X[gather(pix,r,s)][ci] * Wf[co][(r,s,ci)]
+//   dgrad   : dX[pix][ci] = sum_{r,s,co} dY[gather'(pix,r,s)][co] * Wd[ci][(r,s,co)]   (+ addend)
+//   wgrad   : dW[co][(r,s,ci)] = sum_pix dY[pix][co] * X[gather(pix,r,s)][ci]   (split-K slabs)
+// The three ResNet-50 streams (RGB / NI / TI) are independent and run as one
+// launch: blockIdx.y = modality, pointers advance by per-modality strides.
+// Replaces torch's conv2d / conv2d backward as dispatched from the reference's
+// torchreid/models/resnet.py:164-184,622-631 and ieee3modalPart.py:427-435.
+#include "gemm_core.h"
+
+namespace ieee {
+
+__device__ __forceinline__ void tile_map_xy(int tiles_m, int tiles_n, int group, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int per = group * tiles_n;
+  const int gi = wg / per, first = gi * group;
+  const int gsz = min(tiles_m - first, group);
+  const int in = wg - gi * per;
+  tm = first + in % gsz;
+  tn = in / gsz;
+}
+
+// C[m][n..n+3] store with optional residual addend (same layout/dtype as the output).
+template <typename T> struct StoreEpi {
+  T* out;
+  const T* addend;
+  int64_t ld;
+  int M, N;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    if (m >= M || n >= N) return;
+    T* o = out + (int64_t)m * ld + n;
+    if (n + 3 < N) {
+      if (addend != nullptr) {
+        const T* a = addend + (int64_t)m * ld + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += to_f32(a[r]);
+      }
+      if constexpr (sizeof(T) == 4) {
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        *(uint2*)o = make_uint2(Vec16<bf16>::pk(v[0], v[1]), Vec16<bf16>::pk(v[2], v[3]));
+      }
+    } else {
+      for (int r = 0; r < 4 && n + r < N; ++r) {
+        float x = v[r];
+        if (addend != nullptr) x += to_f32(addend[(int64_t)m * ld + n + r]);
+        o[r] = from_f32<T>(x);
+      }
+    }
+  }
+};
+
+struct SlabEpi {
+  float* out;
+  int64_t ld;
+  int M, N;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
+    if (m >= M || n >= N) return;
+    float* o = out + (int64_t)m * ld + n;
+    if (n + 3 < N && (ld & 3) == 0) {
+      *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int r = 0; r < 4 && n + r < N; ++r) o[r] = v[r];
+    }
+  }
+};
+
+struct ConvArgs {
+  GatherGeom g;
+  int M, N;          // GEMM rows (pixels) / cols (output channels of this GEMM)
+  int ldw, ktiles;   // packed-weight row length (elements), number of k-tiles
+  int tiles_m, tiles_n;
+  int64_t src_gs, w_gs, dst_gs;   // per-modality strides (elements)
+};
+
+// forward and dgrad share this kernel (they differ only in the gather geometry)
+template <typename T, int BN, bool SLOW>
+__global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
+                                                          T* __restrict__ dst, const T* __restrict__ addend,
+                                                          ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  tile_map_xy(a.tiles_m, a.tiles_n, 8, tm, tn);
+  const int m0 = tm * 128, n0 = tn * BN;
+  const int z = blockIdx.y;
+  src += z * a.src_gs;
+  w += z * a.w_gs;
+  dst += z * a.dst_gs;
+  if (addend != nullptr) addend += z * a.dst_gs;
+  LoaderPlainNT<T, BN / 32> lb;
+  lb.init(w, a.ldw, n0, a.N, a.ldw);
+  StoreEpi<T> epi{dst, addend, a.N, a.M, a.N};
+  if constexpr (SLOW) {
+    LoaderIm2colSlowNT<T, 4> la;
+    la.init(src, a.g, m0);
+    gemm_nt<T, 128, BN>(la, lb, epi, a.ktiles, m0, n0, smem);
+  } else {
+    LoaderIm2colNT<T, 4> la;
+    la.init(src, a.g, m0);
+    gemm_nt<T, 128, BN>(la, lb, epi, a.ktiles, m0, n0, smem);
+  }
+}
+
+struct WgradArgs {
+  GatherGeom g;       // forward geometry of the conv
+  int Co, ncols;      // GEMM M (= Cout), N (= R*S*Cin)
+  int npix, kchunk;   // GEMM K (= N*Ho*Wo) and the K range per split
+  int tiles_n;
+  int64_t dy_gs, x_gs, slab_gs;   // per-modality strides; slab_gs covers all splits of one modality
+};
+
+template <typename T, bool SLOW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         float* __restrict__ slab, WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tm = blockIdx.x / a.tiles_n, tn = blockIdx.x % a.tiles_n;
+  const int ks = blockIdx.y, z = blockIdx.z;
+  const int m0 = tm * 128, n0 = tn * 128;
+  dy += z * a.dy_gs;
+  x += z * a.x_gs;
+  slab += z * a.slab_gs + (int64_t)ks * a.Co * a.ncols;
+  const int kbeg = ks * a.kchunk, kend = min(a.npix, kbeg + a.kchunk);
+  const int ktiles = (kend - kbeg + ImgTN<T>::BK - 1) / ImgTN<T>::BK;
+  LoaderColsTN<T> la;
+  la.init(dy, a.Co, m0, a.Co, kbeg, kend);
+  SlabEpi epi{slab, a.ncols, a.Co, a.ncols};
+  if constexpr (SLOW) {
+    LoaderIm2colSlowTN<T> lb;
+    lb.init(x, a.g, n0, kbeg, kend);
+    gemm_tn<T>(la, lb, epi, ktiles, m0, n0, smem);
+  } else {
+    LoaderIm2colTN<T> lb;
+    lb.init(x, a.g, n0, kbeg, kend);
+    gemm_tn<T>(la, lb, epi, ktiles, m0, n0, smem);
+  }
+}
+
+// dW[z][co][ci][r][s] (OIHW fp32, the reference's parameter layout) = sum over splits of
+// slab[z][ks][co][(r*S+s)*Ci + ci]; deterministic (fixed summation order).
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splitk, int Co,
+                                    int Ci, int RS, int64_t slab_gs, int64_t dw_gs, int accumulate) {
+  const int z = blockIdx.y;
+  const int64_t total = (int64_t)Co * Ci * RS;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int rs = (int)(i % RS);
+  const int64_t t = i / RS;
+  const int ci = (int)(t % Ci);
+  const int co = (int)(t / Ci);
+  const float* s = slab + z * slab_gs + (int64_t)co * (RS * Ci) + (int64_t)rs * Ci + ci;
+  const int64_t stride = (int64_t)Co * Ci * RS;
+  float acc = 0.f;
+  for (int k = 0; k < splitk; ++k) acc += s[k * stride];
+  float* o = dw + z * dw_gs + i;
+  *o = accumulate ? (*o + acc) : acc;
+}
+
+// Weight packing from the reference's fp32 OIHW parameters:
+//  mode 0 (forward): dst[co][(r*S+s)*Ci + ci]  row length ld (zero padded)
+//  mode 1 (dgrad)  : dst[ci][(r*S+s)*Co + co]  row length ld
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Co, int Ci, int R, int S,
+                                   int ld, int mode, int64_t w_gs, int64_t dst_gs) {
+  const int z = blockIdx.y;
+  const int rows = mode == 0 ? Co : Ci;
+  const int64_t total = (int64_t)rows * ld;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int row = (int)(i / ld), col = (int)(i % ld);
+  const int inner = mode == 0 ? Ci : Co;
+  float v = 0.f;
+  if (col < R * S * inner) {
+    const int tap = col / inner, c = col % inner;
+    const int co = mode == 0 ? row : c, ci = mode == 0 ? c : row;
+    v = w[z * w_gs + ((int64_t)co * Ci + ci) * (R * S) + tap];
+  }
+  dst[z * dst_gs + i] = from_f32<T>(v);
+}
+
+template <typename T> static int conv_bk() { return ImgNT<T>::BK; }
+
+template <typename T>
+static int launch_gather(const T* src, const T* w, T* dst, const T* addend, const GatherGeom& g, int M, int N,
+                         int Ktrue, int ldw, int groups, int64_t src_gs, int64_t w_gs, int64_t dst_gs, bool slow,
+                         hipStream_t st) {
+  const int BK = ImgNT<T>::BK;
+  ConvArgs a;
+  a.g = g;
+  a.M = M;
+  a.N = N;
+  a.ldw = ldw;
+  a.ktiles = cdiv(Ktrue, BK);
+  a.src_gs = src_gs;
+  a.w_gs = w_gs;
+  a.dst_gs = dst_gs;
+  a.tiles_m = cdiv(M, 128);
+  const bool narrow = N <= 64;
+  a.tiles_n = cdiv(N, narrow ? 64 : 128);
+  dim3 grid(a.tiles_m * a.tiles_n, groups);
+  const size_t smem = narrow ? 2 * (128 + 64) * 128 : 2 * 256 * 128;
+  if (narrow) {
+    if (slow) conv_gather_kernel<T, 64, true><<<grid, 256, smem, st>>>(src, w, dst, addend, a);
+    else conv_gather_kernel<T, 64, false><<<grid, 256, smem, st>>>(src, w, dst, addend, a);
+  } else {
+    if (slow) conv_gather_kernel<T, 128, true><<<grid, 256, smem, st>>>(src, w, dst, addend, a);
+    else conv_gather_kernel<T, 128, false><<<grid, 256, smem, st>>>(src, w, dst, addend, a);
+  }
+  return launch_status("conv_gather_kernel");
+}
+
+}  // namespace ieee
+
+using namespace ieee;
+
+namespace {
+struct Dims {
+  int N, Hi, Wi, Ci, Co, R, S, stride, pad, Ho, Wo;
+};
+int check_dims(const char* what, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+               int64_t stride, int64_t pad, Dims* d) {
+  IEEE_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Ci > 0 && Co > 0 && R > 0 && S > 0, "%s: non-positive dimension", what);
+  IEEE_REQUIRE(stride == 1 || stride == 2, "%s: stride %ld unsupported (1 or 2)", what, (long)stride);
+  IEEE_REQUIRE(pad >= 0 && pad <= R / 2 + 3, "%s: bad padding", what);
+  d->N = (int)N; d->Hi = (int)Hi; d->Wi = (int)Wi; d->Ci = (int)Ci; d->Co = (int)Co;
+  d->R = (int)R; d->S = (int)S; d->stride = (int)stride; d->pad = (int)pad;
+  d->Ho = (int)((Hi + 2 * pad - R) / stride + 1);
+  d->Wo = (int)((Wi + 2 * pad - S) / stride + 1);
+  IEEE_REQUIRE(d->Ho > 0 && d->Wo > 0, "%s: empty output", what);
+  IEEE_REQUIRE((int64_t)N * d->Ho * d->Wo < (1ll << 31) && (int64_t)N * Hi * Wi < (1ll << 31), "%s: too many pixels",
+               what);
+  return IEEE_OK;
+}
+int elem_bk(int dtype) { return dtype == IEEE_BF16 ? 64 : 32; }
+int elem_vec(int dtype) { return dtype == IEEE_BF16 ? 8 : 4; }
+}  // namespace
+
+extern "C" int64_t ieee_conv_packed_ld(int dtype, int64_t inner_channels, int64_t R, int64_t S) {
+  const int64_t K = R * S * inner_channels, bk = elem_bk(dtype);
+  return (K + bk - 1) / bk * bk;
+}
+
+extern "C" int ieee_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int mode, int64_t groups, int64_t Co,
+                                     int64_t Ci, int64_t R, int64_t S, int64_t w_gs, int64_t dst_gs, void* stream) {
+  IEEE_REQUIRE(w_oihw && dst, "pack_conv_weight: null pointer");
+  IEEE_REQUIRE(mode == 0 || mode == 1, "pack_conv_weight: mode must be 0 (forward) or 1 (dgrad)");
+  IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "pack_conv_weight: bad dtype");
+  const int64_t ld = ieee_conv_packed_ld(dtype, mode == 0 ? Ci : Co, R, S);
+  const int64_t rows = mode == 0 ? Co : Ci;
+  dim3 grid(cdiv(rows * ld, 256), (unsigned)groups);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IEEE_F32)
+    pack_weight_kernel<float><<<grid, 256, 0, st>>>(w_oihw, (float*)dst, (int)Co, (int)Ci, (int)R, (int)S, (int)ld,
+                                                    mode, w_gs, dst_gs);
+  else
+    pack_weight_kernel<bf16><<<grid, 256, 0, st>>>(w_oihw, (bf16*)dst, (int)Co, (int)Ci, (int)R, (int)S, (int)ld, mode,
+                                                   w_gs, dst_gs);
+  return launch_status("pack_weight_kernel");
+}
+
+extern "C" int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N,
+                               int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride,
+                               int64_t pad, int64_t x_gs, int64_t w_gs, int64_t y_gs, void* stream) {
+  IEEE_REQUIRE(x && w_packed && y, "conv2d_fwd: null pointer");
+  Dims d;
+  IEEE_TRY(check_dims("conv2d_fwd", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
+  IEEE_REQUIRE(Co % 4 == 0, "conv2d_fwd: Cout %ld must be a multiple of 4", (long)Co);
+  GatherGeom g{d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.R, d.S, d.stride, -d.pad, +1, 1, d.N * d.Ho * d.Wo};
+  const bool slow = (Ci % elem_bk(dtype)) != 0;
+  const int ldw = (int)ieee_conv_packed_ld(dtype, Ci, R, S);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IEEE_F32)
+    return launch_gather<float>((const float*)x, (const float*)w_packed, (float*)y, nullptr, g, g.npix, d.Co,
+                                d.R * d.S * d.Ci, ldw, (int)groups, x_gs, w_gs, y_gs, slow, st);
+  if (dtype == IEEE_BF16)
+    return launch_gather<bf16>((const bf16*)x, (const bf16*)w_packed, (bf16*)y, nullptr, g, g.npix, d.Co,
+                               d.R * d.S * d.Ci, ldw, (int)groups, x_gs, w_gs, y_gs, slow, st);
+  IEEE_REQUIRE(false, "conv2d_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
+                                 int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
+                                 int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
+                                 void* stream) {
+  IEEE_REQUIRE(dy && w_packed_d && dx, "conv2d_dgrad: null pointer");
+  Dims d;
+  IEEE_TRY(check_dims("conv2d_dgrad", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
+  IEEE_REQUIRE(Co % elem_bk(dtype) == 0, "conv2d_dgrad: Cout %ld must be a multiple of %d", (long)Co, elem_bk(dtype));
+  IEEE_REQUIRE(Ci % 4 == 0, "conv2d_dgrad: Cin %ld must be a multiple of 4", (long)Ci);
+  // rows = input pixels; source = dY [N,Ho,Wo,Co]; h_dy = (hi + pad - r) / stride
+  GatherGeom g{d.Ho, d.Wo, d.Co, d.Hi, d.Wi, d.R, d.S, 1, d.pad, -1, d.stride, d.N * d.Hi * d.Wi};
+  const int ldw = (int)ieee_conv_packed_ld(dtype, Co, R, S);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IEEE_F32)
+    return launch_gather<float>((const float*)dy, (const float*)w_packed_d, (float*)dx, (const float*)addend, g,
+                                g.npix, d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st);
+  if (dtype == IEEE_BF16)
+    return launch_gather<bf16>((const bf16*)dy, (const bf16*)w_packed_d, (bf16*)dx, (const bf16*)addend, g, g.npix,
+                               d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st);
+  IEEE_REQUIRE(false, "conv2d_dgrad: bad dtype %d", dtype);
+}
+
+// split-K heuristic shared by the workspace query and the launch
+static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups, int dtype) {
+  const int64_t tiles = ((Co + 127) / 128) * ((ncols + 127) / 128) * groups;
+  const int64_t bk = elem_bk(dtype);
+  int64_t want = (1536 + tiles - 1) / tiles;                 // aim at >= ~1536 workgroups
+  const int64_t maxsplit = (npix + 4 * bk - 1) / (4 * bk);   // at least 4 k-tiles per split
+  if (want > maxsplit) want = maxsplit;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  return (int)want;
+}
+
+extern "C" int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, int64_t N, int64_t Ho, int64_t Wo,
+                                                     int64_t Ci, int64_t Co, int64_t R, int64_t S) {
+  const int64_t npix = N * Ho * Wo, ncols = R * S * Ci;
+  return (int64_t)wgrad_splitk(npix, Co, ncols, groups, dtype) * groups * Co * ncols * 4;
+}
+
+extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
+                                 int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+                                 int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs,
+                                 int accumulate, void* stream) {
+  IEEE_REQUIRE(dy && x && dw_oihw && work, "conv2d_wgrad: null pointer");
+  Dims d;
+  IEEE_TRY(check_dims("conv2d_wgrad", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
+  IEEE_REQUIRE(Co % elem_vec(dtype) == 0, "conv2d_wgrad: Cout must be a multiple of %d", elem_vec(dtype));
+  WgradArgs a;
+  a.g = GatherGeom{d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.R, d.S, d.stride, -d.pad, +1, 1, d.N * d.Ho * d.Wo};
+  a.Co = d.Co;
+  a.ncols = d.R * d.S * d.Ci;
+  a.npix = a.g.npix;
+  const int splitk = wgrad_splitk(a.npix, d.Co, a.ncols, groups, dtype);
+  const int bk = elem_bk(dtype);
+  a.kchunk = cdiv(cdiv(a.npix, splitk), bk) * bk;
+  const int nsplit = cdiv(a.npix, a.kchunk);
+  a.tiles_n = cdiv(a.ncols, 128);
+  a.dy_gs = dy_gs;
+  a.x_gs = x_gs;
+  a.slab_gs = (int64_t)nsplit * d.Co * a.ncols;
+  const bool slow = (Ci % elem_vec(dtype)) != 0;
+  dim3 grid(cdiv(d.Co, 128) * a.tiles_n, nsplit, (unsigned)groups);
+  const size_t smem = 64 * 1024;
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)work;
+  if (dtype == IEEE_F32) {
+    if (slow) conv_wgrad_kernel<float, true><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
+    else conv_wgrad_kernel<float, false><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
+  } else if (dtype == IEEE_BF16) {
+    if (slow) conv_wgrad_kernel<bf16, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
+    else conv_wgrad_kernel<bf16, false><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
+  } else {
+    IEEE_REQUIRE(false, "conv2d_wgrad: bad dtype %d", dtype);
+  }
+  IEEE_TRY(launch_status("conv_wgrad_kernel"));
+  const int64_t total = (int64_t)d.Co * d.Ci * d.R * d.S;
+  dim3 rgrid(cdiv(total, 256), (unsigned)groups);
+  wgrad_reduce_kernel<<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs,
+                                             accumulate);
+  return launch_status("wgrad_reduce_kernel");
+}

@@ -69,6 +69,44 @@ int ieee_rank_market1501(const float* distmat, int64_t ldd, int64_t num_q, int64
                          const int32_t* g_camids, int64_t max_rank, double* ap, int32_t* first_pos,
                          int64_t* summary, void* stream);
 
+/* ---- convolution as implicit GEMM over NHWC (MFMA) ------------------------ */
+/* These replace torch's conv2d forward / backward as dispatched by the
+ * reference's Bottleneck.forward (torchreid/models/resnet.py:164-184), the
+ * ResNetIEEE stem (:496-501, :622-631) and the CIM 1x1 convs
+ * (torchreid/models/ieee3modalPart.py:28-48, 427-435).  `groups` independent
+ * problems (the three modality streams) run in one launch; *_gs are the
+ * per-group strides in ELEMENTS.  dtype IEEE_F32 (exact fp32 MFMA, parity
+ * mode) or IEEE_BF16 (bf16 storage, fp32 accumulate).  Activations NHWC. */
+
+/* row length (elements) of a packed weight matrix: R*S*inner rounded up to the k-tile */
+int64_t ieee_conv_packed_ld(int dtype, int64_t inner_channels, int64_t R, int64_t S);
+
+/* fp32 OIHW parameters (the reference's state_dict layout) -> GEMM operand.
+ * mode 0: forward  dst[co][(r*S+s)*Ci+ci]; mode 1: dgrad dst[ci][(r*S+s)*Co+co] */
+int ieee_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int mode, int64_t groups, int64_t Co,
+                          int64_t Ci, int64_t R, int64_t S, int64_t w_gs, int64_t dst_gs, void* stream);
+
+/* y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w), no bias (every conv on the path is bias-free) */
+int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N,
+                    int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride,
+                    int64_t pad, int64_t x_gs, int64_t w_gs, int64_t y_gs, void* stream);
+
+/* dx[N,Hi,Wi,Ci] = conv_transpose(dy) (+ addend, same layout as dx, may be NULL): the
+ * residual-branch gradient of Bottleneck (resnet.py:181 `out += identity`) is folded in here */
+int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
+                      int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
+                      int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
+                      void* stream);
+
+/* dw (fp32, OIHW, the layout of param.grad) = or += sum over pixels; deterministic split-K:
+ * partial slabs in `work` (size from the query below) are reduced in a fixed order */
+int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, int64_t N, int64_t Ho, int64_t Wo,
+                                          int64_t Ci, int64_t Co, int64_t R, int64_t S);
+int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
+                      int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+                      int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs, int accumulate,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif
