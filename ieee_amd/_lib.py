@@ -16,25 +16,41 @@ c_void_p, c_int, c_int64, c_float, c_double = (ctypes.c_void_p, ctypes.c_int, ct
 
 IEEE_F32, IEEE_BF16 = 0, 1
 
-# name -> argtypes (restype is int unless listed in _RESTYPE)
-_SIGNATURES = {
-    "ieee_last_error": [],
-    "ieee_version": [],
-    "ieee_device_is_gfx950": [],
-    "ieee_sqeuclid_distmat": [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_int64,
-                              c_void_p, c_void_p],
-    "ieee_rank_market1501": [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                             c_void_p, c_void_p, c_void_p, c_void_p],
-    "ieee_conv_packed_ld": [c_int, c_int64, c_int64, c_int64],
-    "ieee_pack_conv_weight": [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
-                              c_int64, c_void_p],
-    "ieee_conv2d_fwd": [c_void_p, c_void_p, c_void_p, c_int] + [c_int64] * 13 + [c_void_p],
-    "ieee_conv2d_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_int64] * 13 + [c_void_p],
-    "ieee_conv2d_wgrad_workspace_bytes": [c_int] + [c_int64] * 8,
-    "ieee_conv2d_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_int64] * 13 + [c_int, c_void_p],
-}
-_RESTYPE = {"ieee_last_error": ctypes.c_char_p, "ieee_conv_packed_ld": c_int64,
-            "ieee_conv2d_wgrad_workspace_bytes": c_int64}
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ieee_amd.h")
+
+_CTYPE = {"int": c_int, "int64_t": c_int64, "float": c_float, "double": c_double}
+
+
+def _parse_header(path=HEADER_PATH):
+    """include/ieee_amd.h is the single source of truth: every prototype there becomes a ctypes
+    signature here (pointers -> void*, scalars by name), so the binding cannot drift from the ABI."""
+    import re
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"^\s*#.*$", "", txt, flags=re.M)
+    sigs, res = {}, {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(ieee_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        argt = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argt.append(c_void_p)
+                else:
+                    base = a.replace("const", "").split()[0]
+                    argt.append(_CTYPE[base])
+        sigs[name] = argt
+        if "char" in ret and "*" in ret:
+            res[name] = ctypes.c_char_p
+        elif "*" in ret:
+            res[name] = c_void_p
+        else:
+            res[name] = _CTYPE[ret.replace("const", "").split()[0]]
+    return sigs, res
+
+
+_SIGNATURES, _RESTYPE = _parse_header()
 
 
 class IeeeAmdError(RuntimeError):

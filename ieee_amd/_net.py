@@ -1,0 +1,71 @@
+"""Host-side handle of the native layer-graph executor (ieee_net_* in include/ieee_amd.h)."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class NativeNet:
+    """One executor instance = fixed (batch, image size, dtype, ablation flags).  Owns the workspace
+    tensor; parameters / gradients / running statistics stay in the model's flat buffers."""
+
+    def __init__(self, model, batch, height, width, dtype):
+        lib = _lib.require_gpu()
+        self.lib = lib
+        self.batch, self.height, self.width, self.dtype = batch, height, width, dtype
+        self.num_classes = model.num_classes
+        self.handle = ctypes.c_void_p()
+        dt = _lib.IEEE_BF16 if dtype == torch.bfloat16 else _lib.IEEE_F32
+        _lib.check(lib.ieee_net_create(batch, height, width, model.num_classes, dt, int(model.interaction),
+                                       int(model.attention), int(model.using_REM), ctypes.byref(self.handle)))
+        n = lib.ieee_net_num_slots(self.handle)
+        names = [lib.ieee_net_slot_name(self.handle, i).decode() for i in range(n)]
+        offs = (ctypes.c_int64 * n)()
+        for i, name in enumerate(names):
+            if name not in model._offsets:
+                raise KeyError("executor needs tensor %r which the model does not own" % name)
+            offs[i] = model._offsets[name]
+        self._flat = (model._flat_params, model._flat_grads, model._flat_buffers)   # keep alive
+        _lib.check(lib.ieee_net_bind(self.handle, _lib.ptr(model._flat_params), _lib.ptr(model._flat_grads),
+                                     _lib.ptr(model._flat_buffers), offs, n))
+        nbytes = lib.ieee_net_workspace_bytes(self.handle)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=model._flat_params.device)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.ieee_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def forward(self, xs, training):
+        B = self.batch
+        dev = self.workspace.device
+        xs = [x.to(device=dev, dtype=torch.float32).contiguous() for x in xs]
+        if training:
+            logits = torch.empty((18, B, self.num_classes), dtype=torch.float32, device=dev)
+            feats = torch.empty((3, B, 768), dtype=torch.float32, device=dev)
+        else:
+            logits = None
+            feats = torch.empty((B, 2304), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.ieee_net_forward(self.handle, _lib.ptr(self.workspace), _lib.ptr(xs[0]), _lib.ptr(xs[1]),
+                                             _lib.ptr(xs[2]), 1 if training else 0, _lib.ptr(logits),
+                                             _lib.ptr(feats), _lib.stream()))
+        return logits, feats
+
+    def backward(self, dlogits, dfeats):
+        dlogits = dlogits.to(torch.float32).contiguous()
+        dfeats = dfeats.to(torch.float32).contiguous()
+        _lib.check(self.lib.ieee_net_backward(self.handle, _lib.ptr(self.workspace), _lib.ptr(dlogits),
+                                              _lib.ptr(dfeats), _lib.stream()))
+
+    def tensor(self, name):
+        """a named intermediate as a torch view of the workspace (parity tests / debugging)"""
+        off, numel, dt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        _lib.check(self.lib.ieee_net_tensor(self.handle, name.encode(), ctypes.byref(off), ctypes.byref(numel),
+                                            ctypes.byref(dt)))
+        tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.uint8}[dt.value]
+        nbytes = numel.value * torch.empty((), dtype=tdt).element_size()
+        return self.workspace[off.value:off.value + nbytes].view(tdt)

@@ -1,0 +1,335 @@
+// Train/eval BatchNorm2d (+ReLU, +residual) over NHWC maps [M = N*H*W][C], forward and backward,
+// batched over `groups` (the three modality streams): pointer = base + group * stride.
+// Semantics: torch.nn.BatchNorm2d defaults as used by the reference (torchreid/models/resnet.py:151,
+// 164-184; ieee3modalPart.py:38): eps 1e-5, momentum 0.1, biased variance for normalisation,
+// unbiased for the running estimate.  HBM-bound streaming kernels, 16 bytes per lane.
+#include "common.h"
+
+namespace ieee {
+
+constexpr int RED_MAX_BLOCKS = 1536;
+
+struct RedGeom {
+  int M, C;        // rows, channels
+  int cprw;        // 16-byte chunks per row
+  int tx, ty;      // block = tx (chunk lanes) * ty (row lanes) = 256
+  int cblocks;     // column blocks
+  int rblocks;     // row blocks
+  int rows_per_block;
+};
+
+static RedGeom red_geom(int64_t M, int C, int vec) {
+  RedGeom g;
+  g.M = (int)M;
+  g.C = C;
+  g.cprw = C / vec;
+  g.tx = g.cprw < 64 ? g.cprw : 64;
+  // tx must divide 256: round down to a power of two that divides cprw
+  int tx = 1;
+  while (tx * 2 <= g.tx && g.cprw % (tx * 2) == 0) tx *= 2;
+  g.tx = tx;
+  g.ty = 256 / g.tx;
+  g.cblocks = cdiv(g.cprw, g.tx);
+  int rb = RED_MAX_BLOCKS / g.cblocks;
+  if (rb < 1) rb = 1;
+  const int maxrb = cdiv(M, g.ty * 4);   // at least ~4 rows per thread
+  if (rb > maxrb) rb = maxrb;
+  if (rb < 1) rb = 1;
+  g.rows_per_block = cdiv(cdiv(M, rb), g.ty) * g.ty;
+  g.rblocks = cdiv(M, g.rows_per_block);
+  return g;
+}
+
+// Generic per-channel reduction of NQ quantities; F(values...) fills q[NQ][VEC] increments.
+// partial layout: [group][rblock][NQ][C]
+template <typename T, int NQ, class F>
+__device__ __forceinline__ void reduce_channels(const RedGeom& g, float* partial, int64_t partial_gs, F f) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[256 * 8];   // ty rows of (tx * VEC) floats, one quantity at a time
+  const int t = threadIdx.x;
+  const int tx = t % g.tx, ty = t / g.tx;
+  const int cb = blockIdx.x % g.cblocks, rb = blockIdx.x / g.cblocks;
+  const int chunk = cb * g.tx + tx;
+  float acc[NQ][VEC];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[q][e] = 0.f;
+  if (chunk < g.cprw) {
+    const int r0 = rb * g.rows_per_block;
+    const int r1 = min(g.M, r0 + g.rows_per_block);
+    for (int r = r0 + ty; r < r1; r += g.ty) f((int64_t)r * g.C + chunk * VEC, chunk * VEC, acc);
+  }
+  // cross-row (ty) reduction through LDS, one quantity at a time to bound LDS use
+  float* out = partial + blockIdx.y * partial_gs + (int64_t)rb * NQ * g.C;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[(ty * g.tx + tx) * VEC + e] = acc[q][e];
+    __syncthreads();
+    // threads 0 .. tx*VEC-1 each own one channel of this column block
+    if (t < g.tx * VEC) {
+      const int ltx = t / VEC, e = t % VEC;
+      float s = 0.f;
+      for (int y = 0; y < g.ty; ++y) s += red[(y * g.tx + ltx) * VEC + e];
+      const int c = (cb * g.tx + ltx) * VEC + e;
+      if (c < g.C) out[q * g.C + c] = s;
+    }
+  }
+}
+
+// ---- forward statistics: sum(y), sum(y^2)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, int64_t y_gs, RedGeom g,
+                                                       float* partial, int64_t partial_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const T* yy = y + blockIdx.y * y_gs;
+  reduce_channels<T, 2>(g, partial, partial_gs, [&](int64_t off, int c0, float (*acc)[VEC]) {
+    float v[VEC];
+    Vec16<T>::unpack(*(const uint4*)(yy + off), v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { acc[0][e] += v[e]; acc[1][e] += v[e] * v[e]; }
+  });
+}
+
+// mean / invstd / scale / shift + running-stat update (train) or scale/shift from running stats (eval)
+// stats layout per group: [4][C] = mean, invstd, scale, shift
+__global__ void bn_finalize_kernel(const float* partial, int64_t partial_gs, int rblocks, int M, int C,
+                                   const float* gamma, const float* beta, int64_t param_gs, float* running_mean,
+                                   float* running_var, int64_t buf_gs, float* stats, int64_t stats_gs, float momentum,
+                                   float eps, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int z = blockIdx.y;
+  const float ga = gamma[z * param_gs + c], be = beta[z * param_gs + c];
+  float* st = stats + z * stats_gs;
+  float mean, invstd;
+  if (training) {
+    const float* p = partial + z * partial_gs;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rblocks; ++r) { s1 += p[(int64_t)r * 2 * C + c]; s2 += p[(int64_t)r * 2 * C + C + c]; }
+    const double mu = s1 / M;
+    double var = s2 / M - mu * mu;
+    if (var < 0) var = 0;
+    mean = (float)mu;
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr) {
+      float* rm = running_mean + z * buf_gs + c;
+      float* rv = running_var + z * buf_gs + c;
+      const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+      *rm = (1.f - momentum) * (*rm) + momentum * mean;
+      *rv = (1.f - momentum) * (*rv) + momentum * (float)unbiased;
+    }
+  } else {
+    mean = running_mean[z * buf_gs + c];
+    invstd = 1.0f / sqrtf(running_var[z * buf_gs + c] + eps);
+  }
+  st[c] = mean;
+  st[C + c] = invstd;
+  const float sc = ga * invstd;
+  st[2 * C + c] = sc;
+  st[3 * C + c] = be - mean * sc;
+}
+
+// a = [relu]( y*scale + shift [+ residual] )
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ residual,
+                                                       T* __restrict__ out, const float* __restrict__ stats,
+                                                       int64_t stats_gs, int64_t total_chunks, int cprw, int C,
+                                                       int64_t gs, int relu) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  const float* sc = stats + z * stats_gs + 2 * C;
+  const float* sh = sc + C;
+  const T* yy = y + z * gs;
+  const T* rr = residual ? residual + z * gs : nullptr;
+  T* oo = out + z * gs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cprw) * VEC;
+    float v[VEC], r[VEC];
+    Vec16<T>::unpack(*(const uint4*)(yy + i * VEC), v);
+    if (rr) Vec16<T>::unpack(*(const uint4*)(rr + i * VEC), r);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float x = v[e] * sc[c0 + e] + sh[c0 + e];
+      if (rr) x += r[e];
+      if (relu) x = fmaxf(x, 0.f);
+      v[e] = x;
+    }
+    *(uint4*)(oo + i * VEC) = Vec16<T>::pack(v);
+  }
+}
+
+// ---- backward reductions: s1 = sum(g), s2 = sum(g*y) with g = da * [a > 0] (mask optional)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ a,
+                                                            const T* __restrict__ y, int64_t gs, RedGeom g,
+                                                            float* partial, int64_t partial_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const T* dd = da + blockIdx.y * gs;
+  const T* aa = a ? a + blockIdx.y * gs : nullptr;
+  const T* yy = y + blockIdx.y * gs;
+  reduce_channels<T, 2>(g, partial, partial_gs, [&](int64_t off, int c0, float (*acc)[VEC]) {
+    float d[VEC], m[VEC], v[VEC];
+    Vec16<T>::unpack(*(const uint4*)(dd + off), d);
+    Vec16<T>::unpack(*(const uint4*)(yy + off), v);
+    if (aa) {
+      Vec16<T>::unpack(*(const uint4*)(aa + off), m);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d[e] = m[e] > 0.f ? d[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { acc[0][e] += d[e]; acc[1][e] += d[e] * v[e]; }
+  });
+}
+
+// dgamma = sum(g*xhat), dbeta = sum(g);  coefficients of dy = k1*g + k2*y + k3
+// coef layout per group: [3][C]
+__global__ void bn_bwd_finalize_kernel(const float* partial, int64_t partial_gs, int rblocks, int M, int C,
+                                       const float* gamma, int64_t param_gs, const float* stats, int64_t stats_gs,
+                                       float* dgamma, float* dbeta, int64_t grad_gs, float* coef, int64_t coef_gs,
+                                       int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int z = blockIdx.y;
+  const float* p = partial + z * partial_gs;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < rblocks; ++r) { s1 += p[(int64_t)r * 2 * C + c]; s2 += p[(int64_t)r * 2 * C + C + c]; }
+  const float* st = stats + z * stats_gs;
+  const double mean = st[c], invstd = st[C + c];
+  const double sgx = invstd * (s2 - mean * s1);   // sum g * xhat
+  if (dgamma) {
+    float* dg = dgamma + z * grad_gs + c;
+    float* db = dbeta + z * grad_gs + c;
+    *dg = accumulate ? *dg + (float)sgx : (float)sgx;
+    *db = accumulate ? *db + (float)s1 : (float)s1;
+  }
+  const double A = (double)gamma[z * param_gs + c] * invstd;
+  const double c1 = s1 / M, c2 = sgx / M;
+  float* k = coef + z * coef_gs;
+  k[c] = (float)A;
+  k[C + c] = (float)(-A * invstd * c2);
+  k[2 * C + c] = (float)(-A * c1 + A * invstd * c2 * mean);
+}
+
+// dy = k1*g + k2*y + k3, g = da*[a>0]; optionally also writes g (the identity-branch gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ a,
+                                                           const T* __restrict__ y, T* __restrict__ dy,
+                                                           T* __restrict__ gout, const float* __restrict__ coef,
+                                                           int64_t coef_gs, int64_t total_chunks, int cprw, int C,
+                                                           int64_t gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  const float* k1 = coef + z * coef_gs;
+  const float* k2 = k1 + C;
+  const float* k3 = k2 + C;
+  const T* dd = da + z * gs;
+  const T* aa = a ? a + z * gs : nullptr;
+  const T* yy = y + z * gs;
+  T* oo = dy + z * gs;
+  T* go = gout ? gout + z * gs : nullptr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cprw) * VEC;
+    float d[VEC], m[VEC], v[VEC];
+    Vec16<T>::unpack(*(const uint4*)(dd + i * VEC), d);
+    Vec16<T>::unpack(*(const uint4*)(yy + i * VEC), v);
+    if (aa) {
+      Vec16<T>::unpack(*(const uint4*)(aa + i * VEC), m);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d[e] = m[e] > 0.f ? d[e] : 0.f;
+    }
+    if (go) *(uint4*)(go + i * VEC) = Vec16<T>::pack(d);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = k1[c0 + e] * d[e] + k2[c0 + e] * v[e] + k3[c0 + e];
+    *(uint4*)(oo + i * VEC) = Vec16<T>::pack(v);
+  }
+}
+
+static int ew_blocks(int64_t chunks) {
+  int64_t b = (chunks + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace ieee
+
+using namespace ieee;
+
+static int vec_of(int dtype) { return dtype == IEEE_BF16 ? 8 : 4; }
+
+extern "C" int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C) {
+  const RedGeom g = red_geom(M, (int)C, vec_of(dtype));
+  return (int64_t)g.rblocks * 2 * C;
+}
+
+extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
+                             int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
+                             float* running_mean, float* running_var, int64_t buf_gs, float* stats, float* partial,
+                             float momentum, float eps, int training, int relu, void* stream) {
+  IEEE_REQUIRE(y && gamma && beta && stats, "bn2d_fwd: null pointer");
+  IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_fwd: bad dtype");
+  IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_fwd: C %ld not a multiple of %d", (long)C, vec_of(dtype));
+  IEEE_REQUIRE(training || (running_mean && running_var), "bn2d_fwd: eval mode needs running stats");
+  IEEE_REQUIRE(!training || partial, "bn2d_fwd: training needs the partial-sum scratch");
+  hipStream_t st = (hipStream_t)stream;
+  const RedGeom g = red_geom(M, (int)C, vec_of(dtype));
+  const int64_t partial_gs = (int64_t)g.rblocks * 2 * C;
+  if (training) {
+    dim3 grid(g.cblocks * g.rblocks, (unsigned)groups);
+    if (dtype == IEEE_F32) bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float*)y, act_gs, g, partial, partial_gs);
+    else bn_stats_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y, act_gs, g, partial, partial_gs);
+    IEEE_TRY(launch_status("bn_stats_kernel"));
+  }
+  bn_finalize_kernel<<<dim3(cdiv(C, 128), (unsigned)groups), 128, 0, st>>>(
+      partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, beta, param_gs, running_mean, running_var, buf_gs, stats,
+      4 * C, momentum, eps, training);
+  IEEE_TRY(launch_status("bn_finalize_kernel"));
+  if (out == nullptr) return IEEE_OK;   // statistics only: the consumer applies scale/shift itself
+  const int64_t chunks = M * C / vec_of(dtype);
+  dim3 grid(ew_blocks(chunks), (unsigned)groups);
+  if (dtype == IEEE_F32)
+    bn_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)y, (const float*)residual, (float*)out, stats, 4 * C,
+                                                 chunks, g.cprw, (int)C, act_gs, relu);
+  else
+    bn_apply_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y, (const bf16*)residual, (bf16*)out, stats, 4 * C, chunks,
+                                                g.cprw, (int)C, act_gs, relu);
+  return launch_status("bn_apply_kernel");
+}
+
+extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                             int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma,
+                             int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
+                             float* partial, float* coef, int accumulate, void* stream) {
+  IEEE_REQUIRE(dout && y && dy && gamma && stats && partial && coef, "bn2d_bwd: null pointer");
+  IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_bwd: bad dtype");
+  IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_bwd: C not a multiple of the vector width");
+  hipStream_t st = (hipStream_t)stream;
+  const RedGeom g = red_geom(M, (int)C, vec_of(dtype));
+  const int64_t partial_gs = (int64_t)g.rblocks * 2 * C;
+  dim3 rgrid(g.cblocks * g.rblocks, (unsigned)groups);
+  if (dtype == IEEE_F32)
+    bn_bwd_reduce_kernel<float><<<rgrid, 256, 0, st>>>((const float*)dout, (const float*)out_mask, (const float*)y,
+                                                       act_gs, g, partial, partial_gs);
+  else
+    bn_bwd_reduce_kernel<bf16><<<rgrid, 256, 0, st>>>((const bf16*)dout, (const bf16*)out_mask, (const bf16*)y, act_gs,
+                                                      g, partial, partial_gs);
+  IEEE_TRY(launch_status("bn_bwd_reduce_kernel"));
+  bn_bwd_finalize_kernel<<<dim3(cdiv(C, 128), (unsigned)groups), 128, 0, st>>>(
+      partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, param_gs, stats, 4 * C, dgamma, dbeta, grad_gs, coef,
+      3 * C, accumulate);
+  IEEE_TRY(launch_status("bn_bwd_finalize_kernel"));
+  const int64_t chunks = M * C / vec_of(dtype);
+  dim3 grid(ew_blocks(chunks), (unsigned)groups);
+  if (dtype == IEEE_F32)
+    bn_bwd_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)dout, (const float*)out_mask, (const float*)y,
+                                                     (float*)dy, (float*)g_out, coef, 3 * C, chunks, g.cprw, (int)C,
+                                                     act_gs);
+  else
+    bn_bwd_apply_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)dout, (const bf16*)out_mask, (const bf16*)y,
+                                                    (bf16*)dy, (bf16*)g_out, coef, 3 * C, chunks, g.cprw, (int)C,
+                                                    act_gs);
+  return launch_status("bn_bwd_apply_kernel");
+}

@@ -1,0 +1,561 @@
+// Layout conversion, max-pool, and the Cross-modal Interacting Module tail:
+//   reference torchreid/models/ieee3modalPart.py:266-282 (ChannelAttention), :427-435
+//   (crossModalInteractionModule), :342-343 / :449-455 (the (1,1) and (6,1) adaptive average pools),
+//   torchreid/models/resnet.py:499-501 (stem ReLU + MaxPool2d(3,2,1)).
+// All maps are NHWC with a leading modality axis [3][B][H*W][C]; everything here is HBM-bound
+// streaming with 16-byte lanes; per-(b,c) reductions over the 128 positions are done by `ty` row
+// lanes of a block and finished through LDS.
+#include "common.h"
+
+namespace ieee {
+
+// fp32 NCHW images (three separate tensors, as the reference's batch dict carries them) -> NHWC T
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* x0, const float* x1, const float* x2, T* out, int B, int C, int HW) {
+  const int z = blockIdx.y;
+  const float* x = z == 0 ? x0 : (z == 1 ? x1 : x2);
+  const int64_t total = (int64_t)B * HW * C;
+  T* o = out + z * total;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int hw = (int)(p % HW);
+    const int b = (int)(p / HW);
+    o[i] = from_f32<T>(x[((int64_t)b * C + c) * HW + hw]);
+  }
+}
+
+// MaxPool2d(kernel 3, stride 2, pad 1) over NHWC; arg = window-local index (0..8) of the first maximum
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                          uint8_t* __restrict__ arg, int B, int Hi, int Wi, int C,
+                                                          int Ho, int Wo, int64_t x_gs, int64_t o_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  const int cprw = C / VEC;
+  const int64_t total = (int64_t)B * Ho * Wo * cprw;
+  x += z * x_gs;
+  out += z * o_gs;
+  arg += z * o_gs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cprw);
+    int64_t p = i / cprw;
+    const int q = (int)(p % Wo); p /= Wo;
+    const int pp = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float best[VEC];
+    int bi[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int h = pp * 2 - 1 + r;
+      if ((unsigned)h >= (unsigned)Hi) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int w = q * 2 - 1 + s;
+        if ((unsigned)w >= (unsigned)Wi) continue;
+        float v[VEC];
+        Vec16<T>::unpack(*(const uint4*)(x + (((int64_t)b * Hi + h) * Wi + w) * C + ch * VEC), v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (v[e] > best[e]) { best[e] = v[e]; bi[e] = r * 3 + s; }
+      }
+    }
+    const int64_t o = (((int64_t)b * Ho + pp) * Wo + q) * C + ch * VEC;
+    *(uint4*)(out + o) = Vec16<T>::pack(best);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) arg[o + e] = (uint8_t)bi[e];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ arg,
+                                                          T* __restrict__ dx, int B, int Hi, int Wi, int C, int Ho,
+                                                          int Wo, int64_t x_gs, int64_t o_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  const int cprw = C / VEC;
+  const int64_t total = (int64_t)B * Hi * Wi * cprw;
+  dout += z * o_gs;
+  arg += z * o_gs;
+  dx += z * x_gs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cprw);
+    int64_t p = i / cprw;
+    const int w = (int)(p % Wi); p /= Wi;
+    const int h = (int)(p % Hi);
+    const int b = (int)(p / Hi);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int pp = h / 2; pp <= (h + 1) / 2; ++pp) {
+      if (pp >= Ho) continue;
+      const int r = h - (pp * 2 - 1);
+      if (r < 0 || r > 2) continue;
+      for (int q = w / 2; q <= (w + 1) / 2; ++q) {
+        if (q >= Wo) continue;
+        const int s = w - (q * 2 - 1);
+        if (s < 0 || s > 2) continue;
+        const int64_t o = (((int64_t)b * Ho + pp) * Wo + q) * C + ch * VEC;
+        float d[VEC];
+        Vec16<T>::unpack(*(const uint4*)(dout + o), d);
+        const int local = r * 3 + s;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (arg[o + e] == local) acc[e] += d[e];
+      }
+    }
+    *(uint4*)(dx + i * VEC) = Vec16<T>::pack(acc);
+  }
+}
+
+// ------------------------------------------------------------------ per-(b,c) position reductions
+struct PosGeom {
+  int B, P, C;   // batch, positions per sample (H*W), channels
+  int W;         // map width (positions are h*W + w)
+  int cprw, tx, ty, cblocks;
+};
+static PosGeom pos_geom(int B, int H, int W, int C, int vec) {
+  PosGeom g;
+  g.B = B; g.P = H * W; g.C = C; g.W = W;
+  g.cprw = C / vec;
+  int tx = 1;
+  while (tx * 2 <= 64 && g.cprw % (tx * 2) == 0) tx *= 2;
+  g.tx = tx;
+  g.ty = 256 / tx;
+  g.cblocks = g.cprw / tx;
+  return g;
+}
+
+// adaptive-average-pool bin of row h for `parts` bins over H rows: start=floor(i*H/parts), end=ceil((i+1)*H/parts)
+__device__ __forceinline__ int bin_start(int i, int H, int parts) { return (i * H) / parts; }
+__device__ __forceinline__ int bin_end(int i, int H, int parts) { return ((i + 1) * H + parts - 1) / parts; }
+
+// reduce NQ*VEC per-thread accumulators over the ty row lanes; result valid for ty == 0
+template <int NQV>
+__device__ __forceinline__ void reduce_over_ty(float* acc, int tx, int ty, int txn, int tyn, float* red) {
+  for (int q = 0; q < NQV; ++q) {
+    __syncthreads();
+    red[ty * txn + tx] = acc[q];
+    __syncthreads();
+    if (ty == 0) {
+      float s = 0.f;
+      for (int y = 0; y < tyn; ++y) s += red[y * txn + tx];
+      acc[q] = s;
+    }
+  }
+}
+
+// K1: S_m = F_a + F_b (a,b = the other two modalities) and G_m = mean over positions of F_m
+template <typename T>
+__global__ __launch_bounds__(256) void gpool_sum_others_kernel(const T* __restrict__ F, T* __restrict__ S,
+                                                               float* __restrict__ Gp, PosGeom g, int64_t gs,
+                                                               int write_s) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[256];
+  const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
+  const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
+  const int c0 = (cb * g.tx + tx) * VEC;
+  float acc[3 * VEC];
+#pragma unroll
+  for (int e = 0; e < 3 * VEC; ++e) acc[e] = 0.f;
+  for (int p = ty; p < g.P; p += g.ty) {
+    const int64_t off = ((int64_t)b * g.P + p) * g.C + c0;
+    float v[3][VEC];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) Vec16<T>::unpack(*(const uint4*)(F + m * gs + off), v[m]);
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[m * VEC + e] += v[m][e];
+    if (write_s) {
+      float s[VEC];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int a = (m + 1) % 3, c = (m + 2) % 3;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] = v[a][e] + v[c][e];
+        *(uint4*)(S + m * gs + off) = Vec16<T>::pack(s);
+      }
+    }
+  }
+  reduce_over_ty<3 * VEC>(acc, tx, ty, g.tx, g.ty, red);
+  if (ty == 0) {
+    const float inv = 1.0f / g.P;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) Gp[((int64_t)m * g.B + b) * g.C + c0 + e] = acc[m * VEC + e] * inv;
+  }
+}
+
+// K3: rest = relu(y2*scale+shift); avg / max / argmax over positions
+template <typename T>
+__global__ __launch_bounds__(256) void ca_pool_kernel(const T* __restrict__ y2, const float* __restrict__ stats,
+                                                      float* __restrict__ avg, float* __restrict__ mx,
+                                                      int* __restrict__ amax, PosGeom g, int64_t gs,
+                                                      int64_t pool_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[256];
+  __shared__ int redi[256];
+  const int z = blockIdx.y;
+  const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
+  const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
+  const int c0 = (cb * g.tx + tx) * VEC;
+  const float* sc = stats + (int64_t)z * 4 * g.C + 2 * g.C;
+  const float* sh = sc + g.C;
+  float s[VEC], m[VEC];
+  int mi[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { s[e] = 0.f; m[e] = -INFINITY; mi[e] = 0; }
+  for (int p = ty; p < g.P; p += g.ty) {
+    float v[VEC];
+    Vec16<T>::unpack(*(const uint4*)(y2 + z * gs + ((int64_t)b * g.P + p) * g.C + c0), v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float r = fmaxf(v[e] * sc[c0 + e] + sh[c0 + e], 0.f);
+      s[e] += r;
+      if (r > m[e]) { m[e] = r; mi[e] = p; }
+    }
+  }
+  reduce_over_ty<VEC>(s, tx, ty, g.tx, g.ty, red);
+  // max with first-occurrence index: combine over ty in increasing position order
+  for (int e = 0; e < VEC; ++e) {
+    __syncthreads();
+    red[ty * g.tx + tx] = m[e];
+    redi[ty * g.tx + tx] = mi[e];
+    __syncthreads();
+    if (ty == 0) {
+      float bm = -INFINITY; int bi = 0x7fffffff;
+      for (int y = 0; y < g.ty; ++y) {
+        const float v = red[y * g.tx + tx]; const int i = redi[y * g.tx + tx];
+        if (v > bm || (v == bm && i < bi)) { bm = v; bi = i; }
+      }
+      m[e] = bm; mi[e] = bi;
+    }
+  }
+  if (ty == 0) {
+    const int64_t o = ((int64_t)z * g.B + b) * g.C + c0;
+    const int64_t op = z * pool_gs + (int64_t)b * g.C + c0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { avg[op + e] = s[e] / g.P; mx[op + e] = m[e]; amax[o + e] = mi[e]; }
+  }
+}
+
+// K5: out = act1(y1) + act2(y2)*(1+att), pooled into `parts` overlapping row bins -> Pp [3][B][parts][C] fp32
+//   mode 0: full CIM (act = relu(bn)), mode 1: attention off (att ignored), mode 2: interaction off (out = y1 raw)
+template <typename T>
+__global__ __launch_bounds__(256) void cim_tail_kernel(const T* __restrict__ y1, const T* __restrict__ y2,
+                                                       const float* __restrict__ st1, const float* __restrict__ st2,
+                                                       const float* __restrict__ att, float* __restrict__ Pp,
+                                                       PosGeom g, int64_t gs, int H, int parts, int mode) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int MAXP = 8;
+  __shared__ float red[256];
+  const int z = blockIdx.y;
+  const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
+  const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
+  const int c0 = (cb * g.tx + tx) * VEC;
+  float sc1[VEC], sh1[VEC], sc2[VEC], sh2[VEC], at[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    sc1[e] = 1.f; sh1[e] = 0.f; sc2[e] = 0.f; sh2[e] = 0.f; at[e] = 0.f;
+    if (mode != 2) {
+      sc1[e] = st1[(int64_t)z * 4 * g.C + 2 * g.C + c0 + e];
+      sh1[e] = st1[(int64_t)z * 4 * g.C + 3 * g.C + c0 + e];
+      sc2[e] = st2[(int64_t)z * 4 * g.C + 2 * g.C + c0 + e];
+      sh2[e] = st2[(int64_t)z * 4 * g.C + 3 * g.C + c0 + e];
+    }
+    if (mode == 0) at[e] = att[((int64_t)z * g.B + b) * g.C + c0 + e];
+  }
+  float acc[MAXP * VEC];
+#pragma unroll
+  for (int e = 0; e < MAXP * VEC; ++e) acc[e] = 0.f;
+  for (int p = ty; p < g.P; p += g.ty) {
+    const int h = p / g.W;
+    const int64_t off = z * gs + ((int64_t)b * g.P + p) * g.C + c0;
+    float v1[VEC], v2[VEC], o[VEC];
+    Vec16<T>::unpack(*(const uint4*)(y1 + off), v1);
+    if (mode != 2) {
+      Vec16<T>::unpack(*(const uint4*)(y2 + off), v2);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        o[e] = fmaxf(v1[e] * sc1[e] + sh1[e], 0.f) + fmaxf(v2[e] * sc2[e] + sh2[e], 0.f) * (1.f + at[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = v1[e];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (i < parts && h >= bin_start(i, H, parts) && h < bin_end(i, H, parts)) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[i * VEC + e] += o[e];
+      }
+    }
+  }
+  reduce_over_ty<MAXP * VEC>(acc, tx, ty, g.tx, g.ty, red);
+  if (ty == 0) {
+    for (int i = 0; i < parts; ++i) {
+      const float inv = 1.0f / ((bin_end(i, H, parts) - bin_start(i, H, parts)) * g.W);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        Pp[(((int64_t)z * g.B + b) * parts + i) * g.C + c0 + e] = acc[i * VEC + e] * inv;
+    }
+  }
+}
+
+// gradient of the pooled parts w.r.t. the (never materialised) CIM output at row h
+__device__ __forceinline__ void dout_at(const float* dP, int64_t base, int C, int c0, int h, int H, int W, int parts,
+                                        float* d, int VECN) {
+  for (int e = 0; e < VECN; ++e) d[e] = 0.f;
+  for (int i = 0; i < parts; ++i) {
+    const int s = bin_start(i, H, parts), en = bin_end(i, H, parts);
+    if (h >= s && h < en) {
+      const float inv = 1.0f / ((en - s) * W);
+      for (int e = 0; e < VECN; ++e) d[e] += dP[base + (int64_t)i * C + c0 + e] * inv;
+    }
+  }
+}
+
+// backward part 1: d_att[b,c] = sum_pos d_out * rest
+template <typename T>
+__global__ __launch_bounds__(256) void cim_bwd_datt_kernel(const float* __restrict__ dP, const T* __restrict__ y2,
+                                                           const float* __restrict__ st2, float* __restrict__ datt,
+                                                           PosGeom g, int64_t gs, int H, int parts) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[256];
+  const int z = blockIdx.y;
+  const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
+  const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
+  const int c0 = (cb * g.tx + tx) * VEC;
+  const float* sc = st2 + (int64_t)z * 4 * g.C + 2 * g.C;
+  const float* sh = sc + g.C;
+  const int64_t pbase = ((int64_t)z * g.B + b) * parts * g.C;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  for (int p = ty; p < g.P; p += g.ty) {
+    float d[VEC], v[VEC];
+    dout_at(dP, pbase, g.C, c0, p / g.W, H, g.W, parts, d, VEC);
+    Vec16<T>::unpack(*(const uint4*)(y2 + z * gs + ((int64_t)b * g.P + p) * g.C + c0), v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] += d[e] * fmaxf(v[e] * sc[c0 + e] + sh[c0 + e], 0.f);
+  }
+  reduce_over_ty<VEC>(acc, tx, ty, g.tx, g.ty, red);
+  if (ty == 0) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) datt[((int64_t)z * g.B + b) * g.C + c0 + e] = acc[e];
+  }
+}
+
+// backward part 2 (elementwise): g1 = d_out*[one>0]; g2 = (d_out*(1+att) + d_avg/P + [p==argmax]*d_max)*[rest>0]
+//   mode 2 (interaction off): g1 = d_out (gradient straight to the trunk output), no g2
+template <typename T>
+__global__ __launch_bounds__(256) void cim_bwd_g_kernel(const float* __restrict__ dP, const T* __restrict__ y1,
+                                                        const T* __restrict__ y2, const float* __restrict__ st1,
+                                                        const float* __restrict__ st2, const float* __restrict__ att,
+                                                        const float* __restrict__ davg, const float* __restrict__ dmax,
+                                                        const int* __restrict__ amax, T* __restrict__ g1,
+                                                        T* __restrict__ g2, PosGeom g, int64_t gs, int H, int parts,
+                                                        int mode, int64_t pool_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  const int64_t total = (int64_t)g.B * g.P * g.cprw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % g.cprw);
+    const int64_t bp = i / g.cprw;
+    const int p = (int)(bp % g.P), b = (int)(bp / g.P);
+    const int c0 = ch * VEC;
+    float d[VEC];
+    dout_at(dP, ((int64_t)z * g.B + b) * parts * g.C, g.C, c0, p / g.W, H, g.W, parts, d, VEC);
+    const int64_t off = z * gs + i * VEC;
+    if (mode == 2) {
+      *(uint4*)(g1 + off) = Vec16<T>::pack(d);
+      continue;
+    }
+    float v1[VEC], v2[VEC], o1[VEC], o2[VEC];
+    Vec16<T>::unpack(*(const uint4*)(y1 + off), v1);
+    Vec16<T>::unpack(*(const uint4*)(y2 + off), v2);
+    const float* s1 = st1 + (int64_t)z * 4 * g.C;
+    const float* s2 = st2 + (int64_t)z * 4 * g.C;
+    const int64_t bc = ((int64_t)z * g.B + b) * g.C + c0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = c0 + e;
+      const bool on1 = v1[e] * s1[2 * g.C + c] + s1[3 * g.C + c] > 0.f;
+      const bool on2 = v2[e] * s2[2 * g.C + c] + s2[3 * g.C + c] > 0.f;
+      float t2 = d[e];
+      if (mode == 0) {
+        const int64_t pc = z * pool_gs + (int64_t)b * g.C + c0 + e;
+        t2 = d[e] * (1.f + att[bc + e]) + davg[pc] * (1.0f / g.P);
+        if (amax[bc + e] == p) t2 += dmax[pc];
+      }
+      o1[e] = on1 ? d[e] : 0.f;
+      o2[e] = on2 ? t2 : 0.f;
+    }
+    *(uint4*)(g1 + off) = Vec16<T>::pack(o1);
+    *(uint4*)(g2 + off) = Vec16<T>::pack(o2);
+  }
+}
+
+// gradient w.r.t. the trunk output: dF_m = D1_m + DS_a + DS_b + dG_m/P  (a,b = other modalities)
+//   (mode 2: dF_m = D1_m + dG_m/P)
+template <typename T>
+__global__ __launch_bounds__(256) void cim_bwd_combine_kernel(const T* __restrict__ D1, const T* __restrict__ DS,
+                                                              const float* __restrict__ dG, T* __restrict__ dF,
+                                                              PosGeom g, int64_t gs, int mode) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int64_t total = (int64_t)g.B * g.P * g.cprw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % g.cprw);
+    const int b = (int)((i / g.cprw) / g.P);
+    float ds[3][VEC];
+    if (mode != 2) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m) Vec16<T>::unpack(*(const uint4*)(DS + m * gs + i * VEC), ds[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      float v[VEC];
+      Vec16<T>::unpack(*(const uint4*)(D1 + m * gs + i * VEC), v);
+      const int a = (m + 1) % 3, c = (m + 2) % 3;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float x = v[e] + dG[((int64_t)m * g.B + b) * g.C + ch * VEC + e] * (1.0f / g.P);
+        if (mode != 2) x += ds[a][e] + ds[c][e];
+        v[e] = x;
+      }
+      *(uint4*)(dF + m * gs + i * VEC) = Vec16<T>::pack(v);
+    }
+  }
+}
+
+static int ew_blocks2(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace ieee
+
+using namespace ieee;
+
+static int vecw(int dtype) { return dtype == IEEE_BF16 ? 8 : 4; }
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16)                      \
+  do {                                                              \
+    if ((dtype) == IEEE_F32) { CALL_F32; }                          \
+    else if ((dtype) == IEEE_BF16) { CALL_BF16; }                   \
+    else { IEEE_REQUIRE(false, "bad dtype %d", (int)(dtype)); }     \
+  } while (0)
+
+extern "C" int ieee_nchw_to_nhwc3(const float* x_rgb, const float* x_ni, const float* x_ti, void* out, int dtype,
+                                  int64_t B, int64_t C, int64_t H, int64_t W, void* stream) {
+  IEEE_REQUIRE(x_rgb && x_ni && x_ti && out, "nchw_to_nhwc3: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ew_blocks2(B * C * H * W), 3);
+  DISPATCH_T(dtype, (nchw_to_nhwc_kernel<float><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (float*)out, (int)B, (int)C, (int)(H * W))),
+             (nchw_to_nhwc_kernel<bf16><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (bf16*)out, (int)B, (int)C, (int)(H * W))));
+  return launch_status("nchw_to_nhwc_kernel");
+}
+
+extern "C" int ieee_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int dtype, int64_t groups, int64_t B,
+                                     int64_t Hi, int64_t Wi, int64_t C, void* stream) {
+  IEEE_REQUIRE(x && out && argmax, "maxpool_fwd: null pointer");
+  IEEE_REQUIRE(C % vecw(dtype) == 0, "maxpool_fwd: C not a multiple of the vector width");
+  const int Ho = (int)((Hi + 2 - 3) / 2 + 1), Wo = (int)((Wi + 2 - 3) / 2 + 1);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ew_blocks2(B * Ho * Wo * C / vecw(dtype)), (unsigned)groups);
+  const int64_t xgs = B * Hi * Wi * C, ogs = B * Ho * Wo * C;
+  DISPATCH_T(dtype, (maxpool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (float*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs)),
+             (maxpool_fwd_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)x, (bf16*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs)));
+  return launch_status("maxpool_fwd_kernel");
+}
+
+extern "C" int ieee_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int dtype, int64_t groups,
+                                     int64_t B, int64_t Hi, int64_t Wi, int64_t C, void* stream) {
+  IEEE_REQUIRE(dout && dx && argmax, "maxpool_bwd: null pointer");
+  const int Ho = (int)((Hi + 2 - 3) / 2 + 1), Wo = (int)((Wi + 2 - 3) / 2 + 1);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ew_blocks2(B * Hi * Wi * C / vecw(dtype)), (unsigned)groups);
+  const int64_t xgs = B * Hi * Wi * C, ogs = B * Ho * Wo * C;
+  DISPATCH_T(dtype, (maxpool_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)dout, argmax, (float*)dx, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs)),
+             (maxpool_bwd_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)dout, argmax, (bf16*)dx, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs)));
+  return launch_status("maxpool_bwd_kernel");
+}
+
+extern "C" int ieee_gpool_sum_others(const void* F, void* S, float* Gp, int dtype, int64_t B, int64_t H, int64_t W,
+                                     int64_t C, void* stream) {
+  IEEE_REQUIRE(F && Gp, "gpool_sum_others: null pointer");
+  IEEE_REQUIRE(C % (vecw(dtype)) == 0, "gpool_sum_others: bad C");
+  const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t gs = B * H * W * C;
+  dim3 grid((unsigned)(B * g.cblocks));
+  DISPATCH_T(dtype, (gpool_sum_others_kernel<float><<<grid, 256, 0, st>>>((const float*)F, (float*)S, Gp, g, gs, S ? 1 : 0)),
+             (gpool_sum_others_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)F, (bf16*)S, Gp, g, gs, S ? 1 : 0)));
+  return launch_status("gpool_sum_others_kernel");
+}
+
+extern "C" int ieee_ca_pool(const void* y2, const float* stats2, float* avg, float* mx, int64_t pool_gs,
+                            int32_t* argmax, int dtype, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+  IEEE_REQUIRE(y2 && stats2 && avg && mx && argmax, "ca_pool: null pointer");
+  const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)(B * g.cblocks), 3);
+  DISPATCH_T(dtype, (ca_pool_kernel<float><<<grid, 256, 0, st>>>((const float*)y2, stats2, avg, mx, argmax, g, B * H * W * C, pool_gs)),
+             (ca_pool_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y2, stats2, avg, mx, argmax, g, B * H * W * C, pool_gs)));
+  return launch_status("ca_pool_kernel");
+}
+
+extern "C" int ieee_cim_tail_fwd(const void* y1, const void* y2, const float* stats1, const float* stats2,
+                                 const float* att, float* parts_out, int dtype, int64_t B, int64_t H, int64_t W,
+                                 int64_t C, int64_t parts, int mode, void* stream) {
+  IEEE_REQUIRE(y1 && parts_out, "cim_tail_fwd: null pointer");
+  IEEE_REQUIRE(parts >= 1 && parts <= 8, "cim_tail_fwd: parts must be in [1,8]");
+  IEEE_REQUIRE(mode == 2 || (y2 && stats1 && stats2), "cim_tail_fwd: missing CIM operands");
+  IEEE_REQUIRE(mode != 0 || att, "cim_tail_fwd: attention weights missing");
+  const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)(B * g.cblocks), 3);
+  DISPATCH_T(dtype, (cim_tail_kernel<float><<<grid, 256, 0, st>>>((const float*)y1, (const float*)y2, stats1, stats2, att, parts_out, g, B * H * W * C, (int)H, (int)parts, mode)),
+             (cim_tail_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y1, (const bf16*)y2, stats1, stats2, att, parts_out, g, B * H * W * C, (int)H, (int)parts, mode)));
+  return launch_status("cim_tail_kernel");
+}
+
+extern "C" int ieee_cim_tail_bwd_datt(const float* dparts, const void* y2, const float* stats2, float* datt, int dtype,
+                                      int64_t B, int64_t H, int64_t W, int64_t C, int64_t parts, void* stream) {
+  IEEE_REQUIRE(dparts && y2 && stats2 && datt, "cim_tail_bwd_datt: null pointer");
+  const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)(B * g.cblocks), 3);
+  DISPATCH_T(dtype, (cim_bwd_datt_kernel<float><<<grid, 256, 0, st>>>(dparts, (const float*)y2, stats2, datt, g, B * H * W * C, (int)H, (int)parts)),
+             (cim_bwd_datt_kernel<bf16><<<grid, 256, 0, st>>>(dparts, (const bf16*)y2, stats2, datt, g, B * H * W * C, (int)H, (int)parts)));
+  return launch_status("cim_bwd_datt_kernel");
+}
+
+extern "C" int ieee_cim_tail_bwd_g(const float* dparts, const void* y1, const void* y2, const float* stats1,
+                                   const float* stats2, const float* att, const float* davg, const float* dmax,
+                                   int64_t pool_gs, const int32_t* argmax, void* g1, void* g2, int dtype, int64_t B,
+                                   int64_t H, int64_t W, int64_t C, int64_t parts, int mode, void* stream) {
+  IEEE_REQUIRE(dparts && g1, "cim_tail_bwd_g: null pointer");
+  IEEE_REQUIRE(mode == 2 || (y1 && y2 && stats1 && stats2 && g2), "cim_tail_bwd_g: missing CIM operands");
+  IEEE_REQUIRE(mode != 0 || (att && davg && dmax && argmax), "cim_tail_bwd_g: missing attention operands");
+  const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ew_blocks2(B * H * W * C / vecw(dtype)), 3);
+  DISPATCH_T(dtype, (cim_bwd_g_kernel<float><<<grid, 256, 0, st>>>(dparts, (const float*)y1, (const float*)y2, stats1, stats2, att, davg, dmax, argmax, (float*)g1, (float*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs)),
+             (cim_bwd_g_kernel<bf16><<<grid, 256, 0, st>>>(dparts, (const bf16*)y1, (const bf16*)y2, stats1, stats2, att, davg, dmax, argmax, (bf16*)g1, (bf16*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs)));
+  return launch_status("cim_bwd_g_kernel");
+}
+
+extern "C" int ieee_cim_bwd_combine(const void* D1, const void* DS, const float* dG, void* dF, int dtype, int64_t B,
+                                    int64_t H, int64_t W, int64_t C, int mode, void* stream) {
+  IEEE_REQUIRE(D1 && dG && dF, "cim_bwd_combine: null pointer");
+  IEEE_REQUIRE(mode == 2 || DS, "cim_bwd_combine: DS missing");
+  const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ew_blocks2(B * H * W * C / vecw(dtype)));
+  DISPATCH_T(dtype, (cim_bwd_combine_kernel<float><<<grid, 256, 0, st>>>((const float*)D1, (const float*)DS, dG, (float*)dF, g, B * H * W * C, mode)),
+             (cim_bwd_combine_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)D1, (const bf16*)DS, dG, (bf16*)dF, g, B * H * W * C, mode)));
+  return launch_status("cim_bwd_combine_kernel");
+}

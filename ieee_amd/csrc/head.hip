@@ -1,0 +1,637 @@
+// The embedding head of IEEE3modalPart in fp32 (it is <0.5 % of the FLOPs):
+// grouped small GEMMs on the fp32 MFMA, row-wise BatchNorm (BatchNorm2d over [B,C,1,1]/[B,C,6,1] and
+// BatchNorm1d), REM closed form, L2 normalisation, label-smoothed cross entropy, the 3M margin loss
+// and the fused SGD-nesterov step.  "Grouped" = up to IEEE_MAX_GROUPS independent problems per
+// launch, addressed through pointer tables passed by value (no device-side pointer arrays to manage).
+#include "gemm_core.h"
+
+namespace ieee {
+
+constexpr int MAXG = IEEE_MAX_GROUPS;
+
+struct PtrTab { void* p[MAXG]; };
+
+// ------------------------------------------------------------------ grouped fp32 GEMM
+// C[g](m,n) = act( alpha * sum_k A[g](m,k) * B[g](n,k) + bias[g](n) ) (+ C if accumulate)
+// with generic element strides: A(m,k) = A + m*sam + k*sak, B(n,k) = B + n*sbn + k*sbk.
+struct SgemmArgs {
+  PtrTab A, B, C, bias;
+  int M, N, K;
+  int64_t sam, sak, sbn, sbk, ldc;
+  float alpha;
+  int relu, accumulate;
+};
+
+__global__ __launch_bounds__(256) void sgemm_grouped_kernel(SgemmArgs a) {
+  __shared__ float As[2][64][17];
+  __shared__ float Bs[2][64][17];
+  const int g = blockIdx.z;
+  const float* A = (const float*)a.A.p[g];
+  const float* B = (const float*)a.B.p[g];
+  float* C = (float*)a.C.p[g];
+  const float* bias = (const float*)a.bias.p[g];
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  // element -> thread mapping chosen so the contiguous axis runs across lanes
+  const bool a_kc = a.sak == 1, b_kc = a.sbk == 1;
+  int ar[4], ak[4], br[4], bk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (a_kc) { ak[i] = t & 15; ar[i] = (t >> 4) + 16 * i; } else { ar[i] = t & 63; ak[i] = (t >> 6) + 4 * i; }
+    if (b_kc) { bk[i] = t & 15; br[i] = (t >> 4) + 16 * i; } else { br[i] = t & 63; bk[i] = (t >> 6) + 4 * i; }
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ra[4], rb[4];
+  const int ktiles = (a.K + 15) / 16;
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + ar[i], k = kt * 16 + ak[i];
+      ra[i] = (m < a.M && k < a.K) ? A[m * a.sam + k * a.sak] : 0.f;
+      const int n = n0 + br[i], k2 = kt * 16 + bk[i];
+      rb[i] = (n < a.N && k2 < a.K) ? B[n * a.sbn + k2 * a.sbk] : 0.f;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { As[buf][ar[i]][ak[i]] = ra[i]; Bs[buf][br[i]][bk[i]] = rb[i]; }
+  };
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int cur = kt & 1;
+    const bool has_next = kt + 1 < ktiles;
+    if (has_next) gload(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = As[cur][wm * 32 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = Bs[cur][wn * 32 + j * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+    if (has_next) sstore(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + wm * 32 + i * 16 + (lane & 15);
+      const int n = n0 + wn * 32 + j * 16 + (lane >> 4) * 4;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r >= a.N) continue;
+        float v = a.alpha * acc[i][j][r];
+        if (bias) v += bias[n + r];
+        float* c = C + (int64_t)m * a.ldc + n + r;
+        if (a.accumulate) v += *c;
+        if (a.relu) v = fmaxf(v, 0.f);
+        *c = v;
+      }
+    }
+}
+
+// column sums (bias gradients): out[g][n] (+)= sum_m X[g](m,n)
+struct ColsumArgs {
+  PtrTab X, out;
+  int M, N;
+  int64_t ldx;
+  int accumulate;
+};
+__global__ void colsum_grouped_kernel(ColsumArgs a) {
+  const int g = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= a.N) return;
+  const float* X = (const float*)a.X.p[g];
+  float s = 0.f;
+  for (int m = 0; m < a.M; ++m) s += X[(int64_t)m * a.ldx + n];
+  float* o = (float*)a.out.p[g] + n;
+  *o = a.accumulate ? *o + s : s;
+}
+
+// ------------------------------------------------------------------ row-wise BatchNorm (+ReLU)
+// x [R][C] (row stride ldx) -> out [R][C] (row stride ldo); statistics over the R rows.
+struct RowBnArgs {
+  PtrTab x, out, gamma, beta, rmean, rvar, save;   // save[g]: [2][C] mean, invstd
+  int R, C;
+  int64_t ldx, ldo;
+  float momentum, eps;
+  int training, relu;
+};
+__global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnArgs a) {
+  __shared__ float red[4][64];
+  const int g = blockIdx.y;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const bool ok = c < a.C;
+  const float* x = (const float*)a.x.p[g];
+  float* out = (float*)a.out.p[g];
+  float mean, invstd;
+  if (a.training) {
+    float s = 0.f;
+    if (ok) for (int r = ty; r < a.R; r += 4) s += x[(int64_t)r * a.ldx + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / a.R;
+    __syncthreads();
+    float v = 0.f;
+    if (ok) for (int r = ty; r < a.R; r += 4) { const float d = x[(int64_t)r * a.ldx + c] - mean; v += d * d; }
+    red[ty][tx] = v;
+    __syncthreads();
+    const float var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / a.R;
+    invstd = 1.0f / sqrtf(var + a.eps);
+    if (ok && ty == 0) {
+      float* rm = (float*)a.rmean.p[g];
+      float* rv = (float*)a.rvar.p[g];
+      if (rm) {
+        const float unb = a.R > 1 ? var * ((float)a.R / (float)(a.R - 1)) : var;
+        rm[c] = (1.f - a.momentum) * rm[c] + a.momentum * mean;
+        rv[c] = (1.f - a.momentum) * rv[c] + a.momentum * unb;
+      }
+    }
+  } else {
+    mean = ok ? ((const float*)a.rmean.p[g])[c] : 0.f;
+    invstd = ok ? 1.0f / sqrtf(((const float*)a.rvar.p[g])[c] + a.eps) : 0.f;
+  }
+  if (!ok) return;
+  if (ty == 0 && a.save.p[g]) { float* sv = (float*)a.save.p[g]; sv[c] = mean; sv[a.C + c] = invstd; }
+  const float ga = ((const float*)a.gamma.p[g])[c], be = ((const float*)a.beta.p[g])[c];
+  for (int r = ty; r < a.R; r += 4) {
+    float v = (x[(int64_t)r * a.ldx + c] - mean) * invstd * ga + be;
+    if (a.relu) v = fmaxf(v, 0.f);
+    out[(int64_t)r * a.ldo + c] = v;
+  }
+}
+
+struct RowBnBwdArgs {
+  PtrTab dout, out, x, gamma, save, dx, dgamma, dbeta;
+  int R, C;
+  int64_t lddo, ldo, ldx, lddx;
+  int relu, accumulate;
+};
+__global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwdArgs a) {
+  __shared__ float red[2][4][64];
+  const int g = blockIdx.y;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const bool ok = c < a.C;
+  const float* dout = (const float*)a.dout.p[g];
+  const float* out = (const float*)a.out.p[g];
+  const float* x = (const float*)a.x.p[g];
+  const float* sv = (const float*)a.save.p[g];
+  const float mean = ok ? sv[c] : 0.f, invstd = ok ? sv[a.C + c] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok)
+    for (int r = ty; r < a.R; r += 4) {
+      float gq = dout[(int64_t)r * a.lddo + c];
+      if (a.relu && !(out[(int64_t)r * a.ldo + c] > 0.f)) gq = 0.f;
+      s1 += gq;
+      s2 += gq * (x[(int64_t)r * a.ldx + c] - mean) * invstd;
+    }
+  red[0][ty][tx] = s1;
+  red[1][ty][tx] = s2;
+  __syncthreads();
+  s1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+  s2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+  if (!ok) return;
+  const float ga = ((const float*)a.gamma.p[g])[c];
+  if (ty == 0) {
+    float* dg = (float*)a.dgamma.p[g] + c;
+    float* db = (float*)a.dbeta.p[g] + c;
+    *dg = a.accumulate ? *dg + s2 : s2;
+    *db = a.accumulate ? *db + s1 : s1;
+  }
+  float* dx = (float*)a.dx.p[g];
+  const float c1 = s1 / a.R, c2 = s2 / a.R;
+  for (int r = ty; r < a.R; r += 4) {
+    float gq = dout[(int64_t)r * a.lddo + c];
+    if (a.relu && !(out[(int64_t)r * a.ldo + c] > 0.f)) gq = 0.f;
+    const float xh = (x[(int64_t)r * a.ldx + c] - mean) * invstd;
+    dx[(int64_t)r * a.lddx + c] = ga * invstd * (gq - c1 - xh * c2);
+  }
+}
+
+// ------------------------------------------------------------------ small elementwise pieces
+// CA: hs[b][j] = h[b][j] + h[B+b][j]   (relu already applied by the GEMM epilogue)
+__global__ void add_halves_kernel(const float* h, float* hs, int64_t half, int64_t gs_in, int64_t gs_out) {
+  const int z = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (int64_t)gridDim.x * blockDim.x)
+    hs[z * gs_out + i] = h[z * gs_in + i] + h[z * gs_in + half + i];
+}
+__global__ void sigmoid_kernel(float* x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+// dz = datt * att * (1 - att)
+__global__ void sigmoid_bwd_kernel(const float* datt, const float* att, float* dz, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dz[i] = datt[i] * att[i] * (1.f - att[i]);
+}
+// dh[b] = dhs[b]*[h[b]>0], dh[B+b] = dhs[b]*[h[B+b]>0]
+__global__ void add_halves_bwd_kernel(const float* dhs, const float* h, float* dh, int64_t half, int64_t gs_half,
+                                      int64_t gs_full) {
+  const int z = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = dhs[z * gs_half + i];
+    dh[z * gs_full + i] = h[z * gs_full + i] > 0.f ? d : 0.f;
+    dh[z * gs_full + half + i] = h[z * gs_full + half + i] > 0.f ? d : 0.f;
+  }
+}
+
+// REM closed form (ieee3modalPart.py:60-80): out[b][i][:] = part[b][i][:] + 2*param * r[b][:]
+__global__ void rem_fwd_kernel(const float* part, const float* r, const float* param, int64_t param_gs, float* out,
+                               int B, int parts, int D) {
+  const int z = blockIdx.y;
+  const float s = 2.0f * param[z * param_gs];
+  const int64_t n = (int64_t)B * parts * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % D);
+    const int b = (int)(i / ((int64_t)parts * D));
+    out[z * n + i] = part[z * n + i] + s * r[((int64_t)z * B + b) * D + k];
+  }
+}
+// dr[b][k] = 2*param * sum_i dout[b][i][k];  dparam partial[b] = 2 * sum_{i,k} dout[b][i][k]*r[b][k]
+__global__ __launch_bounds__(256) void rem_bwd_kernel(const float* dout, const float* r, const float* param,
+                                                      int64_t param_gs, float* dr, float* dparam_partial, int B,
+                                                      int parts, int D) {
+  __shared__ float red[256];
+  const int z = blockIdx.y, b = blockIdx.x;
+  const float s = 2.0f * param[z * param_gs];
+  float accp = 0.f;
+  for (int k = threadIdx.x; k < D; k += blockDim.x) {
+    float sum = 0.f;
+    for (int i = 0; i < parts; ++i) sum += dout[(((int64_t)z * B + b) * parts + i) * D + k];
+    dr[((int64_t)z * B + b) * D + k] = s * sum;
+    accp += sum * r[((int64_t)z * B + b) * D + k];
+  }
+  red[threadIdx.x] = accp;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) dparam_partial[(int64_t)z * B + b] = 2.0f * red[0];
+}
+__global__ void rem_dparam_kernel(const float* partial, float* dparam, int64_t grad_gs, int B, int accumulate) {
+  const int z = threadIdx.x;
+  if (z >= 3) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += partial[(int64_t)z * B + b];
+  float* o = dparam + z * grad_gs;
+  *o = accumulate ? *o + s : s;
+}
+
+// F.normalize(x, p=2, dim=1), eps 1e-12: one wave per row
+__global__ void l2norm_fwd_kernel(const float* x, float* y, float* norms, int64_t rows, int D) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int k = lane; k < D; k += 64) { const float v = x[row * D + k]; s += v * v; }
+  s = wave_sum(s);
+  const float nrm = fmaxf(sqrtf(s), 1e-12f);
+  for (int k = lane; k < D; k += 64) y[row * D + k] = x[row * D + k] / nrm;
+  if (lane == 0) norms[row] = nrm;
+}
+// dx = (dy - y * (y.dy)) / norm   (rows with norm clamped at eps: dx = dy/eps, like autograd of clamp_min)
+__global__ void l2norm_bwd_kernel(const float* dy, const float* y, const float* norms, float* dx, int64_t rows, int D,
+                                  int accumulate) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int k = lane; k < D; k += 64) s += dy[row * D + k] * y[row * D + k];
+  s = wave_sum(s);
+  const float nrm = norms[row];
+  const float dot = nrm > 1e-12f ? s : 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float v = (dy[row * D + k] - y[row * D + k] * dot) / nrm;
+    dx[row * D + k] = accumulate ? dx[row * D + k] + v : v;
+  }
+}
+
+// ------------------------------------------------------------------ losses
+// label-smoothed CE (torchreid/losses/cross_entropy_loss.py:36-50) over `heads` logits tensors [B][C]:
+// rowloss[h][b] = -sum_c t_c * logp_c, t = (1-eps)*onehot + eps/C; dlogits = (softmax - t) * gscale / B
+__global__ void ce_rows_kernel(const float* logits, const int64_t* target, float* rowloss, int* correct,
+                               float* dlogits, int heads, int B, int C, float eps, float gscale) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)heads * B) return;
+  const int lane = threadIdx.x & 63;
+  const int b = (int)(row % B);
+  const float* x = logits + row * C;
+  const int y = (int)target[b];
+  float mx = -INFINITY;
+  int am = 0;
+  for (int c = lane; c < C; c += 64) { const float v = x[c]; if (v > mx) { mx = v; am = c; } }
+  // wave arg-max (first index on ties)
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o);
+    const int oi = __shfl_xor(am, o);
+    if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+  }
+  float se = 0.f, sx = 0.f;
+  for (int c = lane; c < C; c += 64) { se += expf(x[c] - mx); sx += x[c]; }
+  se = wave_sum(se);
+  sx = wave_sum(sx);
+  const float lse = mx + logf(se);
+  // sum_c logp_c = sx - C*lse ; logp_y = x[y] - lse
+  const float logpy = x[y] - lse;
+  if (lane == 0) {
+    rowloss[row] = -(1.f - eps) * logpy - (eps / C) * (sx - C * lse);
+    correct[row] = am == y ? 1 : 0;
+  }
+  if (dlogits) {
+    const float sc = gscale / B;
+    for (int c = lane; c < C; c += 64) {
+      const float p = expf(x[c] - lse);
+      const float tt = (c == y ? (1.f - eps) : 0.f) + eps / C;
+      dlogits[row * C + c] = (p - tt) * sc;
+    }
+  }
+}
+// per-head mean loss and top-1 % accuracy
+__global__ void ce_heads_kernel(const float* rowloss, const int* correct, float* head_loss, float* head_acc,
+                                int heads, int B) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= heads) return;
+  float s = 0.f;
+  int k = 0;
+  for (int b = 0; b < B; ++b) { s += rowloss[(int64_t)h * B + b]; k += correct[(int64_t)h * B + b]; }
+  head_loss[h] = s / B;
+  head_acc[h] = 100.0f * k / B;
+}
+
+// 3M loss (torchreid/losses/multi_modal_margin_loss_new.py:19-40), feats [3][B][D] in the order R,N,T.
+// out[0] = loss, out[1] = label_num, out[2] = number of chunks torch.chunk yields (< label_num => the
+// reference raises IndexError).  Single block: deterministic, B*D is tiny.
+__global__ __launch_bounds__(256) void margin3m_kernel(const float* feats, const int64_t* pids, float* dfeats,
+                                                       float* out, int B, int D, float margin, float gscale) {
+  __shared__ float red[3][256];
+  __shared__ int s_n;
+  __shared__ int s_sel;
+  __shared__ float s_sign;
+  const int t = threadIdx.x;
+  if (t == 0) {
+    int n = 0;
+    for (int i = 0; i < B; ++i) {
+      bool seen = false;
+      for (int j = 0; j < i; ++j) if (pids[j] == pids[i]) { seen = true; break; }
+      n += seen ? 0 : 1;
+    }
+    s_n = n;
+  }
+  __syncthreads();
+  const int n = s_n;
+  const int csize = (B + n - 1) / n;            // torch.chunk: ceil(B / chunks) rows per chunk
+  const int nchunks = (B + csize - 1) / csize;
+  const int nuse = nchunks < n ? nchunks : n;
+  const int64_t BD = (int64_t)B * D;
+  if (dfeats) for (int64_t i = t; i < 3 * BD; i += 256) dfeats[i] = 0.f;
+  __syncthreads();
+  float loss = 0.f;
+  for (int ch = 0; ch < nuse; ++ch) {
+    const int r0 = ch * csize, r1 = min(B, r0 + csize), rows = r1 - r0;
+    float d12 = 0.f, d23 = 0.f, d13 = 0.f;
+    for (int k = t; k < D; k += 256) {
+      float c1 = 0.f, c2 = 0.f, c3 = 0.f;
+      for (int r = r0; r < r1; ++r) { c1 += feats[r * D + k]; c2 += feats[BD + r * D + k]; c3 += feats[2 * BD + r * D + k]; }
+      c1 /= rows; c2 /= rows; c3 /= rows;
+      d12 += (c1 - c2) * (c1 - c2);
+      d23 += (c2 - c3) * (c2 - c3);
+      d13 += (c1 - c3) * (c1 - c3);
+    }
+    red[0][t] = d12; red[1][t] = d23; red[2][t] = d13;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] += red[2][t + o]; }
+      __syncthreads();
+    }
+    if (t == 0) {
+      // python max(a, b, c) keeps the FIRST maximal argument: order (1,2), (2,3), (1,3)  (:35)
+      const float a1 = fabsf(margin - red[0][0]), a2 = fabsf(margin - red[1][0]), a3 = fabsf(margin - red[2][0]);
+      int sel = 0; float best = a1;
+      if (a2 > best) { best = a2; sel = 1; }
+      if (a3 > best) { best = a3; sel = 2; }
+      const float dsel = sel == 0 ? red[0][0] : (sel == 1 ? red[1][0] : red[2][0]);
+      const float x = margin - dsel;
+      s_sel = sel;
+      s_sign = x > 0.f ? -1.f : (x < 0.f ? 1.f : 0.f);   // d|m-d|/dd
+      red[0][0] = best;
+    }
+    __syncthreads();
+    loss += red[0][0];
+    if (dfeats) {
+      const int sel = s_sel;
+      const int ia = sel == 1 ? 1 : 0;          // pair (a,b): (0,1), (1,2), (0,2)
+      const int ib = sel == 0 ? 1 : 2;
+      const float coef = s_sign * 2.0f / rows * gscale;
+      for (int k = t; k < D; k += 256) {
+        float ca = 0.f, cb = 0.f;
+        for (int r = r0; r < r1; ++r) { ca += feats[ia * BD + r * D + k]; cb += feats[ib * BD + r * D + k]; }
+        const float diff = (ca - cb) / rows;
+        for (int r = r0; r < r1; ++r) {
+          dfeats[ia * BD + r * D + k] += coef * diff;
+          dfeats[ib * BD + r * D + k] -= coef * diff;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) { out[0] = loss; out[1] = (float)n; out[2] = (float)nchunks; }
+}
+
+// torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov=True) (reference optim/optimizer.py:130-138)
+__global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                    int64_t n, float lr, float momentum, float wd, int nesterov) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    float d = g[i] + wd * w;
+    float b = d;
+    if (momentum != 0.f) {
+      b = momentum * buf[i] + d;
+      buf[i] = b;
+      d = nesterov ? d + momentum * b : b;
+    }
+    p[i] = w - lr * d;
+  }
+}
+
+static int ewb(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace ieee
+
+using namespace ieee;
+
+static int fill_tab(PtrTab* t, const void* const* src, int groups) {
+  for (int i = 0; i < MAXG; ++i) t->p[i] = i < groups && src ? (void*)src[i] : nullptr;
+  return 0;
+}
+
+extern "C" int ieee_sgemm_grouped(int64_t groups, const void* const* A, const void* const* B, void* const* C,
+                                  const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak,
+                                  int64_t sbn, int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate,
+                                  void* stream) {
+  IEEE_REQUIRE(groups >= 1 && groups <= MAXG, "sgemm_grouped: groups %ld out of range [1,%d]", (long)groups, MAXG);
+  IEEE_REQUIRE(A && B && C, "sgemm_grouped: null pointer table");
+  IEEE_REQUIRE(M > 0 && N > 0 && K > 0, "sgemm_grouped: empty problem");
+  SgemmArgs a;
+  fill_tab(&a.A, A, (int)groups);
+  fill_tab(&a.B, B, (int)groups);
+  fill_tab(&a.C, (const void* const*)C, (int)groups);
+  fill_tab(&a.bias, bias, (int)groups);
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.sam = sam; a.sak = sak; a.sbn = sbn; a.sbk = sbk; a.ldc = ldc;
+  a.alpha = alpha; a.relu = relu; a.accumulate = accumulate;
+  dim3 grid(cdiv(N, 64), cdiv(M, 64), (unsigned)groups);
+  sgemm_grouped_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status("sgemm_grouped_kernel");
+}
+
+extern "C" int ieee_colsum_grouped(int64_t groups, const void* const* X, void* const* out, int64_t M, int64_t N,
+                                   int64_t ldx, int accumulate, void* stream) {
+  IEEE_REQUIRE(groups >= 1 && groups <= MAXG && X && out, "colsum_grouped: bad arguments");
+  ColsumArgs a;
+  fill_tab(&a.X, X, (int)groups);
+  fill_tab(&a.out, (const void* const*)out, (int)groups);
+  a.M = (int)M; a.N = (int)N; a.ldx = ldx; a.accumulate = accumulate;
+  colsum_grouped_kernel<<<dim3(cdiv(N, 128), (unsigned)groups), 128, 0, (hipStream_t)stream>>>(a);
+  return launch_status("colsum_grouped_kernel");
+}
+
+extern "C" int ieee_rowbn_fwd(int64_t groups, const void* const* x, void* const* out, const void* const* gamma,
+                              const void* const* beta, void* const* running_mean, void* const* running_var,
+                              void* const* save, int64_t R, int64_t C, int64_t ldx, int64_t ldo, float momentum,
+                              float eps, int training, int relu, void* stream) {
+  IEEE_REQUIRE(groups >= 1 && groups <= MAXG && x && out && gamma && beta, "rowbn_fwd: bad arguments");
+  IEEE_REQUIRE(training || (running_mean && running_var), "rowbn_fwd: eval mode needs running stats");
+  RowBnArgs a;
+  fill_tab(&a.x, x, (int)groups);
+  fill_tab(&a.out, (const void* const*)out, (int)groups);
+  fill_tab(&a.gamma, gamma, (int)groups);
+  fill_tab(&a.beta, beta, (int)groups);
+  fill_tab(&a.rmean, (const void* const*)running_mean, (int)groups);
+  fill_tab(&a.rvar, (const void* const*)running_var, (int)groups);
+  fill_tab(&a.save, (const void* const*)save, (int)groups);
+  a.R = (int)R; a.C = (int)C; a.ldx = ldx; a.ldo = ldo; a.momentum = momentum; a.eps = eps;
+  a.training = training; a.relu = relu;
+  rowbn_fwd_kernel<<<dim3(cdiv(C, 64), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status("rowbn_fwd_kernel");
+}
+
+extern "C" int ieee_rowbn_bwd(int64_t groups, const void* const* dout, const void* const* out, const void* const* x,
+                              const void* const* gamma, const void* const* save, void* const* dx,
+                              void* const* dgamma, void* const* dbeta, int64_t R, int64_t C, int64_t lddo,
+                              int64_t ldo, int64_t ldx, int64_t lddx, int relu, int accumulate, void* stream) {
+  IEEE_REQUIRE(groups >= 1 && groups <= MAXG && dout && out && x && gamma && save && dx && dgamma && dbeta,
+               "rowbn_bwd: bad arguments");
+  RowBnBwdArgs a;
+  fill_tab(&a.dout, dout, (int)groups);
+  fill_tab(&a.out, out, (int)groups);
+  fill_tab(&a.x, x, (int)groups);
+  fill_tab(&a.gamma, gamma, (int)groups);
+  fill_tab(&a.save, save, (int)groups);
+  fill_tab(&a.dx, (const void* const*)dx, (int)groups);
+  fill_tab(&a.dgamma, (const void* const*)dgamma, (int)groups);
+  fill_tab(&a.dbeta, (const void* const*)dbeta, (int)groups);
+  a.R = (int)R; a.C = (int)C; a.lddo = lddo; a.ldo = ldo; a.ldx = ldx; a.lddx = lddx;
+  a.relu = relu; a.accumulate = accumulate;
+  rowbn_bwd_kernel<<<dim3(cdiv(C, 64), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status("rowbn_bwd_kernel");
+}
+
+extern "C" int ieee_ca_mix_fwd(const float* h, float* hs, int64_t B, int64_t hidden, void* stream) {
+  IEEE_REQUIRE(h && hs, "ca_mix_fwd: null pointer");
+  add_halves_kernel<<<dim3(ewb(B * hidden), 3), 256, 0, (hipStream_t)stream>>>(h, hs, B * hidden, 2 * B * hidden,
+                                                                                B * hidden);
+  return launch_status("add_halves_kernel");
+}
+extern "C" int ieee_ca_mix_bwd(const float* dhs, const float* h, float* dh, int64_t B, int64_t hidden, void* stream) {
+  IEEE_REQUIRE(dhs && h && dh, "ca_mix_bwd: null pointer");
+  add_halves_bwd_kernel<<<dim3(ewb(B * hidden), 3), 256, 0, (hipStream_t)stream>>>(dhs, h, dh, B * hidden, B * hidden,
+                                                                                    2 * B * hidden);
+  return launch_status("add_halves_bwd_kernel");
+}
+extern "C" int ieee_sigmoid_fwd(float* x, int64_t n, void* stream) {
+  IEEE_REQUIRE(x, "sigmoid_fwd: null pointer");
+  sigmoid_kernel<<<ewb(n), 256, 0, (hipStream_t)stream>>>(x, n);
+  return launch_status("sigmoid_kernel");
+}
+extern "C" int ieee_sigmoid_bwd(const float* datt, const float* att, float* dz, int64_t n, void* stream) {
+  IEEE_REQUIRE(datt && att && dz, "sigmoid_bwd: null pointer");
+  sigmoid_bwd_kernel<<<ewb(n), 256, 0, (hipStream_t)stream>>>(datt, att, dz, n);
+  return launch_status("sigmoid_bwd_kernel");
+}
+
+extern "C" int ieee_rem_fwd(const float* part, const float* r, const float* param, int64_t param_gs, float* out,
+                            int64_t B, int64_t parts, int64_t D, void* stream) {
+  IEEE_REQUIRE(part && r && param && out, "rem_fwd: null pointer");
+  rem_fwd_kernel<<<dim3(ewb(B * parts * D), 3), 256, 0, (hipStream_t)stream>>>(part, r, param, param_gs, out, (int)B,
+                                                                                (int)parts, (int)D);
+  return launch_status("rem_fwd_kernel");
+}
+extern "C" int ieee_rem_bwd(const float* dout, const float* r, const float* param, int64_t param_gs, float* dr,
+                            float* dparam, int64_t grad_gs, float* work, int64_t B, int64_t parts, int64_t D,
+                            int accumulate, void* stream) {
+  IEEE_REQUIRE(dout && r && param && dr && dparam && work, "rem_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  rem_bwd_kernel<<<dim3((unsigned)B, 3), 256, 0, st>>>(dout, r, param, param_gs, dr, work, (int)B, (int)parts, (int)D);
+  IEEE_TRY(launch_status("rem_bwd_kernel"));
+  rem_dparam_kernel<<<1, 64, 0, st>>>(work, dparam, grad_gs, (int)B, accumulate);
+  return launch_status("rem_dparam_kernel");
+}
+
+extern "C" int ieee_l2norm_fwd(const float* x, float* y, float* norms, int64_t rows, int64_t D, void* stream) {
+  IEEE_REQUIRE(x && y && norms, "l2norm_fwd: null pointer");
+  l2norm_fwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, y, norms, rows, (int)D);
+  return launch_status("l2norm_fwd_kernel");
+}
+extern "C" int ieee_l2norm_bwd(const float* dy, const float* y, const float* norms, float* dx, int64_t rows,
+                               int64_t D, int accumulate, void* stream) {
+  IEEE_REQUIRE(dy && y && norms && dx, "l2norm_bwd: null pointer");
+  l2norm_bwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(dy, y, norms, dx, rows, (int)D, accumulate);
+  return launch_status("l2norm_bwd_kernel");
+}
+
+extern "C" int ieee_ce_ls_fwd_bwd(const float* logits, const int64_t* targets, float* dlogits, float* head_loss,
+                                  float* head_acc, float* work, int64_t heads, int64_t B, int64_t C, float eps,
+                                  float grad_scale, void* stream) {
+  IEEE_REQUIRE(logits && targets && head_loss && head_acc && work, "ce_ls_fwd_bwd: null pointer");
+  IEEE_REQUIRE(heads >= 1 && B >= 1 && C >= 1, "ce_ls_fwd_bwd: empty input");
+  hipStream_t st = (hipStream_t)stream;
+  float* rowloss = work;
+  int* correct = (int*)(work + heads * B);
+  ce_rows_kernel<<<cdiv(heads * B, 4), 256, 0, st>>>(logits, targets, rowloss, correct, dlogits, (int)heads, (int)B,
+                                                     (int)C, eps, grad_scale);
+  IEEE_TRY(launch_status("ce_rows_kernel"));
+  ce_heads_kernel<<<cdiv(heads, 64), 64, 0, st>>>(rowloss, correct, head_loss, head_acc, (int)heads, (int)B);
+  return launch_status("ce_heads_kernel");
+}
+
+extern "C" int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, float* dfeats, float* out3, int64_t B,
+                                     int64_t D, float margin, float grad_scale, void* stream) {
+  IEEE_REQUIRE(feats && pids && out3, "margin3m_fwd_bwd: null pointer");
+  IEEE_REQUIRE(B >= 1 && D >= 1, "margin3m_fwd_bwd: empty input");
+  margin3m_kernel<<<1, 256, 0, (hipStream_t)stream>>>(feats, pids, dfeats, out3, (int)B, (int)D, margin, grad_scale);
+  return launch_status("margin3m_kernel");
+}
+
+extern "C" int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
+                                      float momentum, float weight_decay, int nesterov, void* stream) {
+  IEEE_REQUIRE(params && grads && (momentum == 0.f || momentum_buf), "sgd_nesterov_step: null pointer");
+  if (n <= 0) return IEEE_OK;
+  sgd_nesterov_kernel<<<ewb(n), 256, 0, (hipStream_t)stream>>>(params, grads, momentum_buf, n, lr, momentum,
+                                                                weight_decay, nesterov);
+  return launch_status("sgd_nesterov_kernel");
+}

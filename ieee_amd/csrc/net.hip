@@ -1,0 +1,665 @@
+// Layer-graph executor for IEEE3modalPart (reference torchreid/models/ieee3modalPart.py:286-523 on
+// top of three torchreid/models/resnet.py ResNetIEEE trunks): plans one workspace arena, then
+// enqueues the whole forward / backward on the caller's stream as a fixed sequence of ieee_* kernels.
+// The three modality streams (RGB, NI, TI) are batched into every launch (groups = 3).
+// No allocation, no host synchronisation; parameters stay in the caller's flat fp32 buffers, laid
+// out exactly like the reference's state_dict (the caller binds name -> offset, see ieee_net_bind).
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+using namespace ieee;
+
+struct Tensor {
+  size_t off = 0;     // byte offset in the workspace
+  int64_t numel = 0;  // total elements (all groups)
+  int dtype = IEEE_F32;
+};
+
+struct ConvUnit {
+  std::string name;
+  int Ci, Co, R, stride, pad, Hi, Wi, Ho, Wo;
+  int s_w, s_g, s_b, s_rm, s_rv;   // slot ids of modality 0 (modality m = id + m)
+  Tensor y, a, stats, wf, wd;
+  bool need_dgrad = true;
+  int64_t M(int B) const { return (int64_t)B * Ho * Wo; }
+};
+
+struct Block {
+  int c1, c2, c3, ds;   // unit indices (ds = -1 when there is no downsample branch)
+};
+
+struct Net {
+  // config
+  int B, H, W, num_classes, dtype, interaction, attention, using_rem;
+  int parts = 6, rdim = 768, cdim = 128, fdim = 2048, hid = 128;
+  float bn_eps = 1e-5f, bn_mom = 0.1f;
+  // slots
+  std::vector<std::string> slot_names;
+  std::vector<int64_t> slot_off;
+  std::vector<int> triples;   // first slot id of every per-modality triple (uniform stride is required)
+  float *params = nullptr, *grads = nullptr, *buffers = nullptr;
+  bool bound = false;
+  // graph
+  std::vector<ConvUnit> units;
+  std::vector<Block> blocks;
+  int u_stem = -1, u_one = -1, u_rest = -1;
+  int s_ca1, s_ca2, s_rw, s_rg, s_rb, s_rrm, s_rrv, s_rem_param, s_rem_pw, s_rem_pb, s_rem_qw, s_rem_qb;
+  int s_fcw[18], s_fcb[18], s_fcg[18], s_fcbe[18], s_fcrm[18], s_fcrv[18], s_clw[18], s_clb[18];
+  // workspace
+  size_t ws_bytes = 0;
+  std::map<std::string, Tensor> tensors;
+  Tensor x0, pool, pool_arg, S, gbuf[5], slab, bnpart, bncoef;
+  Tensor Gp, avgmax, amax, Hh, Hs, att, Pp, Zg, Zp, glob, part, sv_g, sv_p, rr, part2, fcraw, sv_fc, featcat, fcall,
+      logits, featn, norms;
+  Tensor dfeatcat, dfcraw, dpart2, dr, dglob, dZp, dZg, dPp, dGp, datt, dHs, dH, davgmax, remwork;
+  int esz() const { return dtype == IEEE_BF16 ? 2 : 4; }
+
+  int slot3(const std::string& pattern) {   // registers the three per-modality names, returns the first id
+    const int id = (int)slot_names.size();
+    triples.push_back(id);
+    for (int m = 0; m < 3; ++m) {
+      std::string s = pattern;
+      const size_t p = s.find("{m}");
+      s.replace(p, 3, std::to_string(m));
+      slot_names.push_back(s);
+    }
+    return id;
+  }
+  int slot1(const std::string& name) {
+    slot_names.push_back(name);
+    return (int)slot_names.size() - 1;
+  }
+  Tensor alloc(const std::string& name, int64_t numel, int dt) {
+    Tensor t;
+    t.off = ws_bytes;
+    t.numel = numel;
+    t.dtype = dt;
+    const size_t bytes = (size_t)numel * (dt == IEEE_BF16 ? 2 : (dt == 2 ? 1 : 4));
+    ws_bytes += (bytes + 255) / 256 * 256;
+    if (!name.empty()) tensors[name] = t;
+    return t;
+  }
+  int add_unit(const std::string& conv, const std::string& bn, int Ci, int Co, int R, int stride, int pad, int Hi,
+               int Wi) {
+    ConvUnit u;
+    u.name = conv;
+    u.Ci = Ci; u.Co = Co; u.R = R; u.stride = stride; u.pad = pad; u.Hi = Hi; u.Wi = Wi;
+    u.Ho = (Hi + 2 * pad - R) / stride + 1;
+    u.Wo = (Wi + 2 * pad - R) / stride + 1;
+    u.s_w = slot3(conv + ".weight");
+    u.s_g = slot3(bn + ".weight");
+    u.s_b = slot3(bn + ".bias");
+    u.s_rm = slot3(bn + ".running_mean");
+    u.s_rv = slot3(bn + ".running_var");
+    units.push_back(u);
+    return (int)units.size() - 1;
+  }
+  void build();
+  void plan();
+};
+
+void Net::build() {
+  const std::string bb = "backbone.{m}.";
+  u_stem = add_unit(bb + "conv1", bb + "bn1", 3, 64, 7, 2, 3, H, W);
+  units[u_stem].need_dgrad = false;
+  int h = units[u_stem].Ho, w = units[u_stem].Wo;
+  h = (h + 2 - 3) / 2 + 1;   // maxpool 3x3 s2 p1
+  w = (w + 2 - 3) / 2 + 1;
+  int inpl = 64;
+  const int planes[4] = {64, 128, 256, 512}, nblk[4] = {3, 4, 6, 3}, strides[4] = {1, 2, 2, 1};   // last_stride = 1
+  for (int L = 0; L < 4; ++L) {
+    for (int b = 0; b < nblk[L]; ++b) {
+      const std::string p = bb + "layer" + std::to_string(L + 1) + "." + std::to_string(b) + ".";
+      const int st = b == 0 ? strides[L] : 1;
+      Block blk;
+      blk.c1 = add_unit(p + "conv1", p + "bn1", inpl, planes[L], 1, 1, 0, h, w);
+      blk.c2 = add_unit(p + "conv2", p + "bn2", planes[L], planes[L], 3, st, 1, h, w);
+      const int ho = units[blk.c2].Ho, wo = units[blk.c2].Wo;
+      blk.c3 = add_unit(p + "conv3", p + "bn3", planes[L], planes[L] * 4, 1, 1, 0, ho, wo);
+      blk.ds = -1;
+      if (b == 0) blk.ds = add_unit(p + "downsample.0", p + "downsample.1", inpl, planes[L] * 4, 1, st, 0, h, w);
+      blocks.push_back(blk);
+      inpl = planes[L] * 4;
+      h = ho; w = wo;
+    }
+  }
+  u_one = add_unit("convOne.{m}.layers.0", "convOne.{m}.layers.1", fdim, fdim, 1, 1, 0, h, w);
+  u_rest = add_unit("convAvgRest.{m}.layers.0", "convAvgRest.{m}.layers.1", fdim, fdim, 1, 1, 0, h, w);
+  s_ca1 = slot3("CA.{m}.fc.0.weight");
+  s_ca2 = slot3("CA.{m}.fc.2.weight");
+  s_rw = slot3("reduce_layer.{m}.layers.0.weight");
+  s_rg = slot3("reduce_layer.{m}.layers.1.weight");
+  s_rb = slot3("reduce_layer.{m}.layers.1.bias");
+  s_rrm = slot3("reduce_layer.{m}.layers.1.running_mean");
+  s_rrv = slot3("reduce_layer.{m}.layers.1.running_var");
+  s_rem_param = slot3("REM.{m}.param");
+  s_rem_pw = slot3("REM.{m}.conv_part.weight");
+  s_rem_pb = slot3("REM.{m}.conv_part.bias");
+  s_rem_qw = slot3("REM.{m}.conv_query.weight");
+  s_rem_qb = slot3("REM.{m}.conv_query.bias");
+  const char* letters[3] = {"R", "N", "T"};
+  for (int m = 0; m < 3; ++m)
+    for (int i = 0; i < 6; ++i) {
+      const int g = m * 6 + i;
+      const std::string f = std::string("fc_") + letters[m] + "." + std::to_string(i) + ".";
+      const std::string c = std::string("classifier_") + letters[m] + "." + std::to_string(i) + ".";
+      s_fcw[g] = slot1(f + "0.weight");
+      s_fcb[g] = slot1(f + "0.bias");
+      s_fcg[g] = slot1(f + "1.weight");
+      s_fcbe[g] = slot1(f + "1.bias");
+      s_fcrm[g] = slot1(f + "1.running_mean");
+      s_fcrv[g] = slot1(f + "1.running_var");
+      s_clw[g] = slot1(c + "weight");
+      s_clb[g] = slot1(c + "bias");
+    }
+  slot_off.assign(slot_names.size(), -1);
+}
+
+extern "C" int64_t ieee_conv_packed_ld(int dtype, int64_t inner_channels, int64_t R, int64_t S);
+extern "C" int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, int64_t N, int64_t Ho, int64_t Wo,
+                                                     int64_t Ci, int64_t Co, int64_t R, int64_t S);
+extern "C" int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C);
+
+void Net::plan() {
+  ws_bytes = 0;
+  const int dt = dtype;
+  x0 = alloc("x0", (int64_t)3 * B * H * W * 3, dt);
+  int64_t max_act = 0, max_slab = 0, max_part = 0, max_c = 0;
+  for (size_t i = 0; i < units.size(); ++i) {
+    ConvUnit& u = units[i];
+    const int64_t n = 3 * u.M(B) * u.Co;
+    u.y = alloc(u.name + ".y", n, dt);
+    u.a = alloc(u.name + ".a", n, dt);
+    u.stats = alloc(u.name + ".stats", (int64_t)3 * 4 * u.Co, IEEE_F32);
+    u.wf = alloc("", 3 * u.Co * ieee_conv_packed_ld(dt, u.Ci, u.R, u.R), dt);
+    if (u.need_dgrad) u.wd = alloc("", 3 * u.Ci * ieee_conv_packed_ld(dt, u.Co, u.R, u.R), dt);
+    max_act = std::max(max_act, n);
+    max_act = std::max(max_act, (int64_t)3 * B * u.Hi * u.Wi * u.Ci);
+    max_slab = std::max(max_slab, ieee_conv2d_wgrad_workspace_bytes(dt, 3, B, u.Ho, u.Wo, u.Ci, u.Co, u.R, u.R));
+    max_part = std::max(max_part, 3 * ieee_bn_partial_floats(dt, u.M(B), u.Co));
+    max_c = std::max(max_c, (int64_t)u.Co);
+  }
+  const ConvUnit& st = units[u_stem];
+  const int ph = (st.Ho + 2 - 3) / 2 + 1, pw = (st.Wo + 2 - 3) / 2 + 1;
+  pool = alloc("pool", (int64_t)3 * B * ph * pw * 64, dt);
+  pool_arg = alloc("pool.arg", (int64_t)3 * B * ph * pw * 64, 2 /*u8*/);
+  const ConvUnit& uo = units[u_one];
+  const int64_t P = (int64_t)uo.Hi * uo.Wi;
+  S = alloc("S", (int64_t)3 * B * P * fdim, dt);
+  for (int i = 0; i < 5; ++i) gbuf[i] = alloc("g" + std::to_string(i), max_act, dt);
+  slab = alloc("", max_slab / 4 + 64, IEEE_F32);
+  bnpart = alloc("", max_part + 64, IEEE_F32);
+  bncoef = alloc("", 3 * 3 * max_c, IEEE_F32);
+  const int64_t Bq = B;
+  Gp = alloc("Gp", 3 * Bq * fdim, IEEE_F32);
+  avgmax = alloc("avgmax", 3 * 2 * Bq * fdim, IEEE_F32);
+  amax = alloc("amax", 3 * Bq * fdim, IEEE_F32);
+  Hh = alloc("H", 3 * 2 * Bq * hid, IEEE_F32);
+  Hs = alloc("Hs", 3 * Bq * hid, IEEE_F32);
+  att = alloc("att", 3 * Bq * fdim, IEEE_F32);
+  Pp = alloc("Pp", 3 * Bq * parts * fdim, IEEE_F32);
+  Zg = alloc("Zg", 3 * Bq * rdim, IEEE_F32);
+  Zp = alloc("Zp", 3 * Bq * parts * rdim, IEEE_F32);
+  glob = alloc("glob", 3 * Bq * rdim, IEEE_F32);
+  part = alloc("part", 3 * Bq * parts * rdim, IEEE_F32);
+  sv_g = alloc("", 3 * 2 * rdim, IEEE_F32);
+  sv_p = alloc("", 3 * 2 * rdim, IEEE_F32);
+  rr = alloc("r", 3 * Bq * rdim, IEEE_F32);
+  part2 = alloc("part2", 3 * Bq * parts * rdim, IEEE_F32);
+  fcraw = alloc("fcraw", 18 * Bq * cdim, IEEE_F32);
+  sv_fc = alloc("", 18 * 2 * cdim, IEEE_F32);
+  featcat = alloc("featcat", 3 * Bq * rdim, IEEE_F32);
+  fcall = alloc("fcall", Bq * 3 * rdim, IEEE_F32);
+  logits = alloc("logits", 18 * Bq * num_classes, IEEE_F32);
+  featn = alloc("featn", 3 * Bq * rdim, IEEE_F32);
+  norms = alloc("", 3 * Bq, IEEE_F32);
+  dfeatcat = alloc("dfeatcat", 3 * Bq * rdim, IEEE_F32);
+  dfcraw = alloc("dfcraw", 18 * Bq * cdim, IEEE_F32);
+  dpart2 = alloc("dpart2", 3 * Bq * parts * rdim, IEEE_F32);
+  dr = alloc("dr", 3 * Bq * rdim, IEEE_F32);
+  dglob = alloc("dglob", 3 * Bq * rdim, IEEE_F32);
+  dZp = alloc("dZp", 3 * Bq * parts * rdim, IEEE_F32);
+  dZg = alloc("dZg", 3 * Bq * rdim, IEEE_F32);
+  dPp = alloc("dPp", 3 * Bq * parts * fdim, IEEE_F32);
+  dGp = alloc("dGp", 3 * Bq * fdim, IEEE_F32);
+  datt = alloc("datt", 3 * Bq * fdim, IEEE_F32);
+  dHs = alloc("dHs", 3 * Bq * hid, IEEE_F32);
+  dH = alloc("dH", 3 * 2 * Bq * hid, IEEE_F32);
+  davgmax = alloc("davgmax", 3 * 2 * Bq * fdim, IEEE_F32);
+  remwork = alloc("", 3 * Bq + 64, IEEE_F32);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct Run {
+  Net& n;
+  char* ws;
+  void* st;
+  int B;
+  Run(Net& net, void* workspace, void* stream) : n(net), ws((char*)workspace), st(stream), B(net.B) {}
+  void* P(const Tensor& t) const { return ws + t.off; }
+  float* F(const Tensor& t) const { return (float*)(ws + t.off); }
+  float* par(int slot) const { return n.params + n.slot_off[slot]; }
+  float* grd(int slot) const { return n.grads + n.slot_off[slot]; }
+  float* buf(int slot) const { return n.buffers + n.slot_off[slot]; }
+  int64_t gs(int slot) const { return n.slot_off[slot + 1] - n.slot_off[slot]; }
+
+  int pack(const ConvUnit& u, bool with_dgrad) {
+    const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.R);
+    IEEE_TRY(ieee_pack_conv_weight(par(u.s_w), P(u.wf), n.dtype, 0, 3, u.Co, u.Ci, u.R, u.R, gs(u.s_w), u.Co * ldf, st));
+    if (with_dgrad && u.need_dgrad) {
+      const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.R);
+      IEEE_TRY(ieee_pack_conv_weight(par(u.s_w), P(u.wd), n.dtype, 1, 3, u.Co, u.Ci, u.R, u.R, gs(u.s_w), u.Ci * ldd, st));
+    }
+    return IEEE_OK;
+  }
+  int conv(const ConvUnit& u, const void* in) {
+    const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.R);
+    return ieee_conv2d_fwd(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.R, u.stride, u.pad,
+                           (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, st);
+  }
+  int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training) {
+    return ieee_bn2d_fwd(P(u.y), residual, out, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b),
+                         gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), F(n.bnpart), n.bn_mom, n.bn_eps,
+                         training, relu, st);
+  }
+  // backward of out = [relu](bn(y) [+res]); dy may alias dout
+  int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout) {
+    return ieee_bn2d_bwd(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
+                         F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), F(n.bnpart), F(n.bncoef), 0, st);
+  }
+  int wgrad(const ConvUnit& u, const void* dy, const void* x) {
+    return ieee_conv2d_wgrad(dy, x, grd(u.s_w), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.R, u.stride,
+                             u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, gs(u.s_w), 0, st);
+  }
+  int dgrad(const ConvUnit& u, const void* dy, void* dx, const void* addend) {
+    const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.R);
+    return ieee_conv2d_dgrad(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.R, u.stride, u.pad,
+                             u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, st);
+  }
+  // grouped fp32 GEMM over the 3 modalities with uniform strides
+  int gemm3(const float* A, int64_t a_gs, const float* Bm, int64_t b_gs, float* C, int64_t c_gs, const float* bias,
+            int64_t bias_gs, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk,
+            int64_t ldc, int relu, int acc) {
+    const void* a[3]; const void* b[3]; void* c[3]; const void* bi[3];
+    for (int m = 0; m < 3; ++m) { a[m] = A + m * a_gs; b[m] = Bm + m * b_gs; c[m] = C + m * c_gs; bi[m] = bias ? bias + m * bias_gs : nullptr; }
+    return ieee_sgemm_grouped(3, a, b, c, bias ? bi : nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 1.0f, relu, acc, st);
+  }
+  int forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out);
+  int backward(const float* dlogits, const float* dfeats);
+};
+
+int Run::forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out) {
+  Net& N = n;
+  const int dt = N.dtype;
+  for (auto& u : N.units) {
+    const bool used = N.interaction || (&u != &N.units[N.u_one] && &u != &N.units[N.u_rest]);
+    if (used) IEEE_TRY(pack(u, training != 0));
+  }
+  IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, st));
+  // stem: conv7x7/2 -> BN -> ReLU -> maxpool3x3/2   (resnet.py:622-626)
+  const ConvUnit& s = N.units[N.u_stem];
+  IEEE_TRY(conv(s, P(N.x0)));
+  IEEE_TRY(bn(s, nullptr, P(s.a), 1, training));
+  IEEE_TRY(ieee_maxpool3x3s2_fwd(P(s.a), P(N.pool), (uint8_t*)P(N.pool_arg), dt, 3, B, s.Ho, s.Wo, s.Co, st));
+  const void* x = P(N.pool);
+  for (const Block& b : N.blocks) {   // Bottleneck.forward, resnet.py:164-184
+    const ConvUnit &c1 = N.units[b.c1], &c2 = N.units[b.c2], &c3 = N.units[b.c3];
+    IEEE_TRY(conv(c1, x));
+    IEEE_TRY(bn(c1, nullptr, P(c1.a), 1, training));
+    IEEE_TRY(conv(c2, P(c1.a)));
+    IEEE_TRY(bn(c2, nullptr, P(c2.a), 1, training));
+    IEEE_TRY(conv(c3, P(c2.a)));
+    const void* identity = x;
+    if (b.ds >= 0) {
+      const ConvUnit& d = N.units[b.ds];
+      IEEE_TRY(conv(d, x));
+      IEEE_TRY(bn(d, nullptr, P(d.a), 0, training));
+      identity = P(d.a);
+    }
+    IEEE_TRY(bn(c3, identity, P(c3.a), 1, training));
+    x = P(c3.a);
+  }
+  const void* Fm = x;   // [3][B][16*8][2048]
+  const ConvUnit &uo = N.units[N.u_one], &ur = N.units[N.u_rest];
+  const int Hh_ = uo.Hi, Ww = uo.Wi, C = N.fdim;
+  const int64_t BC = (int64_t)B * C;
+  // global average pool of the raw trunk map (+ sum of the two other modalities for the CIM)   :445-451
+  IEEE_TRY(ieee_gpool_sum_others(Fm, N.interaction ? P(N.S) : nullptr, F(N.Gp), dt, B, Hh_, Ww, C, st));
+  const int mode = !N.interaction ? 2 : (N.attention ? 0 : 1);
+  if (N.interaction) {
+    IEEE_TRY(conv(uo, Fm));
+    IEEE_TRY(ieee_bn2d_fwd(P(uo.y), nullptr, nullptr, dt, 3, uo.M(B), C, uo.M(B) * C, par(uo.s_g), par(uo.s_b), gs(uo.s_g),
+                           buf(uo.s_rm), buf(uo.s_rv), gs(uo.s_rm), F(uo.stats), F(N.bnpart), N.bn_mom, N.bn_eps, training,
+                           1, st));
+    IEEE_TRY(conv(ur, P(N.S)));
+    IEEE_TRY(ieee_bn2d_fwd(P(ur.y), nullptr, nullptr, dt, 3, ur.M(B), C, ur.M(B) * C, par(ur.s_g), par(ur.s_b), gs(ur.s_g),
+                           buf(ur.s_rm), buf(ur.s_rv), gs(ur.s_rm), F(ur.stats), F(N.bnpart), N.bn_mom, N.bn_eps, training,
+                           1, st));
+    if (N.attention) {   // ChannelAttention.forward :277-282
+      IEEE_TRY(ieee_ca_pool(P(ur.y), F(ur.stats), F(N.avgmax), F(N.avgmax) + BC, 2 * BC, (int32_t*)P(N.amax), dt, B, Hh_,
+                            Ww, C, st));
+      IEEE_TRY(gemm3(F(N.avgmax), 2 * BC, par(N.s_ca1), gs(N.s_ca1), F(N.Hh), 2 * B * N.hid, nullptr, 0, 2 * B, N.hid, C,
+                     C, 1, C, 1, N.hid, 1, 0));
+      IEEE_TRY(ieee_ca_mix_fwd(F(N.Hh), F(N.Hs), B, N.hid, st));
+      IEEE_TRY(gemm3(F(N.Hs), (int64_t)B * N.hid, par(N.s_ca2), gs(N.s_ca2), F(N.att), BC, nullptr, 0, B, C, N.hid,
+                     N.hid, 1, N.hid, 1, C, 0, 0));
+      IEEE_TRY(ieee_sigmoid_fwd(F(N.att), 3 * BC, st));
+    }
+    IEEE_TRY(ieee_cim_tail_fwd(P(uo.y), P(ur.y), F(uo.stats), F(ur.stats), F(N.att), F(N.Pp), dt, B, Hh_, Ww, C, N.parts,
+                               mode, st));
+  } else {
+    IEEE_TRY(ieee_cim_tail_fwd(Fm, nullptr, nullptr, nullptr, nullptr, F(N.Pp), dt, B, Hh_, Ww, C, N.parts, 2, st));
+  }
+  // reduce_layer applied twice: global vector first, then the 6 parts (two running-stat updates)  :449-455
+  const int R = N.rdim, PB = N.parts * B;
+  IEEE_TRY(gemm3(F(N.Gp), BC, par(N.s_rw), gs(N.s_rw), F(N.Zg), (int64_t)B * R, nullptr, 0, B, R, C, C, 1, C, 1, R, 0, 0));
+  IEEE_TRY(gemm3(F(N.Pp), (int64_t)PB * C, par(N.s_rw), gs(N.s_rw), F(N.Zp), (int64_t)PB * R, nullptr, 0, PB, R, C, C, 1,
+                 C, 1, R, 0, 0));
+  {
+    const void *x1[3], *x2[3], *ga[3], *be[3];
+    void *o1[3], *o2[3], *rm[3], *rv[3], *s1[3], *s2[3];
+    for (int m = 0; m < 3; ++m) {
+      x1[m] = F(N.Zg) + (int64_t)m * B * R; o1[m] = F(N.glob) + (int64_t)m * B * R;
+      x2[m] = F(N.Zp) + (int64_t)m * PB * R; o2[m] = F(N.part) + (int64_t)m * PB * R;
+      ga[m] = par(N.s_rg + m); be[m] = par(N.s_rb + m); rm[m] = buf(N.s_rrm + m); rv[m] = buf(N.s_rrv + m);
+      s1[m] = F(N.sv_g) + m * 2 * R; s2[m] = F(N.sv_p) + m * 2 * R;
+    }
+    IEEE_TRY(ieee_rowbn_fwd(3, x1, o1, ga, be, rm, rv, s1, B, R, R, R, N.bn_mom, N.bn_eps, training, 1, st));
+    IEEE_TRY(ieee_rowbn_fwd(3, x2, o2, ga, be, rm, rv, s2, PB, R, R, R, N.bn_mom, N.bn_eps, training, 1, st));
+  }
+  // REM (nonLocal) closed form: part + 2*param*(W_p global + b_p)   :60-80, :484-488
+  const float* p2 = F(N.part);
+  if (N.using_rem) {
+    IEEE_TRY(gemm3(F(N.glob), (int64_t)B * R, par(N.s_rem_pw), gs(N.s_rem_pw), F(N.rr), (int64_t)B * R, par(N.s_rem_pb),
+                   gs(N.s_rem_pb), B, R, R, R, 1, R, 1, R, 0, 0));
+    IEEE_TRY(ieee_rem_fwd(F(N.part), F(N.rr), par(N.s_rem_param), gs(N.s_rem_param), F(N.part2), B, N.parts, R, st));
+    p2 = F(N.part2);
+  }
+  // 18 heads: Linear(768,128) + BatchNorm1d + ReLU, concatenated per modality   :491-502
+  const int D = N.cdim;
+  {
+    const void *a[18], *w[18], *bi[18], *ga[18], *be[18], *xs[18];
+    void *c[18], *o[18], *rm[18], *rv[18], *sv[18];
+    const int eval_off[3] = {R, 2 * R, 0};   // eval: fc_all = cat([T, R, N])   :502
+    for (int m = 0; m < 3; ++m)
+      for (int i = 0; i < 6; ++i) {
+        const int g = m * 6 + i;
+        a[g] = p2 + (int64_t)m * PB * R + i * R;
+        w[g] = par(N.s_fcw[g]); bi[g] = par(N.s_fcb[g]);
+        c[g] = F(N.fcraw) + (int64_t)g * B * D; xs[g] = c[g];
+        ga[g] = par(N.s_fcg[g]); be[g] = par(N.s_fcbe[g]); rm[g] = buf(N.s_fcrm[g]); rv[g] = buf(N.s_fcrv[g]);
+        sv[g] = F(N.sv_fc) + g * 2 * D;
+        o[g] = training ? (void*)(F(N.featcat) + (int64_t)m * B * R + i * D) : (void*)(F(N.fcall) + eval_off[m] + i * D);
+      }
+    IEEE_TRY(ieee_sgemm_grouped(18, a, w, c, bi, B, D, R, (int64_t)N.parts * R, 1, R, 1, D, 1.0f, 0, 0, st));
+    IEEE_TRY(ieee_rowbn_fwd(18, xs, o, ga, be, rm, rv, sv, B, D, D, training ? R : 3 * R, N.bn_mom, N.bn_eps, training, 1, st));
+  }
+  if (!training) {
+    IEEE_HIP(hipMemcpyAsync(feats_out, F(N.fcall), sizeof(float) * (size_t)B * 3 * R, hipMemcpyDeviceToDevice, (hipStream_t)st));
+    return IEEE_OK;
+  }
+  {   // classifiers   :507-511
+    const void *a[18], *w[18], *bi[18];
+    void* c[18];
+    const int NC = N.num_classes;
+    for (int m = 0; m < 3; ++m)
+      for (int i = 0; i < 6; ++i) {
+        const int g = m * 6 + i;
+        a[g] = F(N.featcat) + (int64_t)m * B * R + i * D;
+        w[g] = par(N.s_clw[g]); bi[g] = par(N.s_clb[g]);
+        c[g] = logits_out + (int64_t)g * B * NC;
+      }
+    IEEE_TRY(ieee_sgemm_grouped(18, a, w, c, bi, B, NC, D, R, 1, D, 1, NC, 1.0f, 0, 0, st));
+  }
+  // F.normalize per modality   :519
+  IEEE_TRY(ieee_l2norm_fwd(F(N.featcat), F(N.featn), F(N.norms), 3 * (int64_t)B, R, st));
+  IEEE_HIP(hipMemcpyAsync(feats_out, F(N.featn), sizeof(float) * (size_t)3 * B * R, hipMemcpyDeviceToDevice, (hipStream_t)st));
+  return IEEE_OK;
+}
+
+int Run::backward(const float* dlogits, const float* dfeats) {
+  Net& N = n;
+  const int dt = N.dtype;
+  const int R = N.rdim, D = N.cdim, C = N.fdim, PB = N.parts * B, NC = N.num_classes;
+  const int64_t BC = (int64_t)B * C;
+  const ConvUnit &uo = N.units[N.u_one], &ur = N.units[N.u_rest];
+  const int Hh_ = uo.Hi, Ww = uo.Wi;
+  const float* p2 = N.using_rem ? F(N.part2) : F(N.part);
+  // l2norm
+  IEEE_TRY(ieee_l2norm_bwd(dfeats, F(N.featn), F(N.norms), F(N.dfeatcat), 3 * (int64_t)B, R, 0, st));
+  {
+    const void *dl[18], *fe[18], *w[18], *xs[18], *ga[18], *sv[18], *dfr[18], *pp[18];
+    void *dw[18], *db[18], *dfc[18], *dx[18], *dg[18], *dbe[18], *dwf[18], *dbf[18], *dp2[18];
+    for (int m = 0; m < 3; ++m)
+      for (int i = 0; i < 6; ++i) {
+        const int g = m * 6 + i;
+        dl[g] = dlogits + (int64_t)g * B * NC;
+        fe[g] = F(N.featcat) + (int64_t)m * B * R + i * D;
+        w[g] = par(N.s_clw[g]);
+        dw[g] = grd(N.s_clw[g]); db[g] = grd(N.s_clb[g]);
+        dfc[g] = F(N.dfeatcat) + (int64_t)m * B * R + i * D;
+        xs[g] = F(N.fcraw) + (int64_t)g * B * D;
+        ga[g] = par(N.s_fcg[g]); sv[g] = F(N.sv_fc) + g * 2 * D;
+        dx[g] = F(N.dfcraw) + (int64_t)g * B * D; dfr[g] = dx[g];
+        dg[g] = grd(N.s_fcg[g]); dbe[g] = grd(N.s_fcbe[g]);
+        dwf[g] = grd(N.s_fcw[g]); dbf[g] = grd(N.s_fcb[g]);
+        pp[g] = p2 + (int64_t)m * PB * R + i * R;
+        dp2[g] = F(N.dpart2) + (int64_t)m * PB * R + i * R;
+      }
+    // classifier: dW = dlogits^T feat, db = colsum, dfeat += dlogits W
+    IEEE_TRY(ieee_sgemm_grouped(18, dl, fe, dw, nullptr, NC, D, B, 1, NC, 1, R, D, 1.0f, 0, 0, st));
+    IEEE_TRY(ieee_colsum_grouped(18, dl, db, B, NC, NC, 0, st));
+    IEEE_TRY(ieee_sgemm_grouped(18, dl, w, dfc, nullptr, B, D, NC, NC, 1, 1, D, R, 1.0f, 0, 1, st));
+    // fc: BN1d+ReLU backward, then Linear backward
+    IEEE_TRY(ieee_rowbn_bwd(18, (const void* const*)dfc, fe, xs, ga, sv, dx, dg, dbe, B, D, R, R, D, D, 1, 0, st));
+    IEEE_TRY(ieee_sgemm_grouped(18, dfr, pp, dwf, nullptr, D, R, B, 1, D, 1, (int64_t)N.parts * R, R, 1.0f, 0, 0, st));
+    IEEE_TRY(ieee_colsum_grouped(18, dfr, dbf, B, D, D, 0, st));
+    const void* wf[18];
+    for (int g = 0; g < 18; ++g) wf[g] = par(N.s_fcw[g]);
+    IEEE_TRY(ieee_sgemm_grouped(18, dfr, wf, dp2, nullptr, B, R, D, D, 1, 1, R, (int64_t)N.parts * R, 1.0f, 0, 0, st));
+  }
+  // REM backward
+  bool have_dglob = false;
+  if (N.using_rem) {
+    IEEE_TRY(ieee_rem_bwd(F(N.dpart2), F(N.rr), par(N.s_rem_param), gs(N.s_rem_param), F(N.dr), grd(N.s_rem_param),
+                          gs(N.s_rem_param), F(N.remwork), B, N.parts, R, 0, st));
+    // conv_part: dW = dr^T glob, db = colsum(dr), dglob = dr W
+    IEEE_TRY(gemm3(F(N.dr), (int64_t)B * R, F(N.glob), (int64_t)B * R, grd(N.s_rem_pw), gs(N.s_rem_pw), nullptr, 0, R, R, B,
+                   1, R, 1, R, R, 0, 0));
+    {
+      const void* x[3]; void* o[3];
+      for (int m = 0; m < 3; ++m) { x[m] = F(N.dr) + (int64_t)m * B * R; o[m] = grd(N.s_rem_pb + m); }
+      IEEE_TRY(ieee_colsum_grouped(3, x, o, B, R, R, 0, st));
+    }
+    IEEE_TRY(gemm3(F(N.dr), (int64_t)B * R, par(N.s_rem_pw), gs(N.s_rem_pw), F(N.dglob), (int64_t)B * R, nullptr, 0, B, R, R,
+                   R, 1, 1, R, R, 0, 0));
+    have_dglob = true;
+    // conv_query receives exact zeros; conv_value receives no gradient at all
+    for (int m = 0; m < 3; ++m) {
+      IEEE_HIP(hipMemsetAsync(grd(N.s_rem_qw + m), 0, sizeof(float) * (size_t)R * R, (hipStream_t)st));
+      IEEE_HIP(hipMemsetAsync(grd(N.s_rem_qb + m), 0, sizeof(float) * (size_t)R, (hipStream_t)st));
+    }
+  }
+  {   // reduce_layer BN(+ReLU) backward: parts first (overwrite), then the global vector (accumulate)
+    const void *d1[3], *o1[3], *x1[3], *ga[3], *s1[3], *d2[3], *o2[3], *x2[3], *s2[3];
+    void *dx1[3], *dx2[3], *dg[3], *db[3];
+    for (int m = 0; m < 3; ++m) {
+      d1[m] = F(N.dpart2) + (int64_t)m * PB * R; o1[m] = F(N.part) + (int64_t)m * PB * R; x1[m] = F(N.Zp) + (int64_t)m * PB * R;
+      dx1[m] = F(N.dZp) + (int64_t)m * PB * R; s1[m] = F(N.sv_p) + m * 2 * R;
+      d2[m] = F(N.dglob) + (int64_t)m * B * R; o2[m] = F(N.glob) + (int64_t)m * B * R; x2[m] = F(N.Zg) + (int64_t)m * B * R;
+      dx2[m] = F(N.dZg) + (int64_t)m * B * R; s2[m] = F(N.sv_g) + m * 2 * R;
+      ga[m] = par(N.s_rg + m); dg[m] = grd(N.s_rg + m); db[m] = grd(N.s_rb + m);
+    }
+    IEEE_TRY(ieee_rowbn_bwd(3, d1, o1, x1, ga, s1, dx1, dg, db, PB, R, R, R, R, R, 1, 0, st));
+    if (have_dglob) IEEE_TRY(ieee_rowbn_bwd(3, d2, o2, x2, ga, s2, dx2, dg, db, B, R, R, R, R, R, 1, 1, st));
+  }
+  // reduce conv: dWr = dZp^T Pp (+ dZg^T Gp); dPp = dZp Wr; dGp = dZg Wr
+  IEEE_TRY(gemm3(F(N.dZp), (int64_t)PB * R, F(N.Pp), (int64_t)PB * C, grd(N.s_rw), gs(N.s_rw), nullptr, 0, R, C, PB, 1, R, 1,
+                 C, C, 0, 0));
+  IEEE_TRY(gemm3(F(N.dZp), (int64_t)PB * R, par(N.s_rw), gs(N.s_rw), F(N.dPp), (int64_t)PB * C, nullptr, 0, PB, C, R, R, 1, 1,
+                 C, C, 0, 0));
+  if (have_dglob) {
+    IEEE_TRY(gemm3(F(N.dZg), (int64_t)B * R, F(N.Gp), BC, grd(N.s_rw), gs(N.s_rw), nullptr, 0, R, C, B, 1, R, 1, C, C, 0, 1));
+    IEEE_TRY(gemm3(F(N.dZg), (int64_t)B * R, par(N.s_rw), gs(N.s_rw), F(N.dGp), BC, nullptr, 0, B, C, R, R, 1, 1, C, C, 0, 0));
+  } else {
+    IEEE_HIP(hipMemsetAsync(P(N.dGp), 0, sizeof(float) * (size_t)3 * BC, (hipStream_t)st));
+  }
+  // CIM backward -> gradient w.r.t. the trunk output in gbuf[0]
+  void* dF = P(N.gbuf[0]);
+  const void* Fm = P(N.units[N.blocks.back().c3].a);
+  const int mode = !N.interaction ? 2 : (N.attention ? 0 : 1);
+  if (N.interaction) {
+    if (N.attention) {
+      IEEE_TRY(ieee_cim_tail_bwd_datt(F(N.dPp), P(ur.y), F(ur.stats), F(N.datt), dt, B, Hh_, Ww, C, N.parts, st));
+      IEEE_TRY(ieee_sigmoid_bwd(F(N.datt), F(N.att), F(N.datt), 3 * BC, st));   // in place: datt -> dz
+      // W2: dW2 = dz^T Hs ; dHs = dz W2
+      IEEE_TRY(gemm3(F(N.datt), BC, F(N.Hs), (int64_t)B * N.hid, grd(N.s_ca2), gs(N.s_ca2), nullptr, 0, C, N.hid, B, 1, C, 1,
+                     N.hid, N.hid, 0, 0));
+      IEEE_TRY(gemm3(F(N.datt), BC, par(N.s_ca2), gs(N.s_ca2), F(N.dHs), (int64_t)B * N.hid, nullptr, 0, B, N.hid, C, C, 1, 1,
+                     N.hid, N.hid, 0, 0));
+      IEEE_TRY(ieee_ca_mix_bwd(F(N.dHs), F(N.Hh), F(N.dH), B, N.hid, st));
+      // W1: dW1 = dH^T avgmax ; davgmax = dH W1
+      IEEE_TRY(gemm3(F(N.dH), 2 * (int64_t)B * N.hid, F(N.avgmax), 2 * BC, grd(N.s_ca1), gs(N.s_ca1), nullptr, 0, N.hid, C,
+                     2 * B, 1, N.hid, 1, C, C, 0, 0));
+      IEEE_TRY(gemm3(F(N.dH), 2 * (int64_t)B * N.hid, par(N.s_ca1), gs(N.s_ca1), F(N.davgmax), 2 * BC, nullptr, 0, 2 * B, C,
+                     N.hid, N.hid, 1, 1, C, C, 0, 0));
+    }
+    void *g1 = P(N.gbuf[1]), *g2 = P(N.gbuf[2]);
+    IEEE_TRY(ieee_cim_tail_bwd_g(F(N.dPp), P(uo.y), P(ur.y), F(uo.stats), F(ur.stats), F(N.att), F(N.davgmax),
+                                 F(N.davgmax) + BC, 2 * BC, (const int32_t*)P(N.amax), g1, g2, dt, B, Hh_, Ww, C, N.parts,
+                                 mode, st));
+    IEEE_TRY(bn_bwd(uo, g1, nullptr, g1, nullptr));
+    IEEE_TRY(bn_bwd(ur, g2, nullptr, g2, nullptr));
+    IEEE_TRY(wgrad(uo, g1, Fm));
+    IEEE_TRY(wgrad(ur, g2, P(N.S)));
+    IEEE_TRY(dgrad(uo, g1, P(N.gbuf[3]), nullptr));
+    IEEE_TRY(dgrad(ur, g2, P(N.gbuf[4]), nullptr));
+    IEEE_TRY(ieee_cim_bwd_combine(P(N.gbuf[3]), P(N.gbuf[4]), F(N.dGp), dF, dt, B, Hh_, Ww, C, mode, st));
+  } else {
+    IEEE_TRY(ieee_cim_tail_bwd_g(F(N.dPp), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                                 P(N.gbuf[1]), nullptr, dt, B, Hh_, Ww, C, N.parts, 2, st));
+    IEEE_TRY(ieee_cim_bwd_combine(P(N.gbuf[1]), nullptr, F(N.dGp), dF, dt, B, Hh_, Ww, C, 2, st));
+  }
+  // trunk backward (Bottleneck blocks in reverse); X holds d(out) of the current block
+  void* X = P(N.gbuf[0]);
+  void *Q = P(N.gbuf[1]), *Rb = P(N.gbuf[2]), *U = P(N.gbuf[3]), *V = P(N.gbuf[4]);
+  for (int bi = (int)N.blocks.size() - 1; bi >= 0; --bi) {
+    const Block& b = N.blocks[bi];
+    const ConvUnit &c1 = N.units[b.c1], &c2 = N.units[b.c2], &c3 = N.units[b.c3];
+    const void* xin = bi == 0 ? P(N.pool) : P(N.units[N.blocks[bi - 1].c3].a);
+    // out = relu(bn3(y3) + identity): g = dout*[out>0] -> Q ; dy3 -> X (in place)
+    IEEE_TRY(bn_bwd(c3, X, P(c3.a), X, Q));
+    IEEE_TRY(wgrad(c3, X, P(c2.a)));
+    IEEE_TRY(dgrad(c3, X, Rb, nullptr));
+    IEEE_TRY(bn_bwd(c2, Rb, P(c2.a), Rb, nullptr));
+    IEEE_TRY(wgrad(c2, Rb, P(c1.a)));
+    IEEE_TRY(dgrad(c2, Rb, U, nullptr));
+    IEEE_TRY(bn_bwd(c1, U, P(c1.a), U, nullptr));
+    IEEE_TRY(wgrad(c1, U, xin));
+    const void* addend = Q;
+    if (b.ds >= 0) {
+      const ConvUnit& d = N.units[b.ds];
+      IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
+      IEEE_TRY(wgrad(d, Q, xin));
+      IEEE_TRY(dgrad(d, Q, V, nullptr));
+      addend = V;
+    }
+    IEEE_TRY(dgrad(c1, U, X, addend));   // d(block input) = dgrad(conv1) + identity-branch gradient
+  }
+  // stem: maxpool -> ReLU/BN -> conv wgrad (no dgrad: the input is the image)
+  const ConvUnit& s = N.units[N.u_stem];
+  IEEE_TRY(ieee_maxpool3x3s2_bwd(X, (const uint8_t*)P(N.pool_arg), Q, dt, 3, B, s.Ho, s.Wo, s.Co, st));
+  IEEE_TRY(bn_bwd(s, Q, P(s.a), Q, nullptr));
+  IEEE_TRY(wgrad(s, Q, P(N.x0)));
+  return IEEE_OK;
+}
+
+Net* as_net(void* h) { return (Net*)h; }
+
+}  // namespace
+
+extern "C" int ieee_net_create(int64_t batch, int64_t height, int64_t width, int64_t num_classes, int dtype,
+                               int interaction, int attention, int using_rem, void** handle) {
+  IEEE_REQUIRE(handle, "net_create: null handle");
+  IEEE_REQUIRE(batch >= 1 && batch <= 4096, "net_create: batch %ld out of range", (long)batch);
+  IEEE_REQUIRE(height >= 32 && width >= 32 && height % 16 == 0 && width % 16 == 0,
+               "net_create: image size %ldx%ld must be a multiple of 16", (long)height, (long)width);
+  IEEE_REQUIRE(num_classes >= 1, "net_create: num_classes");
+  IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "net_create: dtype");
+  Net* n = new Net();
+  n->B = (int)batch; n->H = (int)height; n->W = (int)width; n->num_classes = (int)num_classes; n->dtype = dtype;
+  n->interaction = interaction; n->attention = attention; n->using_rem = using_rem;
+  n->build();
+  n->plan();
+  *handle = n;
+  return IEEE_OK;
+}
+
+extern "C" int ieee_net_destroy(void* handle) {
+  delete as_net(handle);
+  return IEEE_OK;
+}
+
+extern "C" int64_t ieee_net_num_slots(void* handle) { return handle ? (int64_t)as_net(handle)->slot_names.size() : -1; }
+
+extern "C" const char* ieee_net_slot_name(void* handle, int64_t i) {
+  Net* n = as_net(handle);
+  if (!n || i < 0 || i >= (int64_t)n->slot_names.size()) return nullptr;
+  return n->slot_names[i].c_str();
+}
+
+extern "C" int64_t ieee_net_workspace_bytes(void* handle) { return handle ? (int64_t)as_net(handle)->ws_bytes : -1; }
+
+extern "C" int ieee_net_bind(void* handle, float* params, float* grads, float* buffers, const int64_t* offsets,
+                             int64_t num_offsets) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && params && buffers && offsets, "net_bind: null pointer");
+  IEEE_REQUIRE(num_offsets == (int64_t)n->slot_names.size(), "net_bind: expected %zu offsets, got %ld",
+               n->slot_names.size(), (long)num_offsets);
+  for (int64_t i = 0; i < num_offsets; ++i) {
+    IEEE_REQUIRE(offsets[i] >= 0, "net_bind: slot %s is unbound", n->slot_names[i].c_str());
+    n->slot_off[i] = offsets[i];
+  }
+  for (int t : n->triples)
+    IEEE_REQUIRE(offsets[t + 2] - offsets[t + 1] == offsets[t + 1] - offsets[t],
+                 "net_bind: modality stride of %s is not uniform", n->slot_names[t].c_str());
+  n->params = params;
+  n->grads = grads;
+  n->buffers = buffers;
+  n->bound = true;
+  return IEEE_OK;
+}
+
+extern "C" int ieee_net_forward(void* handle, void* workspace, const float* x_rgb, const float* x_ni, const float* x_ti,
+                                int training, float* logits, float* feats, void* stream) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && n->bound, "net_forward: network not bound to parameters");
+  IEEE_REQUIRE(workspace && x_rgb && x_ni && x_ti && feats, "net_forward: null pointer");
+  IEEE_REQUIRE(!training || logits, "net_forward: training needs the logits output");
+  Run r(*n, workspace, stream);
+  return r.forward(x_rgb, x_ni, x_ti, training, logits, feats);
+}
+
+extern "C" int ieee_net_backward(void* handle, void* workspace, const float* dlogits, const float* dfeats, void* stream) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && n->bound && n->grads, "net_backward: network not bound (or no gradient buffer)");
+  IEEE_REQUIRE(workspace && dlogits && dfeats, "net_backward: null pointer");
+  Run r(*n, workspace, stream);
+  return r.backward(dlogits, dfeats);
+}
+
+extern "C" int ieee_net_tensor(void* handle, const char* name, int64_t* byte_offset, int64_t* numel, int* dtype) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && name && byte_offset && numel && dtype, "net_tensor: null pointer");
+  auto it = n->tensors.find(name);
+  IEEE_REQUIRE(it != n->tensors.end(), "net_tensor: unknown tensor '%s'", name);
+  *byte_offset = (int64_t)it->second.off;
+  *numel = it->second.numel;
+  *dtype = it->second.dtype;
+  return IEEE_OK;
+}

@@ -36,6 +36,8 @@ extern "C" {
 #define IEEE_F32 0
 #define IEEE_BF16 1
 
+#define IEEE_MAX_GROUPS 18 /* pointer-table capacity of the grouped head kernels (3 modalities x 6 parts) */
+
 /* ---- library ---------------------------------------------------------- */
 const char* ieee_last_error(void); /* thread-local text of the last failure */
 int ieee_version(void);            /* ABI version, currently 1 */
@@ -106,6 +108,140 @@ int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work,
                       int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
                       int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs, int accumulate,
                       void* stream);
+
+/* ---- BatchNorm2d (+ residual, + ReLU) over NHWC maps [M][C] ------------------ */
+/* torch.nn.BatchNorm2d as the reference instantiates it (resnet.py:151,164-184;
+ * ieee3modalPart.py:38): eps/momentum passed in, biased variance to normalise,
+ * unbiased for running_var.  groups x [M][C] activations, stride act_gs;
+ * gamma/beta at param_gs, running stats at buf_gs.
+ * stats  : out, groups x [4][C] = mean, invstd, scale, shift (kept for backward)
+ * partial: scratch of groups * ieee_bn_partial_floats() floats
+ * out = [relu]( y*scale + shift [+ residual] ); out NULL = statistics only.  training=0 uses running stats. */
+int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C);
+int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
+                  int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
+                  float* running_mean, float* running_var, int64_t buf_gs, float* stats, float* partial,
+                  float momentum, float eps, int training, int relu, void* stream);
+/* backward of out = [relu](bn(y) [+ residual]): g = dout * [out_mask > 0] (out_mask NULL = no ReLU);
+ * dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); g_out (optional) receives g, which is also
+ * the gradient of the residual branch.  dgamma/dbeta fp32 at grad_gs (NULL to skip).
+ * coef: scratch groups x [3][C]. */
+int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                  int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
+                  const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, float* partial,
+                  float* coef, int accumulate, void* stream);
+
+/* ---- stem plumbing ----------------------------------------------------------- */
+/* three fp32 NCHW image tensors (batch dict 'img' = [RGB, NI, TI], dataset.py:338-351) -> [3][B][H][W][C] */
+int ieee_nchw_to_nhwc3(const float* x_rgb, const float* x_ni, const float* x_ti, void* out, int dtype,
+                       int64_t B, int64_t C, int64_t H, int64_t W, void* stream);
+/* nn.MaxPool2d(3, 2, 1) (resnet.py:501); argmax holds the window-local index of the first maximum */
+int ieee_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int dtype, int64_t groups, int64_t B,
+                          int64_t Hi, int64_t Wi, int64_t C, void* stream);
+int ieee_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int dtype, int64_t groups,
+                          int64_t B, int64_t Hi, int64_t Wi, int64_t C, void* stream);
+
+/* ---- Cross-modal Interacting Module tail (ieee3modalPart.py:266-282, 427-455) -- */
+/* F [3][B][H*W][C]: S_m = F_a + F_b (the two other modalities; S may be NULL), Gp_m = mean over positions
+ * (AdaptiveAvgPool2d((1,1)) of the raw trunk map, :449-451) */
+int ieee_gpool_sum_others(const void* F, void* S, float* Gp, int dtype, int64_t B, int64_t H, int64_t W,
+                          int64_t C, void* stream);
+/* ChannelAttention pools of rest = relu(bn(y2)): avg / max over positions at avg|mx + m*pool_gs + b*C + c,
+ * argmax [3][B][C] */
+int ieee_ca_pool(const void* y2, const float* stats2, float* avg, float* mx, int64_t pool_gs, int32_t* argmax,
+                 int dtype, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+/* parts_out[3][B][parts][C] = AdaptiveAvgPool2d((parts,1)) of relu(bn(y1)) + relu(bn(y2))*(1+att);
+ * mode 0 full CIM, 1 attention off, 2 interaction off (pool y1 as is) */
+int ieee_cim_tail_fwd(const void* y1, const void* y2, const float* stats1, const float* stats2,
+                      const float* att, float* parts_out, int dtype, int64_t B, int64_t H, int64_t W,
+                      int64_t C, int64_t parts, int mode, void* stream);
+int ieee_cim_tail_bwd_datt(const float* dparts, const void* y2, const float* stats2, float* datt, int dtype,
+                           int64_t B, int64_t H, int64_t W, int64_t C, int64_t parts, void* stream);
+int ieee_cim_tail_bwd_g(const float* dparts, const void* y1, const void* y2, const float* stats1,
+                        const float* stats2, const float* att, const float* davg, const float* dmax,
+                        int64_t pool_gs, const int32_t* argmax, void* g1, void* g2, int dtype, int64_t B,
+                        int64_t H, int64_t W, int64_t C, int64_t parts, int mode, void* stream);
+/* dF_m = D1_m + DS_a + DS_b + dGp_m / (H*W) */
+int ieee_cim_bwd_combine(const void* D1, const void* DS, const float* dG, void* dF, int dtype, int64_t B,
+                         int64_t H, int64_t W, int64_t C, int mode, void* stream);
+
+/* ---- embedding head, fp32, grouped through host pointer tables (<= IEEE_MAX_GROUPS) ---- */
+/* C[g](m,n) = act(alpha * sum_k A[g](m,k)*B[g](n,k) + bias[g](n)) (+ C[g] when accumulate);
+ * A(m,k) = A + m*sam + k*sak, B(n,k) = B + n*sbn + k*sbk: nn.Linear / 1x1 conv on pooled vectors and
+ * their backward GEMMs (ieee3modalPart.py:54-56, 272-274, 335-340, 396-424, 374-391) */
+int ieee_sgemm_grouped(int64_t groups, const void* const* A, const void* const* B, void* const* C,
+                       const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak,
+                       int64_t sbn, int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate,
+                       void* stream);
+int ieee_colsum_grouped(int64_t groups, const void* const* X, void* const* out, int64_t M, int64_t N,
+                        int64_t ldx, int accumulate, void* stream);
+/* BatchNorm over the rows of [R][C] (+ReLU): BatchNorm2d on [B,C,1,1] / [B,C,6,1] (reduce_layer, applied
+ * twice per step :449-455) and BatchNorm1d of the 18 fc heads (:417).  save[g] = [2][C] mean, invstd */
+int ieee_rowbn_fwd(int64_t groups, const void* const* x, void* const* out, const void* const* gamma,
+                   const void* const* beta, void* const* running_mean, void* const* running_var,
+                   void* const* save, int64_t R, int64_t C, int64_t ldx, int64_t ldo, float momentum,
+                   float eps, int training, int relu, void* stream);
+int ieee_rowbn_bwd(int64_t groups, const void* const* dout, const void* const* out, const void* const* x,
+                   const void* const* gamma, const void* const* save, void* const* dx, void* const* dgamma,
+                   void* const* dbeta, int64_t R, int64_t C, int64_t lddo, int64_t ldo, int64_t ldx,
+                   int64_t lddx, int relu, int accumulate, void* stream);
+/* ChannelAttention glue: h [3][2B][hidden] (avg rows then max rows, ReLU applied) -> hs = h_avg + h_max */
+int ieee_ca_mix_fwd(const float* h, float* hs, int64_t B, int64_t hidden, void* stream);
+int ieee_ca_mix_bwd(const float* dhs, const float* h, float* dh, int64_t B, int64_t hidden, void* stream);
+int ieee_sigmoid_fwd(float* x, int64_t n, void* stream);
+int ieee_sigmoid_bwd(const float* datt, const float* att, float* dz, int64_t n, void* stream);
+/* REM closed form (nonLocal.forward, ieee3modalPart.py:60-80): out = part + 2*param*r, r = W_p g + b_p */
+int ieee_rem_fwd(const float* part, const float* r, const float* param, int64_t param_gs, float* out,
+                 int64_t B, int64_t parts, int64_t D, void* stream);
+int ieee_rem_bwd(const float* dout, const float* r, const float* param, int64_t param_gs, float* dr,
+                 float* dparam, int64_t grad_gs, float* work, int64_t B, int64_t parts, int64_t D,
+                 int accumulate, void* stream);
+/* F.normalize(p=2, dim=1, eps=1e-12) (:519) */
+int ieee_l2norm_fwd(const float* x, float* y, float* norms, int64_t rows, int64_t D, void* stream);
+int ieee_l2norm_bwd(const float* dy, const float* y, const float* norms, float* dx, int64_t rows, int64_t D,
+                    int accumulate, void* stream);
+
+/* ---- losses and optimizer ------------------------------------------------------- */
+/* label-smoothed CE (torchreid/losses/cross_entropy_loss.py:36-50) over `heads` logits tensors [B][C];
+ * head_loss[h] = (-t*logp).mean(0).sum(), head_acc[h] = top-1 % (metrics/accuracy.py);
+ * dlogits (optional) = d(sum_h head_loss)/dlogits * grad_scale.  work: heads*B*2 floats. */
+int ieee_ce_ls_fwd_bwd(const float* logits, const int64_t* targets, float* dlogits, float* head_loss,
+                       float* head_acc, float* work, int64_t heads, int64_t B, int64_t C, float eps,
+                       float grad_scale, void* stream);
+/* 3M loss (torchreid/losses/multi_modal_margin_loss_new.py:19-40); feats [3][B][D] = R,N,T;
+ * out3 = {loss, label_num, chunks torch.chunk would yield}; dfeats optional */
+int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, float* dfeats, float* out3, int64_t B,
+                          int64_t D, float margin, float grad_scale, void* stream);
+/* torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov) as configured by the reference
+ * (torchreid/optim/optimizer.py:130-138) over a flat fp32 range */
+int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
+                           float momentum, float weight_decay, int nesterov, void* stream);
+
+/* ---- whole-network executor --------------------------------------------------- */
+/* One handle = IEEE3modalPart (ieee3modalPart.py:286-523) for a fixed batch / image size / dtype.
+ * The caller owns three flat fp32 buffers laid out like the reference's state_dict: parameters,
+ * their gradients, and BN running statistics.  ieee_net_slot_name() enumerates the tensor names the
+ * executor needs (e.g. "backbone.0.layer1.0.conv1.weight"); ieee_net_bind() receives, in that order,
+ * each tensor's element offset inside `params` (running_mean/var: inside `buffers`).
+ * forward : x_* fp32 NCHW [B,3,H,W].  training: logits [18][B][C] (R0..5,N0..5,T0..5) and
+ *           feats [3][B][768] = F.normalize(fc_{R,N,T}_all); eval: feats = fc_all [B][2304] (T,R,N).
+ * backward: dlogits / dfeats in the same layouts; every parameter gradient is OVERWRITTEN in `grads`
+ *           (REM.conv_query gets exact zeros, REM.conv_value and unused branches are not touched).
+ * All work is enqueued on `stream`; the workspace (ieee_net_workspace_bytes) keeps the activations
+ * between forward and backward. */
+int ieee_net_create(int64_t batch, int64_t height, int64_t width, int64_t num_classes, int dtype,
+                    int interaction, int attention, int using_rem, void** handle);
+int ieee_net_destroy(void* handle);
+int64_t ieee_net_num_slots(void* handle);
+const char* ieee_net_slot_name(void* handle, int64_t i);
+int64_t ieee_net_workspace_bytes(void* handle);
+int ieee_net_bind(void* handle, float* params, float* grads, float* buffers, const int64_t* offsets,
+                  int64_t num_offsets);
+int ieee_net_forward(void* handle, void* workspace, const float* x_rgb, const float* x_ni, const float* x_ti,
+                     int training, float* logits, float* feats, void* stream);
+int ieee_net_backward(void* handle, void* workspace, const float* dlogits, const float* dfeats, void* stream);
+/* debugging / parity tests: location of a named intermediate inside the workspace */
+int ieee_net_tensor(void* handle, const char* name, int64_t* byte_offset, int64_t* numel, int* dtype);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,172 @@
+"""ORACLE (test infrastructure, never imported by the product): CPU restatement of the
+IEEE3modalPart train / eval step in stock torch fp32 ops, arranged as the reference arranges them.
+
+  bottleneck / resnet50_trunk   <- torchreid/models/resnet.py:164-184, 496-523, 622-635
+  cim / channel_attention       <- torchreid/models/ieee3modalPart.py:266-282, 427-435
+  forward                       <- torchreid/models/ieee3modalPart.py:439-523
+  rem (closed form)             <- torchreid/models/ieee3modalPart.py:60-80
+  cross_entropy_ls              <- torchreid/losses/cross_entropy_loss.py:36-50
+  margin3m                      <- torchreid/losses/multi_modal_margin_loss_new.py:19-40
+  train_step                    <- torchreid/engine/image/margin.py:94-154 + optim/optimizer.py:130-138
+
+Works on a plain dict name -> tensor with the reference's state_dict keys.  Pinned against the imported
+reference by tests/test_model_oracle.py (here) and tests/golden/model_golden.npz (everywhere).
+"""
+import torch
+import torch.nn.functional as F
+
+EPS, MOM = 1e-5, 0.1
+
+
+def _bn(x, sd, p, training):
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        training, MOM, EPS)
+
+
+def bottleneck(x, sd, p, stride, has_ds, training):
+    out = F.relu(_bn(F.conv2d(x, sd[p + "conv1.weight"]), sd, p + "bn1", training))
+    out = F.relu(_bn(F.conv2d(out, sd[p + "conv2.weight"], None, stride, 1), sd, p + "bn2", training))
+    out = _bn(F.conv2d(out, sd[p + "conv3.weight"]), sd, p + "bn3", training)
+    identity = x
+    if has_ds:
+        identity = _bn(F.conv2d(x, sd[p + "downsample.0.weight"], None, stride), sd, p + "downsample.1", training)
+    return F.relu(out + identity)
+
+
+def resnet50_trunk(x, sd, p, training, taps=None):
+    x = F.relu(_bn(F.conv2d(x, sd[p + "conv1.weight"], None, 2, 3), sd, p + "bn1", training))
+    if taps is not None:
+        taps[p + "stem"] = x
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, (blocks, stride) in enumerate(zip((3, 4, 6, 3), (1, 2, 2, 1))):     # last_stride = 1
+        for b in range(blocks):
+            x = bottleneck(x, sd, "%slayer%d.%d." % (p, li + 1, b), stride if b == 0 else 1, b == 0, training)
+        if taps is not None:
+            taps["%slayer%d" % (p, li + 1)] = x
+    return x
+
+
+def channel_attention(x, sd, p):
+    def mlp(v):
+        return F.conv2d(F.relu(F.conv2d(v, sd[p + "fc.0.weight"])), sd[p + "fc.2.weight"])
+    return torch.sigmoid(mlp(F.adaptive_avg_pool2d(x, 1)) + mlp(F.adaptive_max_pool2d(x, 1)))
+
+
+def dim_reduce(x, sd, p, training):
+    return F.relu(_bn(F.conv2d(x, sd[p + "layers.0.weight"]), sd, p + "layers.1", training))
+
+
+def forward(sd, xs, training, loss="margin", interaction=True, attention=True, using_rem=True, taps=None):
+    """xs = [RGB, NI, TI]; sd's running stats are updated in place when training (pass clones)."""
+    f = [resnet50_trunk(xs[m], sd, "backbone.%d." % m, training, taps) for m in range(3)]
+    pooled, glob = [], []
+    if interaction:
+        for m in range(3):
+            a, b = [k for k in range(3) if k != m]
+            one = dim_reduce(f[m], sd, "convOne.%d." % m, training)
+            rest = dim_reduce(f[a] + f[b], sd, "convAvgRest.%d." % m, training)
+            if attention:
+                rest = channel_attention(rest, sd, "CA.%d." % m) * rest + rest
+            pooled.append(one + rest)
+    else:
+        pooled = list(f)
+    for m in range(3):      # reduce_layer: global vector first, then the 6 parts (two BN calls, :449-455)
+        glob.append(dim_reduce(F.adaptive_avg_pool2d(f[m], (1, 1)), sd, "reduce_layer.%d." % m, training))
+    for m in range(3):
+        pooled[m] = dim_reduce(F.adaptive_avg_pool2d(pooled[m], (6, 1)), sd, "reduce_layer.%d." % m, training)
+    glob = [g.flatten(1) for g in glob]
+    parts = [[pooled[m][:, :, i, 0] for i in range(6)] for m in range(3)]
+    if taps is not None:
+        taps["glob"] = torch.stack(glob)
+        taps["parts_pre_rem"] = torch.stack([torch.stack(p, 1) for p in parts])
+    if using_rem:
+        for m in range(3):
+            r = F.linear(glob[m], sd["REM.%d.conv_part.weight" % m], sd["REM.%d.conv_part.bias" % m])
+            parts[m] = [q + 2.0 * sd["REM.%d.param" % m] * r for q in parts[m]]
+    letters = "RNT"
+    fc = [[F.relu(F.batch_norm(F.linear(parts[m][i], sd["fc_%s.%d.0.weight" % (letters[m], i)],
+                                        sd["fc_%s.%d.0.bias" % (letters[m], i)]),
+                               sd["fc_%s.%d.1.running_mean" % (letters[m], i)],
+                               sd["fc_%s.%d.1.running_var" % (letters[m], i)],
+                               sd["fc_%s.%d.1.weight" % (letters[m], i)], sd["fc_%s.%d.1.bias" % (letters[m], i)],
+                               training, MOM, EPS)) for i in range(6)] for m in range(3)]
+    cat = [torch.cat(fc[m], 1) for m in range(3)]
+    if not training:
+        return torch.cat([cat[2], cat[0], cat[1]], 1)          # T, R, N   (:502)
+    logits = [[F.linear(fc[m][i], sd["classifier_%s.%d.weight" % (letters[m], i)],
+                        sd["classifier_%s.%d.bias" % (letters[m], i)]) for i in range(6)] for m in range(3)]
+    if loss == "softmax":
+        return logits[0], logits[1], logits[2]
+    return logits[0], logits[1], logits[2], F.normalize(cat[0]), F.normalize(cat[1]), F.normalize(cat[2])
+
+
+def cross_entropy_ls(logits, target, num_classes, eps=0.1):
+    logp = F.log_softmax(logits, 1)
+    t = torch.zeros_like(logp).scatter_(1, target.unsqueeze(1), 1)
+    t = (1 - eps) * t + eps / num_classes
+    return (-t * logp).mean(0).sum()
+
+
+def margin3m(f1, f2, f3, pids, margin):
+    n = len(pids.unique())
+    c1, c2, c3 = f1.chunk(n, 0), f2.chunk(n, 0), f3.chunk(n, 0)
+    total = 0
+    for i in range(n):
+        a, b, c = c1[i].mean(0), c2[i].mean(0), c3[i].mean(0)
+        d = lambda u, v: ((u - v) ** 2).sum()
+        total = total + max(abs(margin - d(a, b)), abs(margin - d(b, c)), abs(margin - d(a, c)))
+    return total
+
+
+def losses(outputs, pids, num_classes, margin=1.0, weight_m=1.0, weight_x=1.0):
+    oR, oN, oT, fR, fN, fT = outputs
+    loss_m = margin3m(fR, fN, fT, pids, margin)
+    lR = sum(cross_entropy_ls(o, pids, num_classes) for o in oR)
+    lN = sum(cross_entropy_ls(o, pids, num_classes) for o in oN)
+    lT = sum(cross_entropy_ls(o, pids, num_classes) for o in oT)
+    loss = weight_m * loss_m + weight_x * (lR + lN + lT)
+    acc = [sum(100.0 * (o.argmax(1) == pids).float().mean() for o in oo) / 6 for oo in (oR, oN, oT)]
+    return loss, dict(loss=loss, LossX=lR + lN + lT, LossM=loss_m, lossR=lR, lossN=lN, lossT=lT,
+                      accR=acc[0], accN=acc[1], accT=acc[2])
+
+
+PARAM_LEAVES = ("weight", "bias", "param")
+
+
+def split_state(sd):
+    """(params requiring grad, buffers) from a flat state dict"""
+    params = {k: v for k, v in sd.items() if k.rsplit(".", 1)[-1] in PARAM_LEAVES}
+    bufs = {k: v for k, v in sd.items() if k not in params}
+    return params, bufs
+
+
+def train_step(sd, xs, pids, num_classes, lr=1e-3, momentum=0.9, wd=5e-4, mom_state=None, margin=1.0, **flags):
+    """one engine step on CPU: returns (summary, grads, new_state, new_momentum).  SGD with nesterov
+    (hard-coded in the reference, optim/optimizer.py:137), dampening 0."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    params, _ = split_state(sd)
+    for p in params.values():
+        p.requires_grad_(True)
+    out = forward(sd, xs, True, "margin", **flags)
+    loss, summary = losses(out, pids, num_classes, margin)
+    names = list(params)
+    g = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
+    grads = dict(zip(names, g))
+    if flags.get("using_rem", True):
+        # the literal nonLocal.forward routes conv_query through softmax over ONE element, so autograd
+        # hands it exact zeros (not None) and SGD still decays it; conv_value stays None
+        for k in names:
+            if ".conv_query." in k and grads[k] is None:
+                grads[k] = torch.zeros_like(params[k])
+    mom_state = dict(mom_state or {})
+    with torch.no_grad():
+        for k in names:
+            if grads[k] is None:
+                continue
+            d = grads[k] + wd * params[k]
+            buf = mom_state.get(k)
+            buf = d.clone() if buf is None else momentum * buf + d
+            mom_state[k] = buf
+            params[k].sub_(lr * (d + momentum * buf))
+    new_sd = {k: v.detach() for k, v in sd.items()}
+    return {k: float(v.detach()) for k, v in summary.items()}, grads, new_sd, mom_state
