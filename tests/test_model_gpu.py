@@ -1,0 +1,114 @@
+"""GPU parity of the whole model through the reference-shaped surface (build_model -> forward ->
+autograd backward) in fp32 parity mode, against goldens captured from the imported reference.
+Tolerance: logits / features within 1e-3 absolute (BASELINE.json north_star); the reference's own
+1-vs-8-thread noise on these inputs is < 1e-6 (recorded in the fixture)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from tests.util_model import C, compare_stats, generated_state, images, stats
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "model_golden.npz"))
+
+
+def make_model(seed, dtype=torch.float32, **flags):
+    from ieee_amd.models import build_model
+    m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, use_gpu=True,
+                    compute_dtype=dtype, **flags)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(generated_state(shapes, seed))
+    return m
+
+
+def test_eval_forward_matches_reference(G):
+    m = make_model(1).eval()
+    xs = [x.cuda() for x in images(4, 1)]
+    fc = m(xs, torch.zeros(4))                       # junk 2nd arg like engine.py:366
+    assert fc.shape == (4, 2304) and not fc.requires_grad
+    assert np.abs(fc.cpu().numpy() - G["eval/fc_all"]).max() < 1e-3
+    for flags, tag in ((dict(attention=False), "eval_noatt"), (dict(interaction=False), "eval_nocim"),
+                       (dict(using_REM=False), "eval_norem")):
+        for k, v in flags.items():
+            setattr(m, k, v)
+        assert np.abs(m(xs).cpu().numpy() - G[tag + "/fc_all"]).max() < 1e-3, tag
+        for k in flags:
+            setattr(m, k, True)
+
+
+@pytest.mark.parametrize("tag,B,seed", [("train16", 16, 2), ("train8", 8, 3)])
+def test_train_forward_backward_matches_reference(G, tag, B, seed):
+    m = make_model(seed).train()
+    xs = [x.cuda() for x in images(B, seed)]
+    pids = (torch.arange(B) // 4).cuda()
+    out = m(xs)
+    oR, oN, oT, fR, fN, fT = out
+    logits = torch.stack([torch.stack(list(o)) for o in (oR, oN, oT)]).reshape(18, B, C)
+    feats = torch.stack([fR, fN, fT])
+    assert np.abs(logits.detach().cpu().numpy() - G[tag + "/logits"]).max() < 1e-3
+    assert np.abs(feats.detach().cpu().numpy() - G[tag + "/feats"]).max() < 1e-3
+    loss, summary = om.losses(out, pids, C)          # oracle as the checker of the loss values
+    keys = ("loss", "LossX", "LossM", "lossR", "lossN", "lossT", "accR", "accN", "accT")
+    np.testing.assert_allclose([float(summary[k]) for k in keys], G[tag + "/summary"], rtol=1e-4, atol=1e-3)
+    loss.backward()
+    names = [str(n) for n in G[tag + "/param_names"]]
+    params = dict(m.named_parameters())
+    assert [n for n, _ in m.named_parameters()] == names
+    assert [params[n].grad is None for n in names] == list(G[tag + "/grad_none"])
+    for k in ("classifier_R.0.weight", "REM.0.param", "backbone.0.bn1.weight", "reduce_layer.2.layers.1.weight",
+              "fc_T.3.1.bias", "backbone.1.conv1.weight"):
+        ref = G[tag + "/grad:" + k]
+        got = params[k].grad.cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-6) + 1e-7, k
+    mine = [stats(params[n].grad) if params[n].grad is not None else np.zeros(35) for n in names]
+    compare_stats(mine, G[tag + "/grad_stats"], names, 5e-3, "gradients")
+    # BN running statistics after the step (incl. the doubly-updated reduce_layer ones) and counters
+    sd = m.state_dict()
+    bnames = [str(n) for n in G[tag + "/buffer_names"]]
+    compare_stats([stats(sd[n]) for n in bnames], G[tag + "/post_buffer_stats"], bnames, 1e-3, "running stats")
+    assert np.array_equal(np.array([int(sd[k]) for k in sd if k.endswith("num_batches_tracked")]), G[tag + "/nbt"])
+
+
+@pytest.mark.parametrize("tag,flags", [("train8_noatt", dict(attention=False)), ("train8_nocim", dict(interaction=False)),
+                                       ("train8_norem", dict(using_REM=False)), ("train4", {})])
+def test_train_ablations_and_c1_shape(G, tag, flags):
+    B, seed = (4, 4) if tag == "train4" else (8, 5)
+    m = make_model(seed, **flags).train()
+    xs = [x.cuda() for x in images(B, seed)]
+    pids = (torch.arange(B) // 4).cuda()
+    out = m(xs)
+    logits = torch.stack([torch.stack(list(o)) for o in out[:3]]).reshape(18, B, C)
+    feats = torch.stack(list(out[3:]))
+    assert np.abs(logits.detach().cpu().numpy() - G[tag + "/logits"]).max() < 1e-3
+    assert np.abs(feats.detach().cpu().numpy() - G[tag + "/feats"]).max() < 1e-3
+    loss, summary = om.losses(out, pids, C)
+    np.testing.assert_allclose(float(summary["loss"]), G[tag + "/summary"][0], rtol=1e-4)
+    loss.backward()       # exercises the ablated backward paths
+    none = [n for n, p in m.named_parameters() if p.grad is None]
+    if flags.get("interaction", True) is False:
+        assert any(n.startswith("convOne.") for n in none) and any(n.startswith("CA.") for n in none)
+    if flags.get("using_REM", True) is False:
+        assert any(n.startswith("REM.") and "conv_part" in n for n in none)
+
+
+def test_bf16_mode_close_to_fp32_goldens(G):
+    """bf16 speed mode is judged by a loose tolerance (never by 1e-3 on logits)"""
+    m = make_model(2, dtype=torch.bfloat16).train()
+    xs = [x.cuda() for x in images(16, 2)]
+    out = m(xs)
+    feats = torch.stack(list(out[3:])).detach().cpu().numpy()
+    logits = torch.stack([torch.stack(list(o)) for o in out[:3]]).reshape(18, 16, C).detach().cpu().numpy()
+    assert np.abs(feats - G["train16/feats"]).max() < 0.05
+    assert np.abs(logits - G["train16/logits"]).max() < 0.5
+    pids = (torch.arange(16) // 4).cuda()
+    loss, _ = om.losses(out, pids, C)
+    assert abs(float(loss) - G["train16/summary"][0]) / G["train16/summary"][0] < 0.02
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
