@@ -68,9 +68,9 @@ __device__ __forceinline__ void reduce_channels(const RedGeom& g, float* partial
 #pragma unroll
     for (int e = 0; e < VEC; ++e) red[(ty * g.tx + tx) * VEC + e] = acc[q][e];
     __syncthreads();
-    // threads 0 .. tx*VEC-1 each own one channel of this column block
-    if (t < g.tx * VEC) {
-      const int ltx = t / VEC, e = t % VEC;
+    // one channel of this column block per thread (tx*VEC can exceed the block size: bf16, tx = 64)
+    for (int idx = t; idx < g.tx * VEC; idx += 256) {
+      const int ltx = idx / VEC, e = idx % VEC;
       float s = 0.f;
       for (int y = 0; y < g.ty; ++y) s += red[(y * g.tx + ltx) * VEC + e];
       const int c = (cb * g.tx + ltx) * VEC + e;

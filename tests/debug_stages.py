@@ -12,8 +12,9 @@ from tests.util_model import C, generated_state, images  # noqa: E402
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     training = (sys.argv[2] if len(sys.argv) > 2 else "eval") == "train"
+    cdt = torch.bfloat16 if (len(sys.argv) > 3 and sys.argv[3] == "bf16") else torch.float32
     from ieee_amd.models import build_model
-    m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, compute_dtype=torch.float32)
+    m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, compute_dtype=cdt)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = generated_state(shapes, 1)
     m.load_state_dict(sd)
@@ -29,7 +30,8 @@ def main():
         return net.tensor(name).float().view(shape).cpu()
 
     def show(name, a, b):
-        print("%-28s max|diff| %.3e   max|ref| %.3e" % (name, (a - b).abs().max().item(), b.abs().max().item()))
+        print("%-28s max|diff| %.3e   max|ref| %.3e   rel-L2 %.3e" % (name, (a - b).abs().max().item(), b.abs().max().item(),
+                                                                  ((a - b).norm() / b.norm()).item()))
     stem = torch.stack([taps["backbone.%d.stem" % i] for i in range(3)]).permute(0, 1, 3, 4, 2)
     show("stem", nhwc("backbone.{m}.conv1.a", stem.shape), stem)
     for li, last in ((1, 2), (2, 3), (3, 5), (4, 2)):
