@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): 3-modal images/s of the IEEE3modalPart TRAIN STEP
+(forward + CE x18 + 3M + backward + [RCCL grad all-reduce] + SGD-nesterov) on synthetic RGBNT201-shaped
+batches, config "Single-GPU MI355X: RGBNT201 256x128 batch=64, full CIM+REM+3M, bf16" per GPU
+(weak scaling: 64 triples per rank), plus the evaluator's query x gallery distmat GFLOP/s.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+
+One "step" = one Image3MEngine.forward_backward over one resident batch (inputs already in HBM).
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (conv_gather_kernel: implicit
+GEMM forward+dgrad): algorithmic FLOPs of its launches / their summed durations, measured with HIP
+events on the launch stream in a second pass over the same K steps (the event pairs would perturb the
+timed region).  `cpu_baseline` is the oracle's CPU restatement of the same step on the host cores."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+TRAIN_GFLOP_PER_TRIPLE = 92.24
+
+
+class _FakeDM(object):
+    def __init__(self, num_classes):
+        self.num_train_pids = num_classes
+        self.train_loader = []
+        self.test_loader = {}
+        self.sources = ["synthetic"]
+
+
+def make_batch(B, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    imgs = [torch.randn(B, 3, 256, 128, generator=g).to(device) for _ in range(3)]
+    pids = (torch.arange(B) // 4).to(device)
+    return {"img": imgs, "pid": pids, "camid": torch.zeros(B, dtype=torch.long), "impath": "",
+            "timeid": torch.zeros(B, dtype=torch.long)}
+
+
+def cpu_baseline_train(seconds_budget=25.0):
+    """oracle (stock torch CPU ops arranged like the reference) on a bounded sample: B=8 steps"""
+    from ieee_amd import detgen
+    from ieee_amd._spec import state_spec
+    from oracle import model as om
+    C = 171
+    shapes = {k: s for k, s, _ in state_spec(C)}
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in detgen.generate_state(shapes, 0, rem_param=0.0).items()}
+    B = 8
+    xs = [torch.from_numpy(x) for x in detgen.generate_images(B, 0)]
+    pids = torch.arange(B) // 4
+    threads = torch.get_num_threads()
+    om.train_step(sd, xs, pids, C)                       # warm-up
+    t0, n = time.time(), 0
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 6):
+        om.train_step(sd, xs, pids, C)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": B / dt, "unit": "3-modal images/s", "cores": threads, "kind": "port",
+            "sample": "%d oracle train steps at batch %d (fp32, torch CPU ops, %d threads), %.2f s/step" % (n, B, threads, dt)}
+
+
+def bench_distmat(device):
+    """config C4: 10k x 100k x 768 squared-Euclidean distmat (fp32, exact) + CMC/mAP on the device"""
+    from ieee_amd.metrics import compute_distance_matrix, evaluate_rank
+    g = torch.Generator(device="cpu").manual_seed(1)
+    Q, G, D = 10000, 100000, 768
+    qf = torch.randn(Q, D, generator=g).abs().to(device)
+    gf = torch.randn(G, D, generator=g).abs().to(device)
+    rs = np.random.RandomState(1)
+    qp, gp = rs.randint(0, 1000, Q), rs.randint(0, 1000, G)
+    qc, gc = rs.randint(0, 4, Q), rs.randint(0, 4, G)
+    out = {}
+    for name, a, b in (("fp32", qf, gf), ("bf16", qf.bfloat16(), gf.bfloat16())):
+        compute_distance_matrix(a, b)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            dm = compute_distance_matrix(a, b)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out[name] = {"ms": ms, "GFLOP/s": 2.0 * Q * G * D / ms / 1e6}
+    dm = compute_distance_matrix(qf, gf)
+    evaluate_rank(dm, qp, gp, qc, gc)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    cmc, m_ap = evaluate_rank(dm, qp, gp, qc, gc)
+    torch.cuda.synchronize()
+    out["rank_ms"] = (time.time() - t0) * 1e3
+    out["workload"] = "10000 x 100000 x 768 (BASELINE config 4)"
+    out["roofline_fp32"] = {"bound": "mfma", "achieved": out["fp32"]["GFLOP/s"] / 1e3, "peak": PEAK_F32_TFLOPS,
+                            "unit": "TFLOP/s", "frac": out["fp32"]["GFLOP/s"] / 1e3 / PEAK_F32_TFLOPS}
+    # CPU baselines on bounded samples: oracle sgemm-form distmat, reference's own Cython evaluator
+    try:
+        from oracle import evaluator as ev
+        q2, g2 = qf[:2000].cpu().numpy(), gf[:20000].cpu().numpy()
+        t0 = time.time()
+        d2 = ev.sqeuclid_np(q2, g2)
+        dt = time.time() - t0
+        out["cpu_distmat"] = {"GFLOP/s": 2.0 * 2000 * 20000 * D / dt / 1e9, "kind": "port", "sample": "2000 x 20000 x 768 numpy"}
+        t0 = time.time()
+        ev.rank_market1501_c(d2[:300, :3000].copy(), qp[:300], gp[:3000], qc[:300], gc[:3000])
+        out["cpu_rank_ms_300x3000"] = (time.time() - t0) * 1e3
+    except Exception as e:      # the baseline is informative only
+        out["cpu_distmat"] = {"error": str(e)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="triples per GPU (BASELINE config 2/3: 64)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-distmat", action="store_true")
+    args = ap.parse_args()
+
+    from ieee_amd import _lib, dist as ddp
+    world, rank, local = ddp.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torchrun for --gpus > 1"
+    _lib.require_gpu()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from ieee_amd.engine import Image3MEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    C = 171
+    torch.manual_seed(0)
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, use_gpu=True,
+                        compute_dtype=cdt, device=device)
+    opt = build_optimizer(model, optim="sgd", lr=1e-3, weight_decay=5e-4, momentum=0.9)
+    engine = Image3MEngine(_FakeDM(C), model, opt, margin=1, weight_m=1, weight_x=1, use_gpu=True, label_smooth=True)
+    model.train()
+    B = args.batch
+    batch = make_batch(B, seed=rank, device=device)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        summary = engine.forward_backward(batch)
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        summary = engine.forward_backward(batch)
+    barrier()
+    dt = time.time() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    value = args.steps * B * world / dt
+
+    # ---- roofline pass: same steps with a HIP event pair around every conv launch (launch stream)
+    import ctypes
+    net = model.native_net(B, 256, 128)
+    lib = _lib.load()
+    _lib.check(lib.ieee_net_profile(net.handle, 1, None))
+    for _ in range(args.steps):
+        engine.forward_backward(batch)
+    out6 = (ctypes.c_double * 6)()
+    _lib.check(lib.ieee_net_profile(net.handle, 0, out6))
+    g_ms, g_fl, g_n, w_ms, w_fl, w_n = list(out6)
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": None, "kernel": "conv_gather_kernel (implicit-GEMM forward + dgrad)",
+                "launches": int(g_n), "avg_launch_us": g_ms * 1e3 / max(g_n, 1),
+                "flops_per_launch": g_fl / max(g_n, 1),
+                "wgrad": {"achieved": (w_fl / (w_ms * 1e-3) / 1e12) if w_ms > 0 else 0.0, "launches": int(w_n),
+                          "avg_launch_us": w_ms * 1e3 / max(w_n, 1)},
+                "conv_ms_per_step": (g_ms + w_ms) / args.steps,
+                "whole_step_frac_of_peak": value / world * TRAIN_GFLOP_PER_TRIPLE * 1e9 / (peak * 1e12)}
+
+    line = {
+        "metric": "3-modal images/s (train fwd+bwd)",
+        "value": value,
+        "unit": "3-modal images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": "IEEE3modalPart train step, RGBNT201-shaped 256x128 triples, batch %d per GPU, "
+                               "171 classes, full CIM+REM+3M, SGD-nesterov" % B,
+                   "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "loss_last_step": float(summary["loss"])},
+        "roofline": roofline,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_train()
+        if world == 1 and not args.no_distmat:
+            del engine, net
+            model._nets.clear()
+            torch.cuda.empty_cache()
+            line["distmat"] = bench_distmat(device)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,14 @@ struct Net {
       logits, featn, norms;
   Tensor dfeatcat, dfcraw, dpart2, dr, dglob, dZp, dZg, dPp, dGp, datt, dHs, dH, davgmax, remwork;
   int esz() const { return dtype == IEEE_BF16 ? 2 : 4; }
+  // optional per-launch timing of the conv kernels (bench.py's roofline leg): category 0 = forward +
+  // dgrad (conv_gather_kernel), 1 = wgrad (conv_wgrad_kernel)
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_cat;
+  size_t ev_used = 0;
+  double prof_flops[2] = {0, 0};
+  int64_t prof_launches[2] = {0, 0};
 
   int slot3(const std::string& pattern) {   // registers the three per-modality names, returns the first id
     const int id = (int)slot_names.size();
@@ -257,8 +265,25 @@ struct Run {
     }
     return IEEE_OK;
   }
+  void prof_begin(int cat, const ConvUnit& u) {
+    if (!n.profiling) return;
+    if (n.ev_used + 2 > n.ev_pool.size()) {
+      for (int i = 0; i < 256; ++i) { hipEvent_t e; hipEventCreate(&e); n.ev_pool.push_back(e); }
+    }
+    hipEventRecord(n.ev_pool[n.ev_used], (hipStream_t)st);
+    n.ev_cat.push_back(cat);
+    n.prof_flops[cat] += 3.0 * 2.0 * (double)u.M(B) * u.Co * u.R * u.R * u.Ci;   // algorithmic, 3 modalities
+    n.prof_launches[cat] += 1;
+  }
+  void prof_end() {
+    if (!n.profiling) return;
+    hipEventRecord(n.ev_pool[n.ev_used + 1], (hipStream_t)st);
+    n.ev_used += 2;
+  }
   int conv(const ConvUnit& u, const void* in) {
     const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.R);
+    prof_begin(0, u);
+    struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_fwd(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.R, u.stride, u.pad,
                            (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, st);
   }
@@ -273,11 +298,15 @@ struct Run {
                          F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), F(n.bnpart), F(n.bncoef), 0, st);
   }
   int wgrad(const ConvUnit& u, const void* dy, const void* x) {
+    prof_begin(1, u);
+    struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_wgrad(dy, x, grd(u.s_w), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.R, u.stride,
                              u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, gs(u.s_w), 0, st);
   }
   int dgrad(const ConvUnit& u, const void* dy, void* dx, const void* addend) {
     const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.R);
+    prof_begin(0, u);
+    struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_dgrad(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.R, u.stride, u.pad,
                              u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, st);
   }
@@ -651,6 +680,30 @@ extern "C" int ieee_net_backward(void* handle, void* workspace, const float* dlo
   IEEE_REQUIRE(workspace && dlogits && dfeats, "net_backward: null pointer");
   Run r(*n, workspace, stream);
   return r.backward(dlogits, dfeats);
+}
+
+extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n, "net_profile: null handle");
+  if (enable) {
+    n->profiling = true;
+    n->ev_used = 0;
+    n->ev_cat.clear();
+    n->prof_flops[0] = n->prof_flops[1] = 0;
+    n->prof_launches[0] = n->prof_launches[1] = 0;
+    return IEEE_OK;
+  }
+  IEEE_REQUIRE(out6, "net_profile: null output");
+  n->profiling = false;
+  IEEE_HIP(hipDeviceSynchronize());   // host-side query, outside any timed region
+  double ms[2] = {0, 0};
+  for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
+    float t = 0.f;
+    IEEE_HIP(hipEventElapsedTime(&t, n->ev_pool[i], n->ev_pool[i + 1]));
+    ms[n->ev_cat[i / 2]] += t;
+  }
+  for (int c = 0; c < 2; ++c) { out6[c * 3 + 0] = ms[c]; out6[c * 3 + 1] = n->prof_flops[c]; out6[c * 3 + 2] = (double)n->prof_launches[c]; }
+  return IEEE_OK;
 }
 
 extern "C" int ieee_net_tensor(void* handle, const char* name, int64_t* byte_offset, int64_t* numel, int* dtype) {

@@ -1,0 +1,88 @@
+"""Data parallelism for the train step: one process per GPU, replicated weights, ONE all-reduce (sum)
+of the flat fp32 gradient buffer per step over RCCL/xGMI (backend "nccl" is RCCL on ROCm), replacing
+the reference's single-process nn.DataParallel (scripts/mainMultiModal.py:219-220: per-step parameter
+broadcast + scatter + gather + reduce-add to GPU0).  Loss scaling: CE is a batch MEAN
+(cross_entropy_loss.py:50) so each rank scales it by 1/world; 3M is a SUM over identities
+(multi_modal_margin_loss_new.py:33-38) so it is not scaled; BatchNorm statistics stay rank-local, which
+is DataParallel's behaviour.  Batches are sharded on identity boundaries (multiples of K instances) so
+every 3M chunk is rank-local."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_from_env(backend=None):
+    """initialise torch.distributed from torchrun's environment; returns (world, rank, local_rank)"""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return world, rank, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_bounds(global_batch, num_instances, world, rank_):
+    """[start, end) of this rank's slice of an identity-contiguous global batch (RandomIdentitySampler
+    emits K=num_instances consecutive samples per identity, reference data/sampler.py:73-79).  Shards
+    are whole identities, as even as possible."""
+    assert global_batch % num_instances == 0, "global batch must hold whole identities"
+    ids = global_batch // num_instances
+    base, extra = divmod(ids, world)
+    start_id = rank_ * base + min(rank_, extra)
+    n_id = base + (1 if rank_ < extra else 0)
+    return start_id * num_instances, (start_id + n_id) * num_instances
+
+
+def shard_batch(data, num_instances, world=None, rank_=None):
+    """slice a reference-style batch dict {'img': [R,N,T], 'pid', 'camid', 'timeid', ...} for this rank"""
+    world = world_size() if world is None else world
+    rank_ = rank() if rank_ is None else rank_
+    if world == 1:
+        return data
+    B = data['pid'].shape[0]
+    a, b = shard_bounds(B, num_instances, world, rank_)
+    out = {}
+    for k, v in data.items():
+        if k == 'img':
+            out[k] = [x[a:b] for x in v]
+        elif torch.is_tensor(v) or isinstance(v, (list, tuple)):
+            out[k] = v[a:b]
+        else:
+            out[k] = v
+    return out
+
+
+def allreduce_sum_(flat):
+    """the step's single collective: in-place sum of the flat gradient buffer across ranks"""
+    if world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def ce_grad_scale():
+    return 1.0 / world_size()
+
+
+def reduce_summary_(vec):
+    """optional: average the 9 logging scalars (loss terms are per-rank means / sums)"""
+    if world_size() > 1:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    return vec

@@ -240,6 +240,11 @@ int ieee_net_bind(void* handle, float* params, float* grads, float* buffers, con
 int ieee_net_forward(void* handle, void* workspace, const float* x_rgb, const float* x_ni, const float* x_ti,
                      int training, float* logits, float* feats, void* stream);
 int ieee_net_backward(void* handle, void* workspace, const float* dlogits, const float* dfeats, void* stream);
+/* measurement: enable=1 starts recording a HIP event pair (on the launch stream) around every conv
+ * launch of subsequent forward/backward calls; enable=0 stops, synchronises the device and returns
+ * out6 = {ms, algorithmic FLOPs, launches} for [0] forward+dgrad (conv_gather_kernel) and
+ * [1] wgrad (conv_wgrad_kernel + its slab reduce) */
+int ieee_net_profile(void* handle, int enable, double* out6);
 /* debugging / parity tests: location of a named intermediate inside the workspace */
 int ieee_net_tensor(void* handle, const char* name, int64_t* byte_offset, int64_t* numel, int* dtype);
 
