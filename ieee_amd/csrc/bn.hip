@@ -93,22 +93,35 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, 
   });
 }
 
+// sum the per-row-block partials of channel c: 32 lanes stride over the row blocks, then a shuffle tree.
+// block = 8 channels x 32 lanes; returns the totals in every lane of the channel's 32-lane group.
+__device__ __forceinline__ void sum_partials(const float* p, int rblocks, int C, int c, int lane32, double& s1,
+                                             double& s2) {
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C)
+    for (int r = lane32; r < rblocks; r += 32) { a1 += p[(int64_t)r * 2 * C + c]; a2 += p[(int64_t)r * 2 * C + C + c]; }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+  s1 = a1; s2 = a2;
+}
+
 // mean / invstd / scale / shift + running-stat update (train) or scale/shift from running stats (eval)
-// stats layout per group: [4][C] = mean, invstd, scale, shift
-__global__ void bn_finalize_kernel(const float* partial, int64_t partial_gs, int rblocks, int M, int C,
-                                   const float* gamma, const float* beta, int64_t param_gs, float* running_mean,
-                                   float* running_var, int64_t buf_gs, float* stats, int64_t stats_gs, float momentum,
-                                   float eps, int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// stats layout per group: [4][C] = mean, invstd, scale, shift.   launch: block 256 = 8 channels x 32 lanes
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int64_t partial_gs, int rblocks, int M,
+                                                          int C, const float* gamma, const float* beta,
+                                                          int64_t param_gs, float* running_mean, float* running_var,
+                                                          int64_t buf_gs, float* stats, int64_t stats_gs,
+                                                          float momentum, float eps, int training) {
+  const int lane32 = threadIdx.x & 31;
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int z = blockIdx.y;
+  double s1 = 0.0, s2 = 0.0;
+  if (training) sum_partials(partial + z * partial_gs, rblocks, C, c, lane32, s1, s2);
+  if (c >= C || lane32 != 0) return;
   const float ga = gamma[z * param_gs + c], be = beta[z * param_gs + c];
   float* st = stats + z * stats_gs;
   float mean, invstd;
   if (training) {
-    const float* p = partial + z * partial_gs;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < rblocks; ++r) { s1 += p[(int64_t)r * 2 * C + c]; s2 += p[(int64_t)r * 2 * C + C + c]; }
     const double mu = s1 / M;
     double var = s2 / M - mu * mu;
     if (var < 0) var = 0;
@@ -185,17 +198,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // dgamma = sum(g*xhat), dbeta = sum(g);  coefficients of dy = k1*g + k2*y + k3
-// coef layout per group: [3][C]
-__global__ void bn_bwd_finalize_kernel(const float* partial, int64_t partial_gs, int rblocks, int M, int C,
-                                       const float* gamma, int64_t param_gs, const float* stats, int64_t stats_gs,
-                                       float* dgamma, float* dbeta, int64_t grad_gs, float* coef, int64_t coef_gs,
-                                       int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// coef layout per group: [3][C].   launch: block 256 = 8 channels x 32 lanes
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int64_t partial_gs, int rblocks,
+                                                              int M, int C, const float* gamma, int64_t param_gs,
+                                                              const float* stats, int64_t stats_gs, float* dgamma,
+                                                              float* dbeta, int64_t grad_gs, float* coef,
+                                                              int64_t coef_gs, int accumulate) {
+  const int lane32 = threadIdx.x & 31;
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int z = blockIdx.y;
-  const float* p = partial + z * partial_gs;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < rblocks; ++r) { s1 += p[(int64_t)r * 2 * C + c]; s2 += p[(int64_t)r * 2 * C + C + c]; }
+  double s1, s2;
+  sum_partials(partial + z * partial_gs, rblocks, C, c, lane32, s1, s2);
+  if (c >= C || lane32 != 0) return;
   const float* st = stats + z * stats_gs;
   const double mean = st[c], invstd = st[C + c];
   const double sgx = invstd * (s2 - mean * s1);   // sum g * xhat
@@ -283,7 +297,7 @@ extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int
     else bn_stats_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y, act_gs, g, partial, partial_gs);
     IEEE_TRY(launch_status("bn_stats_kernel"));
   }
-  bn_finalize_kernel<<<dim3(cdiv(C, 128), (unsigned)groups), 128, 0, st>>>(
+  bn_finalize_kernel<<<dim3(cdiv(C, 8), (unsigned)groups), 256, 0, st>>>(
       partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, beta, param_gs, running_mean, running_var, buf_gs, stats,
       4 * C, momentum, eps, training);
   IEEE_TRY(launch_status("bn_finalize_kernel"));
@@ -317,7 +331,7 @@ extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void*
     bn_bwd_reduce_kernel<bf16><<<rgrid, 256, 0, st>>>((const bf16*)dout, (const bf16*)out_mask, (const bf16*)y, act_gs,
                                                       g, partial, partial_gs);
   IEEE_TRY(launch_status("bn_bwd_reduce_kernel"));
-  bn_bwd_finalize_kernel<<<dim3(cdiv(C, 128), (unsigned)groups), 128, 0, st>>>(
+  bn_bwd_finalize_kernel<<<dim3(cdiv(C, 8), (unsigned)groups), 256, 0, st>>>(
       partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, param_gs, stats, 4 * C, dgamma, dbeta, grad_gs, coef,
       3 * C, accumulate);
   IEEE_TRY(launch_status("bn_bwd_finalize_kernel"));

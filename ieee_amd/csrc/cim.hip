@@ -349,8 +349,10 @@ __global__ __launch_bounds__(256) void cim_bwd_datt_kernel(const float* __restri
   }
 }
 
-// backward part 2 (elementwise): g1 = d_out*[one>0]; g2 = (d_out*(1+att) + d_avg/P + [p==argmax]*d_max)*[rest>0]
-//   mode 2 (interaction off): g1 = d_out (gradient straight to the trunk output), no g2
+// backward part 2: g1 = d_out*[one>0]; g2 = (d_out*(1+att) + d_avg/P + [p==argmax]*d_max)*[rest>0]
+//   mode 2 (interaction off): g1 = d_out (gradient straight to the trunk output), no g2.
+// One block per (sample, channel block): the per-(b,c) operands (6 pooled gradients pre-scaled by their
+// bin size, attention, BN scale/shift) are loaded once and the block then streams its 128 positions.
 template <typename T>
 __global__ __launch_bounds__(256) void cim_bwd_g_kernel(const float* __restrict__ dP, const T* __restrict__ y1,
                                                         const T* __restrict__ y2, const float* __restrict__ st1,
@@ -360,16 +362,54 @@ __global__ __launch_bounds__(256) void cim_bwd_g_kernel(const float* __restrict_
                                                         T* __restrict__ g2, PosGeom g, int64_t gs, int H, int parts,
                                                         int mode, int64_t pool_gs) {
   constexpr int VEC = 16 / sizeof(T);
+  constexpr int MAXP = 8;
   const int z = blockIdx.y;
-  const int64_t total = (int64_t)g.B * g.P * g.cprw;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % g.cprw);
-    const int64_t bp = i / g.cprw;
-    const int p = (int)(bp % g.P), b = (int)(bp / g.P);
-    const int c0 = ch * VEC;
+  const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
+  const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
+  const int c0 = (cb * g.tx + tx) * VEC;
+  float dps[MAXP][VEC];
+  int bs[MAXP], be[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    bs[i] = i < parts ? bin_start(i, H, parts) : 0;
+    be[i] = i < parts ? bin_end(i, H, parts) : 0;
+    const float inv = i < parts ? 1.0f / ((be[i] - bs[i]) * g.W) : 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+      dps[i][e] = i < parts ? dP[(((int64_t)z * g.B + b) * parts + i) * g.C + c0 + e] * inv : 0.f;
+  }
+  float sc1[VEC], sh1[VEC], sc2[VEC], sh2[VEC], a1[VEC], dav[VEC], dmx[VEC];
+  int am[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    sc1[e] = sh1[e] = sc2[e] = sh2[e] = 0.f; a1[e] = 1.f; dav[e] = dmx[e] = 0.f; am[e] = -1;
+    if (mode != 2) {
+      sc1[e] = st1[(int64_t)z * 4 * g.C + 2 * g.C + c0 + e];
+      sh1[e] = st1[(int64_t)z * 4 * g.C + 3 * g.C + c0 + e];
+      sc2[e] = st2[(int64_t)z * 4 * g.C + 2 * g.C + c0 + e];
+      sh2[e] = st2[(int64_t)z * 4 * g.C + 3 * g.C + c0 + e];
+    }
+    if (mode == 0) {
+      const int64_t bc = ((int64_t)z * g.B + b) * g.C + c0 + e;
+      const int64_t pc = z * pool_gs + (int64_t)b * g.C + c0 + e;
+      a1[e] = 1.f + att[bc];
+      dav[e] = davg[pc] * (1.0f / g.P);
+      dmx[e] = dmax[pc];
+      am[e] = amax[bc];
+    }
+  }
+  for (int p = ty; p < g.P; p += g.ty) {
+    const int h = p / g.W;
     float d[VEC];
-    dout_at(dP, ((int64_t)z * g.B + b) * parts * g.C, g.C, c0, p / g.W, H, g.W, parts, d, VEC);
-    const int64_t off = z * gs + i * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) d[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i)
+      if (h >= bs[i] && h < be[i]) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d[e] += dps[i][e];
+      }
+    const int64_t off = z * gs + ((int64_t)b * g.P + p) * g.C + c0;
     if (mode == 2) {
       *(uint4*)(g1 + off) = Vec16<T>::pack(d);
       continue;
@@ -377,20 +417,12 @@ __global__ __launch_bounds__(256) void cim_bwd_g_kernel(const float* __restrict_
     float v1[VEC], v2[VEC], o1[VEC], o2[VEC];
     Vec16<T>::unpack(*(const uint4*)(y1 + off), v1);
     Vec16<T>::unpack(*(const uint4*)(y2 + off), v2);
-    const float* s1 = st1 + (int64_t)z * 4 * g.C;
-    const float* s2 = st2 + (int64_t)z * 4 * g.C;
-    const int64_t bc = ((int64_t)z * g.B + b) * g.C + c0;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const int c = c0 + e;
-      const bool on1 = v1[e] * s1[2 * g.C + c] + s1[3 * g.C + c] > 0.f;
-      const bool on2 = v2[e] * s2[2 * g.C + c] + s2[3 * g.C + c] > 0.f;
-      float t2 = d[e];
-      if (mode == 0) {
-        const int64_t pc = z * pool_gs + (int64_t)b * g.C + c0 + e;
-        t2 = d[e] * (1.f + att[bc + e]) + davg[pc] * (1.0f / g.P);
-        if (amax[bc + e] == p) t2 += dmax[pc];
-      }
+      const bool on1 = v1[e] * sc1[e] + sh1[e] > 0.f;
+      const bool on2 = v2[e] * sc2[e] + sh2[e] > 0.f;
+      float t2 = d[e] * a1[e] + dav[e];
+      if (am[e] == p) t2 += dmx[e];
       o1[e] = on1 ? d[e] : 0.f;
       o2[e] = on2 ? t2 : 0.f;
     }
@@ -542,7 +574,7 @@ extern "C" int ieee_cim_tail_bwd_g(const float* dparts, const void* y1, const vo
   IEEE_REQUIRE(mode != 0 || (att && davg && dmax && argmax), "cim_tail_bwd_g: missing attention operands");
   const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(ew_blocks2(B * H * W * C / vecw(dtype)), 3);
+  dim3 grid((unsigned)(B * g.cblocks), 3);
   DISPATCH_T(dtype, (cim_bwd_g_kernel<float><<<grid, 256, 0, st>>>(dparts, (const float*)y1, (const float*)y2, stats1, stats2, att, davg, dmax, argmax, (float*)g1, (float*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs)),
              (cim_bwd_g_kernel<bf16><<<grid, 256, 0, st>>>(dparts, (const bf16*)y1, (const bf16*)y2, stats1, stats2, att, davg, dmax, argmax, (bf16*)g1, (bf16*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs)));
   return launch_status("cim_bwd_g_kernel");

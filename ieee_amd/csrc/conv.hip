@@ -139,23 +139,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ d
 }
 
 // dW[z][co][ci][r][s] (OIHW fp32, the reference's parameter layout) = sum over splits of
-// slab[z][ks][co][(r*S+s)*Ci + ci]; deterministic (fixed summation order).
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splitk, int Co,
-                                    int Ci, int RS, int64_t slab_gs, int64_t dw_gs, int accumulate) {
+// slab[z][ks][co][(r*S+s)*Ci + ci]; deterministic (fixed summation order).  Threads walk the slab
+// order so the (dominant) slab reads are coalesced; for 3x3 / 7x7 the 4-byte writes scatter.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                           int splitk, int Co, int Ci, int RS, int64_t slab_gs,
+                                                           int64_t dw_gs, int accumulate) {
   const int z = blockIdx.y;
   const int64_t total = (int64_t)Co * Ci * RS;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index in slab order [co][rs][ci]
   if (i >= total) return;
-  const int rs = (int)(i % RS);
-  const int64_t t = i / RS;
-  const int ci = (int)(t % Ci);
-  const int co = (int)(t / Ci);
-  const float* s = slab + z * slab_gs + (int64_t)co * (RS * Ci) + (int64_t)rs * Ci + ci;
-  const int64_t stride = (int64_t)Co * Ci * RS;
+  const float* s = slab + z * slab_gs + i;
   float acc = 0.f;
-  for (int k = 0; k < splitk; ++k) acc += s[k * stride];
-  float* o = dw + z * dw_gs + i;
-  *o = accumulate ? (*o + acc) : acc;
+  for (int k = 0; k < splitk; ++k) acc += s[k * total];
+  int64_t o = i;
+  if (RS > 1) {
+    const int ci = (int)(i % Ci);
+    const int64_t t = i / Ci;
+    const int rs = (int)(t % RS);
+    const int co = (int)(t / RS);
+    o = ((int64_t)co * Ci + ci) * RS + rs;
+  }
+  float* d = dw + z * dw_gs + o;
+  *d = accumulate ? (*d + acc) : acc;
 }
 
 // Weight packing from the reference's fp32 OIHW parameters:

@@ -371,82 +371,95 @@ __global__ void ce_heads_kernel(const float* rowloss, const int* correct, float*
 }
 
 // 3M loss (torchreid/losses/multi_modal_margin_loss_new.py:19-40), feats [3][B][D] in the order R,N,T.
+// One block per identity chunk (torch.chunk semantics: ceil(B/label_num) rows each); every block recounts
+// label_num itself (B is tiny), writes its chunk's term and that chunk's rows of dfeats.  A second, single
+// thread pass sums the terms in chunk order: deterministic.
 // out[0] = loss, out[1] = label_num, out[2] = number of chunks torch.chunk yields (< label_num => the
-// reference raises IndexError).  Single block: deterministic, B*D is tiny.
+// reference raises IndexError).
 __global__ __launch_bounds__(256) void margin3m_kernel(const float* feats, const int64_t* pids, float* dfeats,
-                                                       float* out, int B, int D, float margin, float gscale) {
+                                                       float* terms, int B, int D, float margin, float gscale) {
   __shared__ float red[3][256];
-  __shared__ int s_n;
+  __shared__ int s_cnt[256];
   __shared__ int s_sel;
   __shared__ float s_sign;
   const int t = threadIdx.x;
-  if (t == 0) {
-    int n = 0;
-    for (int i = 0; i < B; ++i) {
-      bool seen = false;
-      for (int j = 0; j < i; ++j) if (pids[j] == pids[i]) { seen = true; break; }
-      n += seen ? 0 : 1;
-    }
-    s_n = n;
+  int cnt = 0;
+  for (int i = t; i < B; i += 256) {
+    bool seen = false;
+    for (int j = 0; j < i; ++j) if (pids[j] == pids[i]) { seen = true; break; }
+    cnt += seen ? 0 : 1;
   }
+  s_cnt[t] = cnt;
   __syncthreads();
-  const int n = s_n;
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) s_cnt[t] += s_cnt[t + o]; __syncthreads(); }
+  const int n = s_cnt[0];
   const int csize = (B + n - 1) / n;            // torch.chunk: ceil(B / chunks) rows per chunk
   const int nchunks = (B + csize - 1) / csize;
   const int nuse = nchunks < n ? nchunks : n;
+  const int ch = blockIdx.x;
   const int64_t BD = (int64_t)B * D;
-  if (dfeats) for (int64_t i = t; i < 3 * BD; i += 256) dfeats[i] = 0.f;
+  if (ch == 0 && t == 0) { terms[B] = (float)n; terms[B + 1] = (float)nchunks; terms[B + 2] = (float)nuse; }
+  const int r0 = ch * csize, r1 = min(B, r0 + csize), rows = r1 - r0;
+  if (rows <= 0) { if (t == 0) terms[ch] = 0.f; return; }
+  if (ch >= nuse) {   // rows beyond the chunks the reference loops over: no loss term, zero gradient
+    if (t == 0) terms[ch] = 0.f;
+    if (dfeats)
+      for (int m = 0; m < 3; ++m)
+        for (int64_t i = t; i < (int64_t)rows * D; i += 256) dfeats[m * BD + (int64_t)r0 * D + i] = 0.f;
+    return;
+  }
+  float d12 = 0.f, d23 = 0.f, d13 = 0.f;
+  for (int k = t; k < D; k += 256) {
+    float c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    for (int r = r0; r < r1; ++r) { c1 += feats[r * D + k]; c2 += feats[BD + r * D + k]; c3 += feats[2 * BD + r * D + k]; }
+    c1 /= rows; c2 /= rows; c3 /= rows;
+    d12 += (c1 - c2) * (c1 - c2);
+    d23 += (c2 - c3) * (c2 - c3);
+    d13 += (c1 - c3) * (c1 - c3);
+  }
+  red[0][t] = d12; red[1][t] = d23; red[2][t] = d13;
   __syncthreads();
-  float loss = 0.f;
-  for (int ch = 0; ch < nuse; ++ch) {
-    const int r0 = ch * csize, r1 = min(B, r0 + csize), rows = r1 - r0;
-    float d12 = 0.f, d23 = 0.f, d13 = 0.f;
-    for (int k = t; k < D; k += 256) {
-      float c1 = 0.f, c2 = 0.f, c3 = 0.f;
-      for (int r = r0; r < r1; ++r) { c1 += feats[r * D + k]; c2 += feats[BD + r * D + k]; c3 += feats[2 * BD + r * D + k]; }
-      c1 /= rows; c2 /= rows; c3 /= rows;
-      d12 += (c1 - c2) * (c1 - c2);
-      d23 += (c2 - c3) * (c2 - c3);
-      d13 += (c1 - c3) * (c1 - c3);
-    }
-    red[0][t] = d12; red[1][t] = d23; red[2][t] = d13;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] += red[2][t + o]; }
-      __syncthreads();
-    }
-    if (t == 0) {
-      // python max(a, b, c) keeps the FIRST maximal argument: order (1,2), (2,3), (1,3)  (:35)
-      const float a1 = fabsf(margin - red[0][0]), a2 = fabsf(margin - red[1][0]), a3 = fabsf(margin - red[2][0]);
-      int sel = 0; float best = a1;
-      if (a2 > best) { best = a2; sel = 1; }
-      if (a3 > best) { best = a3; sel = 2; }
-      const float dsel = sel == 0 ? red[0][0] : (sel == 1 ? red[1][0] : red[2][0]);
-      const float x = margin - dsel;
-      s_sel = sel;
-      s_sign = x > 0.f ? -1.f : (x < 0.f ? 1.f : 0.f);   // d|m-d|/dd
-      red[0][0] = best;
-    }
-    __syncthreads();
-    loss += red[0][0];
-    if (dfeats) {
-      const int sel = s_sel;
-      const int ia = sel == 1 ? 1 : 0;          // pair (a,b): (0,1), (1,2), (0,2)
-      const int ib = sel == 0 ? 1 : 2;
-      const float coef = s_sign * 2.0f / rows * gscale;
-      for (int k = t; k < D; k += 256) {
-        float ca = 0.f, cb = 0.f;
-        for (int r = r0; r < r1; ++r) { ca += feats[ia * BD + r * D + k]; cb += feats[ib * BD + r * D + k]; }
-        const float diff = (ca - cb) / rows;
-        for (int r = r0; r < r1; ++r) {
-          dfeats[ia * BD + r * D + k] += coef * diff;
-          dfeats[ib * BD + r * D + k] -= coef * diff;
-        }
-      }
-    }
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; red[2][t] += red[2][t + o]; }
     __syncthreads();
   }
-  if (t == 0) { out[0] = loss; out[1] = (float)n; out[2] = (float)nchunks; }
+  if (t == 0) {
+    // python max(a, b, c) keeps the FIRST maximal argument: order (1,2), (2,3), (1,3)  (:35)
+    const float a1 = fabsf(margin - red[0][0]), a2 = fabsf(margin - red[1][0]), a3 = fabsf(margin - red[2][0]);
+    int sel = 0; float best = a1;
+    if (a2 > best) { best = a2; sel = 1; }
+    if (a3 > best) { best = a3; sel = 2; }
+    const float dsel = sel == 0 ? red[0][0] : (sel == 1 ? red[1][0] : red[2][0]);
+    const float x = margin - dsel;
+    s_sel = sel;
+    s_sign = x > 0.f ? -1.f : (x < 0.f ? 1.f : 0.f);   // d|m-d|/dd
+    terms[ch] = best;
+  }
+  __syncthreads();
+  if (dfeats) {
+    const int sel = s_sel;
+    const int ia = sel == 1 ? 1 : 0;          // pair (a,b): (0,1), (1,2), (0,2)
+    const int ib = sel == 0 ? 1 : 2;
+    const int ic = 3 - ia - ib;               // the modality not in the selected pair gets zero
+    const float coef = s_sign * 2.0f / rows * gscale;
+    for (int k = t; k < D; k += 256) {
+      float ca = 0.f, cb = 0.f;
+      for (int r = r0; r < r1; ++r) { ca += feats[ia * BD + r * D + k]; cb += feats[ib * BD + r * D + k]; }
+      const float diff = (ca - cb) / rows;
+      for (int r = r0; r < r1; ++r) {
+        dfeats[ia * BD + r * D + k] = coef * diff;
+        dfeats[ib * BD + r * D + k] = -coef * diff;
+        dfeats[ic * BD + r * D + k] = 0.f;
+      }
+    }
+  }
+}
+__global__ void margin3m_sum_kernel(const float* terms, float* out, int B) {
+  if (threadIdx.x != 0) return;
+  const int nuse = (int)terms[B + 2];
+  float loss = 0.f;
+  for (int c = 0; c < nuse; ++c) loss += terms[c];
+  out[0] = loss; out[1] = terms[B]; out[2] = terms[B + 1];
 }
 
 // torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov=True) (reference optim/optimizer.py:130-138)
@@ -619,12 +632,15 @@ extern "C" int ieee_ce_ls_fwd_bwd(const float* logits, const int64_t* targets, f
   return launch_status("ce_heads_kernel");
 }
 
-extern "C" int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, float* dfeats, float* out3, int64_t B,
-                                     int64_t D, float margin, float grad_scale, void* stream) {
-  IEEE_REQUIRE(feats && pids && out3, "margin3m_fwd_bwd: null pointer");
-  IEEE_REQUIRE(B >= 1 && D >= 1, "margin3m_fwd_bwd: empty input");
-  margin3m_kernel<<<1, 256, 0, (hipStream_t)stream>>>(feats, pids, dfeats, out3, (int)B, (int)D, margin, grad_scale);
-  return launch_status("margin3m_kernel");
+extern "C" int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, float* dfeats, float* out3, float* work,
+                                     int64_t B, int64_t D, float margin, float grad_scale, void* stream) {
+  IEEE_REQUIRE(feats && pids && out3 && work, "margin3m_fwd_bwd: null pointer");
+  IEEE_REQUIRE(B >= 1 && D >= 1 && B <= 65535, "margin3m_fwd_bwd: batch out of range");
+  hipStream_t st = (hipStream_t)stream;
+  margin3m_kernel<<<(unsigned)B, 256, 0, st>>>(feats, pids, dfeats, work, (int)B, (int)D, margin, grad_scale);
+  IEEE_TRY(launch_status("margin3m_kernel"));
+  margin3m_sum_kernel<<<1, 64, 0, st>>>(work, out3, (int)B);
+  return launch_status("margin3m_sum_kernel");
 }
 
 extern "C" int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,

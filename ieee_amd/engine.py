@@ -299,15 +299,17 @@ class _FusedStepMixin(object):
         if not hasattr(self, "_scratch") or self._scratch[0].shape != logits.shape:
             self._scratch = (torch.empty_like(logits), torch.empty_like(feats),
                              torch.empty(18 * 2 + 3, dtype=torch.float32, device=dev),
-                             torch.empty(18 * B * 2, dtype=torch.float32, device=dev))
-        dl, df, small, work = self._scratch
+                             torch.empty(18 * B * 2, dtype=torch.float32, device=dev),
+                             torch.empty(B + 3, dtype=torch.float32, device=dev))
+        dl, df, small, work, mwork = self._scratch
         head_loss, head_acc, out3 = small[:18], small[18:36], small[36:39]
         _lib.check(lib.ieee_ce_ls_fwd_bwd(_lib.ptr(logits), _lib.ptr(pids), _lib.ptr(dl), _lib.ptr(head_loss),
                                           _lib.ptr(head_acc), _lib.ptr(work), 18, B, C, float(eps),
                                           float(weight_x) * ddp.ce_grad_scale(), _lib.stream()))
         if weight_m > 0:
-            _lib.check(lib.ieee_margin3m_fwd_bwd(_lib.ptr(feats), _lib.ptr(pids), _lib.ptr(df), _lib.ptr(out3), B,
-                                                 feats.shape[2], float(margin), float(weight_m), _lib.stream()))
+            _lib.check(lib.ieee_margin3m_fwd_bwd(_lib.ptr(feats), _lib.ptr(pids), _lib.ptr(df), _lib.ptr(out3),
+                                                 _lib.ptr(mwork), B, feats.shape[2], float(margin), float(weight_m),
+                                                 _lib.stream()))
         else:
             df.zero_()
             out3.zero_()

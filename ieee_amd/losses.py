@@ -62,7 +62,8 @@ class _MarginFunction(torch.autograd.Function):
         p = pids.to(device=feats.device, dtype=torch.int64).contiguous()
         df = torch.empty_like(feats)
         out3 = torch.empty(3, dtype=torch.float32, device=feats.device)
-        _lib.check(lib.ieee_margin3m_fwd_bwd(_lib.ptr(feats), _lib.ptr(p), _lib.ptr(df), _lib.ptr(out3), B, D,
+        work = torch.empty(B + 3, dtype=torch.float32, device=feats.device)
+        _lib.check(lib.ieee_margin3m_fwd_bwd(_lib.ptr(feats), _lib.ptr(p), _lib.ptr(df), _lib.ptr(out3), _lib.ptr(work), B, D,
                                              float(margin), 1.0, _lib.stream()))
         ctx.save_for_backward(df)
         ctx.out3 = out3

@@ -209,9 +209,9 @@ int ieee_ce_ls_fwd_bwd(const float* logits, const int64_t* targets, float* dlogi
                        float* head_acc, float* work, int64_t heads, int64_t B, int64_t C, float eps,
                        float grad_scale, void* stream);
 /* 3M loss (torchreid/losses/multi_modal_margin_loss_new.py:19-40); feats [3][B][D] = R,N,T;
- * out3 = {loss, label_num, chunks torch.chunk would yield}; dfeats optional */
-int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, float* dfeats, float* out3, int64_t B,
-                          int64_t D, float margin, float grad_scale, void* stream);
+ * out3 = {loss, label_num, chunks torch.chunk would yield}; dfeats optional; work: B+3 floats */
+int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, float* dfeats, float* out3, float* work,
+                          int64_t B, int64_t D, float margin, float grad_scale, void* stream);
 /* torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov) as configured by the reference
  * (torchreid/optim/optimizer.py:130-138) over a flat fp32 range */
 int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
