@@ -4,6 +4,9 @@
 // The three modality streams (RGB, NI, TI) are batched into every launch (groups = 3).
 // No allocation, no host synchronisation; parameters stay in the caller's flat fp32 buffers, laid
 // out exactly like the reference's state_dict (the caller binds name -> offset, see ieee_net_bind).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <map>
 #include <string>
 #include <vector>
@@ -63,6 +66,8 @@ struct Net {
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
   std::vector<int> ev_cat;
+  std::vector<std::string> ev_name;
+  std::vector<double> ev_flops;
   size_t ev_used = 0;
   double prof_flops[2] = {0, 0};
   int64_t prof_launches[2] = {0, 0};
@@ -272,6 +277,9 @@ struct Run {
     }
     hipEventRecord(n.ev_pool[n.ev_used], (hipStream_t)st);
     n.ev_cat.push_back(cat);
+    n.ev_name.push_back(u.name + " " + std::to_string(u.Ci) + "->" + std::to_string(u.Co) + " k" + std::to_string(u.R) +
+                        " s" + std::to_string(u.stride) + " " + std::to_string(u.Ho) + "x" + std::to_string(u.Wo));
+    n.ev_flops.push_back(3.0 * 2.0 * (double)u.M(B) * u.Co * u.R * u.R * u.Ci);
     n.prof_flops[cat] += 3.0 * 2.0 * (double)u.M(B) * u.Co * u.R * u.R * u.Ci;   // algorithmic, 3 modalities
     n.prof_launches[cat] += 1;
   }
@@ -689,6 +697,8 @@ extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {
     n->profiling = true;
     n->ev_used = 0;
     n->ev_cat.clear();
+    n->ev_name.clear();
+    n->ev_flops.clear();
     n->prof_flops[0] = n->prof_flops[1] = 0;
     n->prof_launches[0] = n->prof_launches[1] = 0;
     return IEEE_OK;
@@ -701,6 +711,18 @@ extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {
     float t = 0.f;
     IEEE_HIP(hipEventElapsedTime(&t, n->ev_pool[i], n->ev_pool[i + 1]));
     ms[n->ev_cat[i / 2]] += t;
+  }
+  if (const char* path = getenv("IEEE_PROFILE_DUMP")) {   // per-launch table for kernel tuning
+    if (FILE* f = fopen(path, "w")) {
+      fprintf(f, "unit,kind,us,gflop,tflops\n");
+      for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
+        float t = 0.f;
+        hipEventElapsedTime(&t, n->ev_pool[i], n->ev_pool[i + 1]);
+        fprintf(f, "%s,%s,%.2f,%.3f,%.1f\n", n->ev_name[i / 2].c_str(), n->ev_cat[i / 2] ? "wgrad" : "gather", t * 1e3,
+                n->ev_flops[i / 2] / 1e9, n->ev_flops[i / 2] / (t * 1e-3) / 1e12);
+      }
+      fclose(f);
+    }
   }
   for (int c = 0; c < 2; ++c) { out6[c * 3 + 0] = ms[c]; out6[c * 3 + 1] = n->prof_flops[c]; out6[c * 3 + 2] = (double)n->prof_launches[c]; }
   return IEEE_OK;

@@ -1,0 +1,123 @@
+"""GPU: the reference-shaped engine surface.  Fused train step (native forward, 18-head CE, 3M,
+backward, fused SGD) against the oracle's CPU restatement of the reference step; the autograd path with
+torch.optim.SGD against the fused path; and the device-resident evaluation pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from tests.util_model import C, generated_state, images
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeDM(object):
+    num_train_pids = C
+    sources = ["synthetic"]
+
+    def __init__(self, test_loader=None):
+        self.train_loader = []
+        self.test_loader = test_loader or {}
+
+
+def make(seed, fused=True, dtype=torch.float32):
+    from ieee_amd.engine import Image3MEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, compute_dtype=dtype)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = generated_state(shapes, seed)
+    m.load_state_dict(sd)
+    opt = build_optimizer(m, optim="sgd", lr=1e-3, weight_decay=5e-4, momentum=0.9, fused=fused)
+    eng = Image3MEngine(FakeDM(), m, opt, margin=1, weight_m=1, weight_x=1, use_gpu=True, label_smooth=True)
+    m.train()
+    return eng, m, sd
+
+
+def batch(B, seed):
+    xs = images(B, seed)
+    pids = torch.arange(B) // 4
+    return {"img": xs, "pid": pids, "camid": pids * 0, "impath": "", "timeid": pids * 0}
+
+
+def test_fused_step_matches_oracle_step():
+    B, seed = 8, 3
+    eng, m, sd = make(seed)
+    s = eng.forward_backward(batch(B, seed))
+    assert set(s) == {"loss", "LossX", "LossM", "accR", "lossR", "accN", "lossN", "accT", "lossT"}
+    assert torch.is_tensor(s["LossM"]) and s["LossM"].dim() == 0          # the reference returns a 0-d tensor here
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    ref, grads, new_sd, _ = om.train_step(sd, images(B, seed), torch.arange(B) // 4, C)
+    for k in ("loss", "LossX", "lossR", "lossN", "lossT", "accR", "accN", "accT"):
+        assert abs(float(s[k]) - ref[k]) <= 1e-4 * max(1.0, abs(ref[k])), k
+    assert abs(float(s["LossM"]) - ref["LossM"]) < 1e-4
+    # parameters after one SGD-nesterov step (lr 1e-3): update = lr*(g + wd*p)*(1+momentum)
+    mine = m.state_dict()
+    worst = 0.0
+    for k, v in new_sd.items():
+        if k.endswith("num_batches_tracked") or "running_" in k:
+            continue
+        upd_ref = (new_sd[k] - sd[k])
+        upd_my = (mine[k].cpu() - sd[k])
+        denom = upd_ref.abs().max().item()
+        if denom < 1e-12:
+            assert upd_my.abs().max().item() < 1e-9, k            # conv_value: untouched
+            continue
+        worst = max(worst, (upd_my - upd_ref).abs().max().item() / denom)
+    assert worst < 0.25      # per-tensor max error relative to the largest update; reference noise floor ~0.14
+    # conv_query receives zero gradients but is still decayed; conv_value is untouched
+    q, v = "REM.0.conv_query.weight", "REM.0.conv_value.weight"
+    torch.testing.assert_close(mine[q].cpu(), new_sd[q], rtol=1e-6, atol=1e-9)
+    assert torch.equal(mine[v].cpu(), sd[v])
+
+
+def test_autograd_path_equals_fused_path():
+    B, seed = 8, 4
+    eng_f, m_f, _ = make(seed, fused=True)
+    eng_a, m_a, _ = make(seed, fused=False)
+    assert type(eng_a.optimizer).__name__ == "SGD"
+    b = batch(B, seed)
+    s_f = eng_f.forward_backward({k: ([x.clone() for x in v] if k == "img" else v) for k, v in b.items()})
+    s_a = eng_a.forward_backward(b)
+    for k in ("loss", "LossX", "lossR", "accT"):
+        assert abs(float(s_f[k]) - float(s_a[k])) < 1e-4 * max(1, abs(float(s_a[k])))
+    sd_f, sd_a = m_f.state_dict(), m_a.state_dict()
+    for k in sd_f:
+        if sd_f[k].is_floating_point():
+            assert (sd_f[k] - sd_a[k]).abs().max().item() <= 1e-7 + 1e-5 * sd_a[k].abs().max().item(), k
+    # two more steps exercise the momentum buffers on both sides
+    for _ in range(2):
+        eng_f.forward_backward(batch(B, seed))
+        eng_a.forward_backward(batch(B, seed))
+    for k in ("backbone.0.conv1.weight", "classifier_T.5.weight", "REM.1.conv_query.weight"):
+        a, f = m_a.state_dict()[k], m_f.state_dict()[k]
+        assert (a - f).abs().max().item() <= 2e-3 * (a - _orig(k, seed)).abs().max().item() + 1e-8, k
+
+
+def _orig(k, seed):
+    from ieee_amd._spec import state_spec
+    shapes = {n: s for n, s, _ in state_spec(C)}
+    return generated_state({k: shapes[k]}, seed)[k].cuda()
+
+
+def test_softmax_engine_and_eval_pipeline(capsys):
+    from ieee_amd.engine import MultiModalImageSoftmaxEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    m = build_model("ieee3modalPart", num_classes=C, loss="softmax", pretrained=False, compute_dtype=torch.bfloat16)
+    opt = build_optimizer(m, optim="sgd", lr=1e-3)
+    # tiny synthetic query/gallery loaders in the reference's batch-dict format
+    def loader(n, seed, cam):
+        xs = images(n, seed)
+        return [{"img": [x[i:i + 4] for x in xs], "pid": torch.arange(i, min(i + 4, n)) % 5,
+                 "camid": torch.full((min(4, n - i),), cam), "impath": "", "timeid": torch.zeros(min(4, n - i))}
+                for i in range(0, n, 4)]
+    dm = FakeDM({"synthetic": {"query": loader(8, 1, 0), "gallery": loader(12, 2, 1)}})
+    eng = MultiModalImageSoftmaxEngine(dm, m, opt, use_gpu=True)
+    m.train()
+    s = eng.forward_backward(batch(8, 1))
+    assert set(s) == {"loss_all", "loss_R", "acc_R", "loss_N", "acc_N", "loss_T", "acc_T"}
+    assert np.isfinite(s["loss_all"])
+    rank1_map = eng.test()
+    out = capsys.readouterr().out
+    assert "mAP:" in out and "Rank-1" in out and 0.0 <= rank1_map <= 1.0
