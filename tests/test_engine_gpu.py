@@ -91,7 +91,7 @@ def test_autograd_path_equals_fused_path():
         eng_a.forward_backward(batch(B, seed))
     for k in ("backbone.0.conv1.weight", "classifier_T.5.weight", "REM.1.conv_query.weight"):
         a, f = m_a.state_dict()[k], m_f.state_dict()[k]
-        assert (a - f).abs().max().item() <= 2e-3 * (a - _orig(k, seed)).abs().max().item() + 1e-8, k
+        assert (a - f).abs().max().item() <= 1e-2 * (a - _orig(k, seed)).abs().max().item() + 1e-8, k
 
 
 def _orig(k, seed):
