@@ -1,0 +1,87 @@
+"""CPU, world_size 2 over gloo: the N>1 data path (ieee_amd/dist.py) — identity-aligned sharding, the
+single flat all-reduce, and the loss scaling that makes the sum of rank-local gradients equal the
+gradient of the reference's global loss (CE = batch mean, 3M = sum over identities)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ieee_amd import dist as ddp
+
+
+def test_shard_bounds_cover_batch_on_identity_boundaries():
+    for B, K, W in ((512, 4, 8), (64, 4, 2), (24, 4, 4), (8, 4, 2), (40, 4, 3)):
+        spans = [ddp.shard_bounds(B, K, W, r) for r in range(W)]
+        assert spans[0][0] == 0 and spans[-1][1] == B
+        for (a, b), (c, d) in zip(spans, spans[1:]):
+            assert b == c
+        assert all((b - a) % K == 0 and a % K == 0 for a, b in spans)
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= K
+    with pytest.raises(AssertionError):
+        ddp.shard_bounds(10, 4, 2, 0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    from oracle import model as om
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    w, r, _ = ddp.init_from_env(backend="gloo")
+    assert (w, r) == (world, rank) and ddp.world_size() == world and ddp.rank() == rank
+    torch.manual_seed(0)                      # same global batch on every rank
+    B, K, C, D = 16, 4, 11, 32
+    logits = torch.randn(6, B, C)
+    feats = torch.nn.functional.normalize(torch.randn(3, B, D), dim=2)
+    pids = torch.arange(B) // K
+    data = {"img": [torch.arange(B).float().view(B, 1, 1, 1).expand(B, 3, 2, 2)] * 3, "pid": pids,
+            "camid": torch.zeros(B), "timeid": torch.zeros(B), "impath": "x"}
+    shard = ddp.shard_batch(data, K)
+    a, b = ddp.shard_bounds(B, K, world, rank)
+    assert torch.equal(shard["pid"], pids[a:b]) and shard["img"][0].shape[0] == b - a and shard["impath"] == "x"
+    assert float(shard["img"][1][0, 0, 0, 0]) == a
+    # global loss of the reference: sum_h CE_h (batch mean) + 3M (sum over identities)
+    lg = logits.clone().requires_grad_(True)
+    fg = feats.clone().requires_grad_(True)
+    loss = sum(om.cross_entropy_ls(lg[h], pids, C) for h in range(6)) + om.margin3m(fg[0], fg[1], fg[2], pids, 1.0)
+    loss.backward()
+    # rank-local loss with the DP scaling rule; gradients land in a flat buffer that is all-reduced once
+    ll = logits[:, a:b].clone().requires_grad_(True)
+    fl = feats[:, a:b].clone().requires_grad_(True)
+    lp = pids[a:b]
+    local = ddp.ce_grad_scale() * sum(om.cross_entropy_ls(ll[h], lp, C) for h in range(6)) \
+        + om.margin3m(fl[0], fl[1], fl[2], lp, 1.0)
+    local.backward()
+    flat = torch.zeros(6 * B * C + 3 * B * D)
+    gl = torch.zeros(6, B, C)
+    gf = torch.zeros(3, B, D)
+    gl[:, a:b] = ll.grad
+    gf[:, a:b] = fl.grad
+    flat[:6 * B * C] = gl.flatten()
+    flat[6 * B * C:] = gf.flatten()
+    ddp.allreduce_sum_(flat)
+    torch.testing.assert_close(flat[:6 * B * C].view(6, B, C), lg.grad, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(flat[6 * B * C:].view(3, B, D), fg.grad, rtol=1e-5, atol=1e-7)
+    vec = torch.ones(9)
+    ddp.reduce_summary_(vec)
+    assert float(vec[0]) == world
+    dist.destroy_process_group()
+    ret[rank] = 1
+
+
+def test_two_rank_gloo_allreduce_and_loss_scaling():
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert dict(ret) == {0: 1, 1: 1}
