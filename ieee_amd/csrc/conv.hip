@@ -90,9 +90,18 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ 
   w += z * a.w_gs;
   dst += z * a.dst_gs;
   if (addend != nullptr) addend += z * a.dst_gs;
+  StoreEpi<T> epi{dst, addend, a.N, a.M, a.N};
+  if constexpr (!SLOW && sizeof(T) == 2) {   // bf16 fast path: both operands through LDS-DMA
+    const int ch = nt_dma_chunk(threadIdx.x);
+    LoaderPlainNT<T, BN / 32> lbd;
+    lbd.init(w, a.ldw, n0, a.N, a.ldw, ch);
+    LoaderIm2colNT<T, 4> la;
+    la.init(src, a.g, m0, ch);
+    gemm_nt_dma<128, BN, DMA_STAGES>(la, lbd, epi, a.ktiles, m0, n0, smem);
+    return;
+  }
   LoaderPlainNT<T, BN / 32> lb;
   lb.init(w, a.ldw, n0, a.N, a.ldw);
-  StoreEpi<T> epi{dst, addend, a.N, a.M, a.N};
   if constexpr (SLOW) {
     LoaderIm2colSlowNT<T, 4> la;
     la.init(src, a.g, m0);
@@ -124,9 +133,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ d
   slab += z * a.slab_gs + (int64_t)ks * a.Co * a.ncols;
   const int kbeg = ks * a.kchunk, kend = min(a.npix, kbeg + a.kchunk);
   const int ktiles = (kend - kbeg + ImgTN<T>::BK - 1) / ImgTN<T>::BK;
+  SlabEpi epi{slab, a.ncols, a.Co, a.ncols};
+  if constexpr (!SLOW && sizeof(T) == 2) {
+    const int ch = tn_dma_chunk(threadIdx.x);
+    LoaderColsTN<T> lad;
+    lad.init(dy, a.Co, m0, a.Co, kbeg, kend, ch);
+    LoaderIm2colTN<T> lbd;
+    lbd.init(x, a.g, n0, kbeg, kend, ch);
+    gemm_tn_dma<DMA_STAGES>(lad, lbd, epi, ktiles, m0, n0, smem);
+    return;
+  }
   LoaderColsTN<T> la;
   la.init(dy, a.Co, m0, a.Co, kbeg, kend);
-  SlabEpi epi{slab, a.ncols, a.Co, a.ncols};
   if constexpr (SLOW) {
     LoaderIm2colSlowTN<T> lb;
     lb.init(x, a.g, n0, kbeg, kend);
@@ -205,7 +223,15 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   const bool narrow = N <= 64;
   a.tiles_n = cdiv(N, narrow ? 64 : 128);
   dim3 grid(a.tiles_m * a.tiles_n, groups);
-  const size_t smem = narrow ? 2 * (128 + 64) * 128 : 2 * 256 * 128;
+  const bool dma = !slow && sizeof(T) == 2;                        // bf16 fast path: DMA_STAGES-deep LDS ring
+  const int stages = dma ? DMA_STAGES : 2;
+  const size_t smem = (size_t)stages * (128 + (narrow ? 64 : 128)) * 128;
+  static bool attr_done = false;
+  if (!attr_done) {   // > 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
+    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
   if (narrow) {
     if (slow) conv_gather_kernel<T, 64, true><<<grid, 256, smem, st>>>(src, w, dst, addend, a);
     else conv_gather_kernel<T, 64, false><<<grid, 256, smem, st>>>(src, w, dst, addend, a);
@@ -348,7 +374,12 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   a.slab_gs = (int64_t)nsplit * d.Co * a.ncols;
   const bool slow = (Ci % elem_vec(dtype)) != 0;
   dim3 grid(cdiv(d.Co, 128) * a.tiles_n, nsplit, (unsigned)groups);
-  const size_t smem = 64 * 1024;
+  const size_t smem = (dtype == IEEE_BF16 && !slow) ? (size_t)DMA_STAGES * 32 * 1024 : 64 * 1024;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
   hipStream_t st = (hipStream_t)stream;
   float* slab = (float*)work;
   if (dtype == IEEE_F32) {

@@ -53,9 +53,16 @@ __global__ __launch_bounds__(256) void distmat_kernel(const T* q, const T* g, co
   tile_map(tiles_m, tiles_n, 8, tm, tn);
   const int m0 = tm * 128, n0 = tn * 128;
   LoaderPlainNT<T, 4> la, lb;
+  DistEpi epi{out, qn, gn, ldo, m, n, metric};
+  if constexpr (sizeof(T) == 2) {   // bf16: operands through LDS-DMA
+    const int ch = nt_dma_chunk(threadIdx.x);
+    la.init(q, d, m0, m, d, ch);
+    lb.init(g, d, n0, n, d, ch);
+    gemm_nt_dma<128, 128, DMA_STAGES>(la, lb, epi, (d + 63) / 64, m0, n0, smem);
+    return;
+  }
   la.init(q, d, m0, m, d);
   lb.init(g, d, n0, n, d);
-  DistEpi epi{out, qn, gn, ldo, m, n, metric};
   gemm_nt<T, 128, 128>(la, lb, epi, (d + ImgNT<T>::BK - 1) / ImgNT<T>::BK, m0, n0, smem);
 }
 
@@ -284,7 +291,12 @@ extern "C" int ieee_sqeuclid_distmat(const void* q, const void* g, int64_t m, in
   float* qn = (float*)work;
   float* gn = qn + m;
   const int tiles_m = cdiv(m, 128), tiles_n = cdiv(n, 128);
-  const size_t smem = 2 * 256 * 128;
+  const size_t smem = (dtype == IEEE_BF16 ? DMA_STAGES : 2) * 256 * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)distmat_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
   if (dtype == IEEE_F32) {
     rownorm_kernel<float><<<cdiv(m, 4), 256, 0, st>>>((const float*)q, m, (int)d, metric, qn);
     rownorm_kernel<float><<<cdiv(n, 4), 256, 0, st>>>((const float*)g, n, (int)d, metric, gn);

@@ -246,6 +246,171 @@ __device__ __forceinline__ void gemm_tn(LA& la, LB& lb, Epi& epi, int ktiles, in
       epi(m0 + wm * 64 + i * 16 + (lane & 15), n0 + wn * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
 }
 
+// ------------------------------------------------------------------ LDS-DMA (bf16) cores
+// ds_write_b128 moves only ~79 B/clk/CU, so register staging makes the LDS pipe (not the MFMA) the
+// limiter of the bf16 tiles.  These variants stage both operands with global_load_lds_dwordx4
+// (global -> LDS, no VGPR, no ds_write).  The DMA writes lane-linearly (wave-uniform base + lane*16),
+// so the XOR swizzle moves to the SOURCE side: the thread whose LDS position is (row, slot f) fetches
+// logical chunk f ^ key(row); fragment reads are unchanged.  Out-of-range chunks (conv padding, tile
+// tails) are fetched from a 16-byte zero page.
+__device__ __attribute__((aligned(16))) static const unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ const void* zero_page() { return (const void*)g_zero_page; }
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// NT logical chunk of thread t (same for every slot: rows advance by 32, the key (row>>1)&7 does not change)
+__device__ __forceinline__ int nt_dma_chunk(int t) { return (t & 7) ^ ((t >> 4) & 7); }
+// TN logical chunk (bf16, 16 chunks per 256-B k-row): physical window (t&15)>>1, key h(k-row)
+__device__ __forceinline__ int tn_dma_chunk(int t) {
+  const int h = ((t >> 4) & 3) | (((t >> 7) & 1) << 2);
+  return ((((t & 15) >> 1) ^ h) << 1) | (t & 1);
+}
+
+// Loader contract (DMA): const void* addr(int slot) -> global address of the 16 bytes that belong at this
+// thread's LDS position (or zero_page()); void next().  Loaders are initialised with nt_dma_chunk /
+// tn_dma_chunk as their column chunk.
+//
+// Pipeline: a ring of DMA_STAGES LDS stages, up to DMA_STAGES-1 k-tiles in flight.  Per k-tile ONE raw
+// s_barrier, preceded by a COUNTED s_waitcnt vmcnt(N) that only retires the tile about to be read (the
+// younger tiles stay in flight across the barrier; __syncthreads() would drain them).  The tile issued
+// after the barrier overwrites the stage whose readers all passed that barrier.
+constexpr int DMA_STAGES = 2;   // default ring depth (the cores take it as a template parameter)
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `tiles_in_flight` younger tiles (PER glds each) are outstanding
+template <int PER> __device__ __forceinline__ void wait_tiles(int tiles_in_flight) {
+  if (tiles_in_flight >= 2) wait_vmcnt<2 * PER>();
+  else if (tiles_in_flight == 1) wait_vmcnt<PER>();
+  else wait_vmcnt<0>();
+}
+
+template <int BM, int BN, int STAGES, class LA, class LB, class Epi>
+__device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem) {
+  typedef ImgNT<bf16> Img;
+  constexpr int DMA_STAGES = STAGES;
+  constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;
+  constexpr int FM = BM / 32, FN = BN / 32;
+  constexpr int STAGE = (BM + BN) * 128;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int stage_idx) {
+    char* stage = smem + stage_idx * STAGE;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) glds16(la.addr(i), stage + (32 * i + 8 * wave_u) * 128);
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) glds16(lb.addr(i), stage + BM * 128 + (32 * i + 8 * wave_u) * 128);
+  };
+  // prologue: tiles 0 .. DMA_STAGES-2
+  int issued = 0;
+  for (; issued < DMA_STAGES - 1 && issued < ktiles; ++issued) {
+    if (issued > 0) { la.next(); lb.next(); }
+    issue(issued);
+  }
+  for (int kt = 0; kt < ktiles; ++kt) {
+    wait_tiles<ACH + BCH>(issued - kt - 1);   // tile kt has landed (for this wave's DMAs)
+    __builtin_amdgcn_s_barrier();              // ... for every wave's; and stage (kt-1)%S is free
+    if (issued < ktiles) {
+      la.next();
+      lb.next();
+      issue(issued % DMA_STAGES);
+      ++issued;
+    }
+    const char* cur = smem + (kt % DMA_STAGES) * STAGE;
+    const char* At = cur + (wm * (BM / 2)) * 128;
+    const char* Bt = cur + BM * 128 + (wn * (BN / 2)) * 128;
+#pragma unroll
+    for (int kk = 0; kk < Img::KSTEPS; ++kk) {
+      Img::Frag fa[FM], fb[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa[i] = Img::frag(At, i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb[j] = Img::frag(Bt, j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      epi(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, acc[i][j]);
+}
+
+template <int STAGES, class LA, class LB, class Epi>
+__device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem) {
+  typedef ImgTN<bf16> Img;
+  constexpr int DMA_STAGES = STAGES;
+  constexpr int TILE = Img::BK * 128 * 2;   // 16 KB
+  constexpr int STAGE = 2 * TILE;
+  constexpr int NCH = 4;                    // 64 k-rows / (256 threads / 16 chunks per row)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int stage_idx) {
+    char* stage = smem + stage_idx * STAGE;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) glds16(la.addr(i), stage + (16 * i + 4 * wave_u) * 256);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) glds16(lb.addr(i), stage + TILE + (16 * i + 4 * wave_u) * 256);
+  };
+  int issued = 0;
+  for (; issued < DMA_STAGES - 1 && issued < ktiles; ++issued) {
+    if (issued > 0) { la.next(); lb.next(); }
+    issue(issued);
+  }
+  for (int kt = 0; kt < ktiles; ++kt) {
+    wait_tiles<2 * NCH>(issued - kt - 1);
+    __builtin_amdgcn_s_barrier();
+    if (issued < ktiles) {
+      la.next();
+      lb.next();
+      issue(issued % DMA_STAGES);
+      ++issued;
+    }
+    const char* cur = smem + (kt % DMA_STAGES) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < Img::KSTEPS; ++kk) {
+      Img::Frag fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = Img::frag(cur, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = Img::frag(cur + TILE, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      epi(m0 + wm * 64 + i * 16 + (lane & 15), n0 + wn * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+}
+
 // ------------------------------------------------------------------ loaders
 // Plain row-major [rows][ld] matrix, K contiguous (weights, features, linear inputs).
 template <typename T, int NCH> struct LoaderPlainNT {
@@ -253,19 +418,22 @@ template <typename T, int NCH> struct LoaderPlainNT {
   static constexpr int BK = ImgNT<T>::BK;
   const T* p[NCH];
   int kcol, K;
-  __device__ __forceinline__ void init(const T* base, int64_t ld, int row0, int nrows, int K_) {
+  __device__ __forceinline__ void init(const T* base, int64_t ld, int row0, int nrows, int K_, int chunk = -1) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int row = row0 + (t >> 3) + 32 * i;
       p[i] = row < nrows ? base + (int64_t)row * ld : nullptr;
     }
-    kcol = (t & 7) * VEC;
+    kcol = (chunk < 0 ? (t & 7) : chunk) * VEC;
     K = K_;
   }
   __device__ __forceinline__ uint4 load(int i) const {
     if (p[i] == nullptr || kcol >= K) return make_uint4(0, 0, 0, 0);
     return *(const uint4*)(p[i] + kcol);
+  }
+  __device__ __forceinline__ const void* addr(int i) const {
+    return (p[i] == nullptr || kcol >= K) ? zero_page() : (const void*)(p[i] + kcol);
   }
   __device__ __forceinline__ void next() { kcol += BK; }
 };
@@ -290,17 +458,18 @@ template <typename T, int NCH> struct LoaderIm2colNT {
   int hb[NCH], wb[NCH];
   int r, s, ci0;
   GatherGeom g;
-  __device__ __forceinline__ void init(const T* src, const GatherGeom& g_, int m0) {
+  __device__ __forceinline__ void init(const T* src, const GatherGeom& g_, int m0, int chunk = -1) {
     g = g_;
     const int t = threadIdx.x;
     const int hw = g.Ho * g.Wo;
+    const int ch = chunk < 0 ? (t & 7) : chunk;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int m = m0 + (t >> 3) + 32 * i;
       if (m < g.npix) {
         const int n = m / hw, rem = m - n * hw;
         const int pp = rem / g.Wo, qq = rem - pp * g.Wo;
-        p[i] = src + (int64_t)n * g.Hs * g.Ws * g.Cs + (t & 7) * VEC;
+        p[i] = src + (int64_t)n * g.Hs * g.Ws * g.Cs + ch * VEC;
         hb[i] = pp * g.mul + g.off;
         wb[i] = qq * g.mul + g.off;
       } else {
@@ -318,6 +487,16 @@ template <typename T, int NCH> struct LoaderIm2colNT {
     }
     if ((unsigned)h >= (unsigned)g.Hs || (unsigned)w >= (unsigned)g.Ws) return make_uint4(0, 0, 0, 0);
     return *(const uint4*)(p[i] + ((int64_t)h * g.Ws + w) * g.Cs + ci0);
+  }
+  __device__ __forceinline__ const void* addr(int i) const {
+    if (p[i] == nullptr || r >= g.R) return zero_page();
+    int h = hb[i] + g.sgn * r, w = wb[i] + g.sgn * s;
+    if (g.div == 2) {
+      if ((h | w) & 1) return zero_page();
+      h >>= 1; w >>= 1;
+    }
+    if ((unsigned)h >= (unsigned)g.Hs || (unsigned)w >= (unsigned)g.Ws) return zero_page();
+    return (const void*)(p[i] + ((int64_t)h * g.Ws + w) * g.Cs + ci0);
   }
   __device__ __forceinline__ void next() {
     ci0 += BK;
@@ -382,9 +561,10 @@ template <typename T> struct LoaderColsTN {
   const T* base;  // already offset to this thread's column chunk, or nullptr if the chunk is out of range
   int64_t ld;
   int k0, kend;
-  __device__ __forceinline__ void init(const T* mat, int64_t ld_, int col0, int ncols, int kbeg, int kend_) {
+  __device__ __forceinline__ void init(const T* mat, int64_t ld_, int col0, int ncols, int kbeg, int kend_,
+                                       int chunk = -1) {
     const int t = threadIdx.x;
-    const int col = col0 + (t % CPR) * VEC;
+    const int col = col0 + (chunk < 0 ? (t % CPR) : chunk) * VEC;
     base = col < ncols ? mat + col : nullptr;
     ld = ld_;
     k0 = kbeg + t / CPR;
@@ -394,6 +574,10 @@ template <typename T> struct LoaderColsTN {
     const int k = k0 + RPP * i;
     if (base == nullptr || k >= kend) return make_uint4(0, 0, 0, 0);
     return *(const uint4*)(base + (int64_t)k * ld);
+  }
+  __device__ __forceinline__ const void* addr(int i) const {
+    const int k = k0 + RPP * i;
+    return (base == nullptr || k >= kend) ? zero_page() : (const void*)(base + (int64_t)k * ld);
   }
   __device__ __forceinline__ void next() { k0 += BK; }
 };
@@ -408,11 +592,12 @@ template <typename T> struct LoaderIm2colTN {
   int r, s, ci;       // this thread's (fixed) column chunk
   bool colok;
   int lw, lhw;        // log2(Wo), log2(Ho*Wo) or -1
-  __device__ __forceinline__ void init(const T* src_, const GatherGeom& g_, int col0, int kbeg, int kend_) {
+  __device__ __forceinline__ void init(const T* src_, const GatherGeom& g_, int col0, int kbeg, int kend_,
+                                       int chunk = -1) {
     g = g_;
     src = src_;
     const int t = threadIdx.x;
-    const int tc = col0 + (t % CPR) * VEC;
+    const int tc = col0 + (chunk < 0 ? (t % CPR) : chunk) * VEC;
     const int ncols = g.R * g.S * g.Cs;
     colok = tc < ncols;
     const int tap = tc / g.Cs;
@@ -426,8 +611,12 @@ template <typename T> struct LoaderIm2colTN {
     lhw = (hw & (hw - 1)) == 0 ? __builtin_ctz(hw) : -1;
   }
   __device__ __forceinline__ uint4 load(int i) const {
+    const void* a = addr(i);
+    return a == zero_page() ? make_uint4(0, 0, 0, 0) : *(const uint4*)a;
+  }
+  __device__ __forceinline__ const void* addr(int i) const {
     const int m = k0 + RPP * i;
-    if (!colok || m >= kend) return make_uint4(0, 0, 0, 0);
+    if (!colok || m >= kend) return zero_page();
     int n, pp, qq;
     if (lw >= 0 && lhw >= 0) {
       n = m >> lhw;
@@ -442,8 +631,8 @@ template <typename T> struct LoaderIm2colTN {
       qq = rem - pp * g.Wo;
     }
     const int h = pp * g.mul + g.off + r, w = qq * g.mul + g.off + s;
-    if ((unsigned)h >= (unsigned)g.Hs || (unsigned)w >= (unsigned)g.Ws) return make_uint4(0, 0, 0, 0);
-    return *(const uint4*)(src + (((int64_t)n * g.Hs + h) * g.Ws + w) * g.Cs + ci);
+    if ((unsigned)h >= (unsigned)g.Hs || (unsigned)w >= (unsigned)g.Ws) return zero_page();
+    return (const void*)(src + (((int64_t)n * g.Hs + h) * g.Ws + w) * g.Cs + ci);
   }
   __device__ __forceinline__ void next() { k0 += BK; }
 };

@@ -273,9 +273,9 @@ struct Run {
   void prof_begin(int cat, const ConvUnit& u) {
     if (!n.profiling) return;
     if (n.ev_used + 2 > n.ev_pool.size()) {
-      for (int i = 0; i < 256; ++i) { hipEvent_t e; hipEventCreate(&e); n.ev_pool.push_back(e); }
+      for (int i = 0; i < 256; ++i) { hipEvent_t e; (void)hipEventCreate(&e); n.ev_pool.push_back(e); }
     }
-    hipEventRecord(n.ev_pool[n.ev_used], (hipStream_t)st);
+    (void)hipEventRecord(n.ev_pool[n.ev_used], (hipStream_t)st);
     n.ev_cat.push_back(cat);
     n.ev_name.push_back(u.name + " " + std::to_string(u.Ci) + "->" + std::to_string(u.Co) + " k" + std::to_string(u.R) +
                         " s" + std::to_string(u.stride) + " " + std::to_string(u.Ho) + "x" + std::to_string(u.Wo));
@@ -285,7 +285,7 @@ struct Run {
   }
   void prof_end() {
     if (!n.profiling) return;
-    hipEventRecord(n.ev_pool[n.ev_used + 1], (hipStream_t)st);
+    (void)hipEventRecord(n.ev_pool[n.ev_used + 1], (hipStream_t)st);
     n.ev_used += 2;
   }
   int conv(const ConvUnit& u, const void* in) {
@@ -717,7 +717,7 @@ extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {
       fprintf(f, "unit,kind,us,gflop,tflops\n");
       for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
         float t = 0.f;
-        hipEventElapsedTime(&t, n->ev_pool[i], n->ev_pool[i + 1]);
+        (void)hipEventElapsedTime(&t, n->ev_pool[i], n->ev_pool[i + 1]);
         fprintf(f, "%s,%s,%.2f,%.3f,%.1f\n", n->ev_name[i / 2].c_str(), n->ev_cat[i / 2] ? "wgrad" : "gather", t * 1e3,
                 n->ev_flops[i / 2] / 1e9, n->ev_flops[i / 2] / (t * 1e-3) / 1e12);
       }
