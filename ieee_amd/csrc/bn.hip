@@ -178,11 +178,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ a,
                                                             const T* __restrict__ y, int64_t gs, RedGeom g,
-                                                            float* partial, int64_t partial_gs) {
+                                                            float* partial, int64_t partial_gs,
+                                                            const float* __restrict__ stats, int64_t stats_gs,
+                                                            int mask_from_y) {
   constexpr int VEC = 16 / sizeof(T);
   const T* dd = da + blockIdx.y * gs;
   const T* aa = a ? a + blockIdx.y * gs : nullptr;
   const T* yy = y + blockIdx.y * gs;
+  const float* sc = stats + blockIdx.y * stats_gs + 2 * g.C;
+  const float* sh = sc + g.C;
   reduce_channels<T, 2>(g, partial, partial_gs, [&](int64_t off, int c0, float (*acc)[VEC]) {
     float d[VEC], m[VEC], v[VEC];
     Vec16<T>::unpack(*(const uint4*)(dd + off), d);
@@ -191,6 +195,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       Vec16<T>::unpack(*(const uint4*)(aa + off), m);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) d[e] = m[e] > 0.f ? d[e] : 0.f;
+    } else if (mask_from_y) {   // out = relu(y*scale+shift), so [out > 0] needs no extra tensor
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d[e] = (v[e] * sc[c0 + e] + sh[c0 + e]) > 0.f ? d[e] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { acc[0][e] += d[e]; acc[1][e] += d[e] * v[e]; }
@@ -233,9 +240,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ y, T* __restrict__ dy,
                                                            T* __restrict__ gout, const float* __restrict__ coef,
                                                            int64_t coef_gs, int64_t total_chunks, int cprw, int C,
-                                                           int64_t gs) {
+                                                           int64_t gs, const float* __restrict__ stats,
+                                                           int64_t stats_gs, int mask_from_y) {
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
+  const float* sc = stats + z * stats_gs + 2 * C;
+  const float* sh = sc + C;
   const float* k1 = coef + z * coef_gs;
   const float* k2 = k1 + C;
   const float* k3 = k2 + C;
@@ -253,6 +263,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       Vec16<T>::unpack(*(const uint4*)(aa + i * VEC), m);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) d[e] = m[e] > 0.f ? d[e] : 0.f;
+    } else if (mask_from_y) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d[e] = (v[e] * sc[c0 + e] + sh[c0 + e]) > 0.f ? d[e] : 0.f;
     }
     if (go) *(uint4*)(go + i * VEC) = Vec16<T>::pack(d);
 #pragma unroll
@@ -316,7 +329,7 @@ extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int
 extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
                              int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma,
                              int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
-                             float* partial, float* coef, int accumulate, void* stream) {
+                             float* partial, float* coef, int accumulate, int mask_from_y, void* stream) {
   IEEE_REQUIRE(dout && y && dy && gamma && stats && partial && coef, "bn2d_bwd: null pointer");
   IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_bwd: bad dtype");
   IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_bwd: C not a multiple of the vector width");
@@ -326,10 +339,10 @@ extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void*
   dim3 rgrid(g.cblocks * g.rblocks, (unsigned)groups);
   if (dtype == IEEE_F32)
     bn_bwd_reduce_kernel<float><<<rgrid, 256, 0, st>>>((const float*)dout, (const float*)out_mask, (const float*)y,
-                                                       act_gs, g, partial, partial_gs);
+                                                       act_gs, g, partial, partial_gs, stats, 4 * C, mask_from_y);
   else
     bn_bwd_reduce_kernel<bf16><<<rgrid, 256, 0, st>>>((const bf16*)dout, (const bf16*)out_mask, (const bf16*)y, act_gs,
-                                                      g, partial, partial_gs);
+                                                      g, partial, partial_gs, stats, 4 * C, mask_from_y);
   IEEE_TRY(launch_status("bn_bwd_reduce_kernel"));
   bn_bwd_finalize_kernel<<<dim3(cdiv(C, 8), (unsigned)groups), 256, 0, st>>>(
       partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, param_gs, stats, 4 * C, dgamma, dbeta, grad_gs, coef,
@@ -340,10 +353,10 @@ extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void*
   if (dtype == IEEE_F32)
     bn_bwd_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)dout, (const float*)out_mask, (const float*)y,
                                                      (float*)dy, (float*)g_out, coef, 3 * C, chunks, g.cprw, (int)C,
-                                                     act_gs);
+                                                     act_gs, stats, 4 * C, mask_from_y);
   else
     bn_bwd_apply_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)dout, (const bf16*)out_mask, (const bf16*)y,
                                                     (bf16*)dy, (bf16*)g_out, coef, 3 * C, chunks, g.cprw, (int)C,
-                                                    act_gs);
+                                                    act_gs, stats, 4 * C, mask_from_y);
   return launch_status("bn_bwd_apply_kernel");
 }

@@ -11,17 +11,18 @@ namespace ieee {
 
 // fp32 NCHW images (three separate tensors, as the reference's batch dict carries them) -> NHWC T
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* x0, const float* x1, const float* x2, T* out, int B, int C, int HW) {
+__global__ void nchw_to_nhwc_kernel(const float* x0, const float* x1, const float* x2, T* out, int B, int C, int HW,
+                                    int Cpad) {
   const int z = blockIdx.y;
   const float* x = z == 0 ? x0 : (z == 1 ? x1 : x2);
-  const int64_t total = (int64_t)B * HW * C;
+  const int64_t total = (int64_t)B * HW * Cpad;
   T* o = out + z * total;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int64_t p = i / C;
+    const int c = (int)(i % Cpad);
+    const int64_t p = i / Cpad;
     const int hw = (int)(p % HW);
     const int b = (int)(p / HW);
-    o[i] = from_f32<T>(x[((int64_t)b * C + c) * HW + hw]);
+    o[i] = c < C ? from_f32<T>(x[((int64_t)b * C + c) * HW + hw]) : from_f32<T>(0.f);
   }
 }
 
@@ -481,12 +482,13 @@ static int vecw(int dtype) { return dtype == IEEE_BF16 ? 8 : 4; }
   } while (0)
 
 extern "C" int ieee_nchw_to_nhwc3(const float* x_rgb, const float* x_ni, const float* x_ti, void* out, int dtype,
-                                  int64_t B, int64_t C, int64_t H, int64_t W, void* stream) {
+                                  int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cpad, void* stream) {
   IEEE_REQUIRE(x_rgb && x_ni && x_ti && out, "nchw_to_nhwc3: null pointer");
+  IEEE_REQUIRE(Cpad >= C, "nchw_to_nhwc3: Cpad < C");
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(ew_blocks2(B * C * H * W), 3);
-  DISPATCH_T(dtype, (nchw_to_nhwc_kernel<float><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (float*)out, (int)B, (int)C, (int)(H * W))),
-             (nchw_to_nhwc_kernel<bf16><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (bf16*)out, (int)B, (int)C, (int)(H * W))));
+  dim3 grid(ew_blocks2(B * Cpad * H * W), 3);
+  DISPATCH_T(dtype, (nchw_to_nhwc_kernel<float><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (float*)out, (int)B, (int)C, (int)(H * W), (int)Cpad)),
+             (nchw_to_nhwc_kernel<bf16><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (bf16*)out, (int)B, (int)C, (int)(H * W), (int)Cpad)));
   return launch_status("nchw_to_nhwc_kernel");
 }
 

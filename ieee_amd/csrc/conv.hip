@@ -10,6 +10,10 @@
 
 namespace ieee {
 
+// LDS-DMA staging (gemm_nt_dma / gemm_tn_dma) measured equal to register staging on isolated launches and
+// ~8 % slower inside the full step (profiles/r01 notes); kept selectable for the next tuning round.
+constexpr bool kUseDma = false;
+
 __device__ __forceinline__ void tile_map_xy(int tiles_m, int tiles_n, int group, int& tm, int& tn) {
   const int nwg = tiles_m * tiles_n;
   const int bid = blockIdx.x;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ 
   dst += z * a.dst_gs;
   if (addend != nullptr) addend += z * a.dst_gs;
   StoreEpi<T> epi{dst, addend, a.N, a.M, a.N};
-  if constexpr (!SLOW && sizeof(T) == 2) {   // bf16 fast path: both operands through LDS-DMA
+  if constexpr (kUseDma && !SLOW && sizeof(T) == 2) {   // bf16 fast path: both operands through LDS-DMA
     const int ch = nt_dma_chunk(threadIdx.x);
     LoaderPlainNT<T, BN / 32> lbd;
     lbd.init(w, a.ldw, n0, a.N, a.ldw, ch);
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ d
   const int kbeg = ks * a.kchunk, kend = min(a.npix, kbeg + a.kchunk);
   const int ktiles = (kend - kbeg + ImgTN<T>::BK - 1) / ImgTN<T>::BK;
   SlabEpi epi{slab, a.ncols, a.Co, a.ncols};
-  if constexpr (!SLOW && sizeof(T) == 2) {
+  if constexpr (kUseDma && !SLOW && sizeof(T) == 2) {
     const int ch = tn_dma_chunk(threadIdx.x);
     LoaderColsTN<T> lad;
     lad.init(dy, a.Co, m0, a.Co, kbeg, kend, ch);
@@ -184,9 +188,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // Weight packing from the reference's fp32 OIHW parameters:
 //  mode 0 (forward): dst[co][(r*S+s)*Ci + ci]  row length ld (zero padded)
 //  mode 1 (dgrad)  : dst[ci][(r*S+s)*Co + co]  row length ld
+// (Ci, S) are the packed dims; the fp32 source is OIHW [Co][Ci_src][R][S_src] with Ci_src <= Ci, S_src <= S
+// (zero fill beyond: the channel / column padded stem)
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Co, int Ci, int R, int S,
-                                   int ld, int mode, int64_t w_gs, int64_t dst_gs) {
+                                   int ld, int mode, int64_t w_gs, int64_t dst_gs, int Ci_src, int S_src) {
   const int z = blockIdx.y;
   const int rows = mode == 0 ? Co : Ci;
   const int64_t total = (int64_t)rows * ld;
@@ -198,9 +204,64 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   if (col < R * S * inner) {
     const int tap = col / inner, c = col % inner;
     const int co = mode == 0 ? row : c, ci = mode == 0 ? c : row;
-    v = w[z * w_gs + ((int64_t)co * Ci + ci) * (R * S) + tap];
+    const int rr = tap / S, ss = tap % S;
+    if (ci < Ci_src && ss < S_src) v = w[z * w_gs + (((int64_t)co * Ci_src + ci) * R + rr) * S_src + ss];
   }
   dst[z * dst_gs + i] = from_f32<T>(v);
+}
+
+// dw_real[co][ci][r][s] (Ci_src x S_src) = dw_padded[co][ci][r][s] (Ci x S): drop the padded entries
+__global__ void unpad_weight_grad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int R,
+                                         int S, int Ci_src, int S_src, int64_t dwp_gs, int64_t dw_gs, int accumulate) {
+  const int z = blockIdx.y;
+  const int64_t total = (int64_t)Co * Ci_src * R * S_src;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ss = (int)(i % S_src);
+  int64_t t = i / S_src;
+  const int rr = (int)(t % R); t /= R;
+  const int ci = (int)(t % Ci_src);
+  const int co = (int)(t / Ci_src);
+  const float v = dwp[z * dwp_gs + (((int64_t)co * Ci + ci) * R + rr) * S + ss];
+  float* o = dw + z * dw_gs + i;
+  *o = accumulate ? *o + v : v;
+}
+
+// One launch packs every conv weight of the network: blockIdx.x walks a device-side descriptor table
+// (prefix sums of 256-thread blocks), blockIdx.y = modality.
+struct PackDesc {
+  int64_t src_off, src_gs;   // elements, relative to the flat fp32 parameter buffer
+  int64_t dst_off, dst_gs;   // elements of T, relative to the workspace base given to the kernel
+  int Co, Ci, R, S, ld, mode, Ci_src, S_src;
+  int block_begin;           // first blockIdx.x of this descriptor
+  int pad_;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__ params, char* __restrict__ ws,
+                                                       const PackDesc* __restrict__ descs, int ndesc) {
+  int lo = 0, hi = ndesc - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block_begin <= b) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  const int z = blockIdx.y;
+  const int rows = d.mode == 0 ? d.Co : d.Ci;
+  const int64_t total = (int64_t)rows * d.ld;
+  const int64_t i = (int64_t)(b - d.block_begin) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int row = (int)(i / d.ld), col = (int)(i % d.ld);
+  const int inner = d.mode == 0 ? d.Ci : d.Co;
+  float v = 0.f;
+  if (col < d.R * d.S * inner) {
+    const int tap = col / inner, c = col % inner;
+    const int co = d.mode == 0 ? row : c, ci = d.mode == 0 ? c : row;
+    const int rr = tap / d.S, ss = tap % d.S;
+    if (ci < d.Ci_src && ss < d.S_src)
+      v = params[d.src_off + z * d.src_gs + (((int64_t)co * d.Ci_src + ci) * d.R + rr) * d.S_src + ss];
+  }
+  ((T*)ws)[d.dst_off + z * d.dst_gs + i] = from_f32<T>(v);
 }
 
 template <typename T> static int conv_bk() { return ImgNT<T>::BK; }
@@ -223,7 +284,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   const bool narrow = N <= 64;
   a.tiles_n = cdiv(N, narrow ? 64 : 128);
   dim3 grid(a.tiles_m * a.tiles_n, groups);
-  const bool dma = !slow && sizeof(T) == 2;                        // bf16 fast path: DMA_STAGES-deep LDS ring
+  const bool dma = kUseDma && !slow && sizeof(T) == 2;             // bf16 fast path: DMA_STAGES-deep LDS ring
   const int stages = dma ? DMA_STAGES : 2;
   const size_t smem = (size_t)stages * (128 + (narrow ? 64 : 128)) * 128;
   static bool attr_done = false;
@@ -273,6 +334,53 @@ extern "C" int64_t ieee_conv_packed_ld(int dtype, int64_t inner_channels, int64_
   return (K + bk - 1) / bk * bk;
 }
 
+extern "C" int ieee_pack_conv_weight_padded(const float* w_oihw, void* dst, int dtype, int mode, int64_t groups,
+                                            int64_t Co, int64_t Ci_src, int64_t R, int64_t S_src, int64_t Ci,
+                                            int64_t S, int64_t w_gs, int64_t dst_gs, void* stream) {
+  IEEE_REQUIRE(w_oihw && dst, "pack_conv_weight_padded: null pointer");
+  IEEE_REQUIRE(mode == 0, "pack_conv_weight_padded: forward packing only (the padded stem has no dgrad)");
+  IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "pack_conv_weight_padded: bad dtype");
+  IEEE_REQUIRE(Ci_src <= Ci && S_src <= S, "pack_conv_weight_padded: source larger than destination");
+  const int64_t ld = ieee_conv_packed_ld(dtype, Ci, R, S);
+  dim3 grid(cdiv(Co * ld, 256), (unsigned)groups);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IEEE_F32)
+    pack_weight_kernel<float><<<grid, 256, 0, st>>>(w_oihw, (float*)dst, (int)Co, (int)Ci, (int)R, (int)S, (int)ld, 0,
+                                                    w_gs, dst_gs, (int)Ci_src, (int)S_src);
+  else
+    pack_weight_kernel<bf16><<<grid, 256, 0, st>>>(w_oihw, (bf16*)dst, (int)Co, (int)Ci, (int)R, (int)S, (int)ld, 0,
+                                                   w_gs, dst_gs, (int)Ci_src, (int)S_src);
+  return launch_status("pack_weight_kernel");
+}
+
+extern "C" int64_t ieee_pack_desc_bytes(void) { return (int64_t)sizeof(ieee::PackDesc); }
+
+/* descs: device array of `ndesc` descriptors (layout: struct PackDesc above, filled by the executor);
+ * total_blocks = sum of 256-thread blocks over all descriptors */
+extern "C" int ieee_pack_all_weights(const float* params, void* ws_base, const void* descs, int64_t ndesc,
+                                     int64_t total_blocks, int dtype, void* stream) {
+  IEEE_REQUIRE(params && ws_base && descs && ndesc > 0 && total_blocks > 0, "pack_all_weights: bad arguments");
+  dim3 grid((unsigned)total_blocks, 3);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == IEEE_F32)
+    pack_all_kernel<float><<<grid, 256, 0, st>>>(params, (char*)ws_base, (const PackDesc*)descs, (int)ndesc);
+  else if (dtype == IEEE_BF16)
+    pack_all_kernel<bf16><<<grid, 256, 0, st>>>(params, (char*)ws_base, (const PackDesc*)descs, (int)ndesc);
+  else
+    IEEE_REQUIRE(false, "pack_all_weights: bad dtype");
+  return launch_status("pack_all_kernel");
+}
+
+extern "C" int ieee_unpad_weight_grad(const float* dw_padded, float* dw, int64_t groups, int64_t Co, int64_t Ci,
+                                      int64_t R, int64_t S, int64_t Ci_src, int64_t S_src, int64_t dwp_gs,
+                                      int64_t dw_gs, int accumulate, void* stream) {
+  IEEE_REQUIRE(dw_padded && dw, "unpad_weight_grad: null pointer");
+  dim3 grid(cdiv(Co * Ci_src * R * S_src, 256), (unsigned)groups);
+  unpad_weight_grad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(dw_padded, dw, (int)Co, (int)Ci, (int)R, (int)S,
+                                                                  (int)Ci_src, (int)S_src, dwp_gs, dw_gs, accumulate);
+  return launch_status("unpad_weight_grad_kernel");
+}
+
 extern "C" int ieee_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int mode, int64_t groups, int64_t Co,
                                      int64_t Ci, int64_t R, int64_t S, int64_t w_gs, int64_t dst_gs, void* stream) {
   IEEE_REQUIRE(w_oihw && dst, "pack_conv_weight: null pointer");
@@ -284,10 +392,10 @@ extern "C" int ieee_pack_conv_weight(const float* w_oihw, void* dst, int dtype, 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IEEE_F32)
     pack_weight_kernel<float><<<grid, 256, 0, st>>>(w_oihw, (float*)dst, (int)Co, (int)Ci, (int)R, (int)S, (int)ld,
-                                                    mode, w_gs, dst_gs);
+                                                    mode, w_gs, dst_gs, (int)Ci, (int)S);
   else
     pack_weight_kernel<bf16><<<grid, 256, 0, st>>>(w_oihw, (bf16*)dst, (int)Co, (int)Ci, (int)R, (int)S, (int)ld, mode,
-                                                   w_gs, dst_gs);
+                                                   w_gs, dst_gs, (int)Ci, (int)S);
   return launch_status("pack_weight_kernel");
 }
 
@@ -299,7 +407,9 @@ extern "C" int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int
   IEEE_TRY(check_dims("conv2d_fwd", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
   IEEE_REQUIRE(Co % 4 == 0, "conv2d_fwd: Cout %ld must be a multiple of 4", (long)Co);
   GatherGeom g{d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.R, d.S, d.stride, -d.pad, +1, 1, d.N * d.Ho * d.Wo};
-  const bool slow = (Ci % elem_bk(dtype)) != 0;
+  const int bk = elem_bk(dtype);
+  const bool fast = (Ci % bk == 0) || (Ci < bk && Ci % elem_vec(dtype) == 0 && bk % Ci == 0 && S % (bk / Ci) == 0);
+  const bool slow = !fast;
   const int ldw = (int)ieee_conv_packed_ld(dtype, Ci, R, S);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IEEE_F32)
@@ -337,7 +447,7 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
 static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups, int dtype) {
   const int64_t tiles = ((Co + 127) / 128) * ((ncols + 127) / 128) * groups;
   const int64_t bk = elem_bk(dtype);
-  int64_t want = (1536 + tiles - 1) / tiles;                 // aim at >= ~1536 workgroups
+  int64_t want = (1024 + tiles - 1) / tiles;                 // aim at ~1024 workgroups (2 resident per CU x 2 rounds)
   const int64_t maxsplit = (npix + 4 * bk - 1) / (4 * bk);   // at least 4 k-tiles per split
   if (want > maxsplit) want = maxsplit;
   if (want < 1) want = 1;
@@ -374,7 +484,7 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   a.slab_gs = (int64_t)nsplit * d.Co * a.ncols;
   const bool slow = (Ci % elem_vec(dtype)) != 0;
   dim3 grid(cdiv(d.Co, 128) * a.tiles_n, nsplit, (unsigned)groups);
-  const size_t smem = (dtype == IEEE_BF16 && !slow) ? (size_t)DMA_STAGES * 32 * 1024 : 64 * 1024;
+  const size_t smem = (kUseDma && dtype == IEEE_BF16 && !slow) ? (size_t)DMA_STAGES * 32 * 1024 : 64 * 1024;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

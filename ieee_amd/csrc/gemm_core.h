@@ -450,26 +450,33 @@ struct GatherGeom {
   int npix;            // N*Ho*Wo
 };
 
-// Fast path: Cs % BK == 0, so one k-tile stays inside one tap.
+// Fast path: either Cs % BK == 0 (a k-tile stays inside one tap) or BK % Cs == 0 with S % (BK/Cs) == 0
+// (a k-tile covers BK/Cs consecutive horizontal taps of one row: the channel-padded stem, Cs = 8).
 template <typename T, int NCH> struct LoaderIm2colNT {
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int BK = ImgNT<T>::BK;
   const T* p[NCH];
   int hb[NCH], wb[NCH];
   int r, s, ci0;
+  int ds;              // this thread's tap offset inside the k-tile (0 when Cs >= BK)
+  int tpt;             // taps per k-tile
   GatherGeom g;
   __device__ __forceinline__ void init(const T* src, const GatherGeom& g_, int m0, int chunk = -1) {
     g = g_;
     const int t = threadIdx.x;
     const int hw = g.Ho * g.Wo;
     const int ch = chunk < 0 ? (t & 7) : chunk;
+    int coff = ch * VEC;
+    ds = 0;
+    tpt = 1;
+    if (g.Cs < BK) { tpt = BK / g.Cs; ds = coff / g.Cs; coff -= ds * g.Cs; }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int m = m0 + (t >> 3) + 32 * i;
       if (m < g.npix) {
         const int n = m / hw, rem = m - n * hw;
         const int pp = rem / g.Wo, qq = rem - pp * g.Wo;
-        p[i] = src + (int64_t)n * g.Hs * g.Ws * g.Cs + ch * VEC;
+        p[i] = src + (int64_t)n * g.Hs * g.Ws * g.Cs + coff;
         hb[i] = pp * g.mul + g.off;
         wb[i] = qq * g.mul + g.off;
       } else {
@@ -478,19 +485,9 @@ template <typename T, int NCH> struct LoaderIm2colNT {
     }
     r = 0; s = 0; ci0 = 0;
   }
-  __device__ __forceinline__ uint4 load(int i) const {
-    if (p[i] == nullptr || r >= g.R) return make_uint4(0, 0, 0, 0);
-    int h = hb[i] + g.sgn * r, w = wb[i] + g.sgn * s;
-    if (g.div == 2) {
-      if ((h | w) & 1) return make_uint4(0, 0, 0, 0);
-      h >>= 1; w >>= 1;
-    }
-    if ((unsigned)h >= (unsigned)g.Hs || (unsigned)w >= (unsigned)g.Ws) return make_uint4(0, 0, 0, 0);
-    return *(const uint4*)(p[i] + ((int64_t)h * g.Ws + w) * g.Cs + ci0);
-  }
   __device__ __forceinline__ const void* addr(int i) const {
     if (p[i] == nullptr || r >= g.R) return zero_page();
-    int h = hb[i] + g.sgn * r, w = wb[i] + g.sgn * s;
+    int h = hb[i] + g.sgn * r, w = wb[i] + g.sgn * (s + ds);
     if (g.div == 2) {
       if ((h | w) & 1) return zero_page();
       h >>= 1; w >>= 1;
@@ -498,9 +495,18 @@ template <typename T, int NCH> struct LoaderIm2colNT {
     if ((unsigned)h >= (unsigned)g.Hs || (unsigned)w >= (unsigned)g.Ws) return zero_page();
     return (const void*)(p[i] + ((int64_t)h * g.Ws + w) * g.Cs + ci0);
   }
+  __device__ __forceinline__ uint4 load(int i) const {
+    const void* a = addr(i);
+    return a == zero_page() ? make_uint4(0, 0, 0, 0) : *(const uint4*)a;
+  }
   __device__ __forceinline__ void next() {
-    ci0 += BK;
-    if (ci0 >= g.Cs) { ci0 = 0; if (++s == g.S) { s = 0; ++r; } }
+    if (g.Cs < BK) {
+      s += tpt;
+      if (s >= g.S) { s = 0; ++r; }
+    } else {
+      ci0 += BK;
+      if (ci0 >= g.Cs) { ci0 = 0; if (++s == g.S) { s = 0; ++r; } }
+    }
   }
 };
 

@@ -26,11 +26,22 @@ struct Tensor {
 struct ConvUnit {
   std::string name;
   int Ci, Co, R, stride, pad, Hi, Wi, Ho, Wo;
+  int S = 0;                       // kernel width (== R except for the column-padded stem)
+  int Ci_src = 0, S_src = 0;       // dims of the reference parameter when the unit runs zero-padded
   int s_w, s_g, s_b, s_rm, s_rv;   // slot ids of modality 0 (modality m = id + m)
-  Tensor y, a, stats, wf, wd;
+  Tensor y, a, stats, wf, wd, dwpad;
   bool need_dgrad = true;
   int64_t M(int B) const { return (int64_t)B * Ho * Wo; }
 };
+
+// must match struct PackDesc in conv.hip
+struct PackDescHost {
+  int64_t src_off, src_gs, dst_off, dst_gs;
+  int Co, Ci, R, S, ld, mode, Ci_src, S_src;
+  int block_begin, pad_;
+};
+extern "C" int ieee_pack_all_weights(const float* params, void* ws_base, const void* descs, int64_t ndesc,
+                                     int64_t total_blocks, int dtype, void* stream);
 
 struct Block {
   int c1, c2, c3, ds;   // unit indices (ds = -1 when there is no downsample branch)
@@ -56,7 +67,10 @@ struct Net {
   // workspace
   size_t ws_bytes = 0;
   std::map<std::string, Tensor> tensors;
-  Tensor x0, pool, pool_arg, S, gbuf[5], slab, bnpart, bncoef;
+  Tensor x0, pool, pool_arg, S, gbuf[5], slab, bnpart, bncoef, packtab;
+  std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
+  int pack_blocks_train = 0, pack_blocks_eval = 0;
+  const void* pack_uploaded_ws = nullptr;
   Tensor Gp, avgmax, amax, Hh, Hs, att, Pp, Zg, Zp, glob, part, sv_g, sv_p, rr, part2, fcraw, sv_fc, featcat, fcall,
       logits, featn, norms;
   Tensor dfeatcat, dfcraw, dpart2, dr, dglob, dZp, dZg, dPp, dGp, datt, dHs, dH, davgmax, remwork;
@@ -101,7 +115,8 @@ struct Net {
                int Wi) {
     ConvUnit u;
     u.name = conv;
-    u.Ci = Ci; u.Co = Co; u.R = R; u.stride = stride; u.pad = pad; u.Hi = Hi; u.Wi = Wi;
+    u.Ci = Ci; u.Co = Co; u.R = R; u.S = R; u.Ci_src = Ci; u.S_src = R;
+    u.stride = stride; u.pad = pad; u.Hi = Hi; u.Wi = Wi;
     u.Ho = (Hi + 2 * pad - R) / stride + 1;
     u.Wo = (Wi + 2 * pad - R) / stride + 1;
     u.s_w = slot3(conv + ".weight");
@@ -120,6 +135,10 @@ void Net::build() {
   const std::string bb = "backbone.{m}.";
   u_stem = add_unit(bb + "conv1", bb + "bn1", 3, 64, 7, 2, 3, H, W);
   units[u_stem].need_dgrad = false;
+  // the stem runs as a 7x8 conv over 8 (zero-padded) channels: one k-tile = 8 contiguous NHWC pixels of one
+  // input row, so it takes the vectorised / LDS-DMA path instead of a 3-channel element-wise gather
+  units[u_stem].Ci = 8;
+  units[u_stem].S = 8;
   int h = units[u_stem].Ho, w = units[u_stem].Wo;
   h = (h + 2 - 3) / 2 + 1;   // maxpool 3x3 s2 p1
   w = (w + 2 - 3) / 2 + 1;
@@ -181,7 +200,7 @@ extern "C" int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C);
 void Net::plan() {
   ws_bytes = 0;
   const int dt = dtype;
-  x0 = alloc("x0", (int64_t)3 * B * H * W * 3, dt);
+  x0 = alloc("x0", (int64_t)3 * B * H * W * 8, dt);
   int64_t max_act = 0, max_slab = 0, max_part = 0, max_c = 0;
   for (size_t i = 0; i < units.size(); ++i) {
     ConvUnit& u = units[i];
@@ -189,11 +208,12 @@ void Net::plan() {
     u.y = alloc(u.name + ".y", n, dt);
     u.a = alloc(u.name + ".a", n, dt);
     u.stats = alloc(u.name + ".stats", (int64_t)3 * 4 * u.Co, IEEE_F32);
-    u.wf = alloc("", 3 * u.Co * ieee_conv_packed_ld(dt, u.Ci, u.R, u.R), dt);
-    if (u.need_dgrad) u.wd = alloc("", 3 * u.Ci * ieee_conv_packed_ld(dt, u.Co, u.R, u.R), dt);
+    u.wf = alloc("", 3 * u.Co * ieee_conv_packed_ld(dt, u.Ci, u.R, u.S), dt);
+    if (u.need_dgrad) u.wd = alloc("", 3 * u.Ci * ieee_conv_packed_ld(dt, u.Co, u.R, u.S), dt);
+    if (u.Ci != u.Ci_src || u.S != u.S_src) u.dwpad = alloc("", (int64_t)3 * u.Co * u.Ci * u.R * u.S, IEEE_F32);
     max_act = std::max(max_act, n);
-    max_act = std::max(max_act, (int64_t)3 * B * u.Hi * u.Wi * u.Ci);
-    max_slab = std::max(max_slab, ieee_conv2d_wgrad_workspace_bytes(dt, 3, B, u.Ho, u.Wo, u.Ci, u.Co, u.R, u.R));
+    if (u.need_dgrad) max_act = std::max(max_act, (int64_t)3 * B * u.Hi * u.Wi * u.Ci);
+    max_slab = std::max(max_slab, ieee_conv2d_wgrad_workspace_bytes(dt, 3, B, u.Ho, u.Wo, u.Ci, u.Co, u.R, u.S));
     max_part = std::max(max_part, 3 * ieee_bn_partial_floats(dt, u.M(B), u.Co));
     max_c = std::max(max_c, (int64_t)u.Co);
   }
@@ -245,6 +265,7 @@ void Net::plan() {
   dH = alloc("dH", 3 * 2 * Bq * hid, IEEE_F32);
   davgmax = alloc("davgmax", 3 * 2 * Bq * fdim, IEEE_F32);
   remwork = alloc("", 3 * Bq + 64, IEEE_F32);
+  packtab = alloc("", (int64_t)(2 * 2 * units.size() + 8) * sizeof(PackDescHost) / 4, IEEE_F32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -262,11 +283,16 @@ struct Run {
   int64_t gs(int slot) const { return n.slot_off[slot + 1] - n.slot_off[slot]; }
 
   int pack(const ConvUnit& u, bool with_dgrad) {
-    const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.R);
-    IEEE_TRY(ieee_pack_conv_weight(par(u.s_w), P(u.wf), n.dtype, 0, 3, u.Co, u.Ci, u.R, u.R, gs(u.s_w), u.Co * ldf, st));
+    const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
+    if (u.Ci != u.Ci_src || u.S != u.S_src) {
+      IEEE_TRY(ieee_pack_conv_weight_padded(par(u.s_w), P(u.wf), n.dtype, 0, 3, u.Co, u.Ci_src, u.R, u.S_src, u.Ci, u.S,
+                                            gs(u.s_w), u.Co * ldf, st));
+      return IEEE_OK;
+    }
+    IEEE_TRY(ieee_pack_conv_weight(par(u.s_w), P(u.wf), n.dtype, 0, 3, u.Co, u.Ci, u.R, u.S, gs(u.s_w), u.Co * ldf, st));
     if (with_dgrad && u.need_dgrad) {
-      const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.R);
-      IEEE_TRY(ieee_pack_conv_weight(par(u.s_w), P(u.wd), n.dtype, 1, 3, u.Co, u.Ci, u.R, u.R, gs(u.s_w), u.Ci * ldd, st));
+      const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.S);
+      IEEE_TRY(ieee_pack_conv_weight(par(u.s_w), P(u.wd), n.dtype, 1, 3, u.Co, u.Ci, u.R, u.S, gs(u.s_w), u.Ci * ldd, st));
     }
     return IEEE_OK;
   }
@@ -277,10 +303,10 @@ struct Run {
     }
     (void)hipEventRecord(n.ev_pool[n.ev_used], (hipStream_t)st);
     n.ev_cat.push_back(cat);
-    n.ev_name.push_back(u.name + " " + std::to_string(u.Ci) + "->" + std::to_string(u.Co) + " k" + std::to_string(u.R) +
+    n.ev_name.push_back(u.name + " " + std::to_string(u.Ci_src) + "->" + std::to_string(u.Co) + " k" + std::to_string(u.R) +
                         " s" + std::to_string(u.stride) + " " + std::to_string(u.Ho) + "x" + std::to_string(u.Wo));
-    n.ev_flops.push_back(3.0 * 2.0 * (double)u.M(B) * u.Co * u.R * u.R * u.Ci);
-    n.prof_flops[cat] += 3.0 * 2.0 * (double)u.M(B) * u.Co * u.R * u.R * u.Ci;   // algorithmic, 3 modalities
+    n.ev_flops.push_back(3.0 * 2.0 * (double)u.M(B) * u.Co * u.R * u.S_src * u.Ci_src);
+    n.prof_flops[cat] += 3.0 * 2.0 * (double)u.M(B) * u.Co * u.R * u.S_src * u.Ci_src;   // algorithmic, 3 modalities
     n.prof_launches[cat] += 1;
   }
   void prof_end() {
@@ -289,10 +315,10 @@ struct Run {
     n.ev_used += 2;
   }
   int conv(const ConvUnit& u, const void* in) {
-    const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.R);
+    const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
     prof_begin(0, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
-    return ieee_conv2d_fwd(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.R, u.stride, u.pad,
+    return ieee_conv2d_fwd(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
                            (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, st);
   }
   int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training) {
@@ -301,21 +327,28 @@ struct Run {
                          training, relu, st);
   }
   // backward of out = [relu](bn(y) [+res]); dy may alias dout
-  int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout) {
+  int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0) {
     return ieee_bn2d_bwd(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
-                         F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), F(n.bnpart), F(n.bncoef), 0, st);
+                         F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), F(n.bnpart), F(n.bncoef), 0, mask_from_y, st);
   }
   int wgrad(const ConvUnit& u, const void* dy, const void* x) {
     prof_begin(1, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
-    return ieee_conv2d_wgrad(dy, x, grd(u.s_w), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.R, u.stride,
+    if (u.Ci != u.Ci_src || u.S != u.S_src) {   // padded stem: gradient of the padded operand, then drop the padding
+      const int64_t npad = (int64_t)u.Co * u.Ci * u.R * u.S;
+      IEEE_TRY(ieee_conv2d_wgrad(dy, x, F(u.dwpad), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride,
+                                 u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, npad, 0, st));
+      return ieee_unpad_weight_grad(F(u.dwpad), grd(u.s_w), 3, u.Co, u.Ci, u.R, u.S, u.Ci_src, u.S_src, npad, gs(u.s_w), 0,
+                                    st);
+    }
+    return ieee_conv2d_wgrad(dy, x, grd(u.s_w), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride,
                              u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, gs(u.s_w), 0, st);
   }
   int dgrad(const ConvUnit& u, const void* dy, void* dx, const void* addend) {
-    const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.R);
+    const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.S);
     prof_begin(0, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
-    return ieee_conv2d_dgrad(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.R, u.stride, u.pad,
+    return ieee_conv2d_dgrad(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
                              u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, st);
   }
   // grouped fp32 GEMM over the 3 modalities with uniform strides
@@ -333,11 +366,22 @@ struct Run {
 int Run::forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out) {
   Net& N = n;
   const int dt = N.dtype;
-  for (auto& u : N.units) {
-    const bool used = N.interaction || (&u != &N.units[N.u_one] && &u != &N.units[N.u_rest]);
-    if (used) IEEE_TRY(pack(u, training != 0));
+  {   // one launch packs every conv weight (forward operand; + dgrad operand when training)
+    char* tab_dev = ws + N.packtab.off;
+    const size_t bytes_eval = N.pack_eval.size() * sizeof(PackDescHost);
+    if (N.pack_uploaded_ws != (const void*)ws) {
+      IEEE_HIP(hipMemcpyAsync(tab_dev, N.pack_eval.data(), bytes_eval, hipMemcpyHostToDevice, (hipStream_t)st));
+      IEEE_HIP(hipMemcpyAsync(tab_dev + bytes_eval, N.pack_train.data(), N.pack_train.size() * sizeof(PackDescHost),
+                              hipMemcpyHostToDevice, (hipStream_t)st));
+      N.pack_uploaded_ws = ws;
+    }
+    if (training)
+      IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev + bytes_eval, (int64_t)N.pack_train.size(), N.pack_blocks_train,
+                                     dt, st));
+    else
+      IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev, (int64_t)N.pack_eval.size(), N.pack_blocks_eval, dt, st));
   }
-  IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, st));
+  IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, 8, st));
   // stem: conv7x7/2 -> BN -> ReLU -> maxpool3x3/2   (resnet.py:622-626)
   const ConvUnit& s = N.units[N.u_stem];
   IEEE_TRY(conv(s, P(N.x0)));
@@ -593,10 +637,10 @@ int Run::backward(const float* dlogits, const float* dfeats) {
     IEEE_TRY(bn_bwd(c3, X, P(c3.a), X, Q));
     IEEE_TRY(wgrad(c3, X, P(c2.a)));
     IEEE_TRY(dgrad(c3, X, Rb, nullptr));
-    IEEE_TRY(bn_bwd(c2, Rb, P(c2.a), Rb, nullptr));
+    IEEE_TRY(bn_bwd(c2, Rb, nullptr, Rb, nullptr, 1));   // relu mask recomputed from y2 (no residual)
     IEEE_TRY(wgrad(c2, Rb, P(c1.a)));
     IEEE_TRY(dgrad(c2, Rb, U, nullptr));
-    IEEE_TRY(bn_bwd(c1, U, P(c1.a), U, nullptr));
+    IEEE_TRY(bn_bwd(c1, U, nullptr, U, nullptr, 1));
     IEEE_TRY(wgrad(c1, U, xin));
     const void* addend = Q;
     if (b.ds >= 0) {
@@ -611,7 +655,7 @@ int Run::backward(const float* dlogits, const float* dfeats) {
   // stem: maxpool -> ReLU/BN -> conv wgrad (no dgrad: the input is the image)
   const ConvUnit& s = N.units[N.u_stem];
   IEEE_TRY(ieee_maxpool3x3s2_bwd(X, (const uint8_t*)P(N.pool_arg), Q, dt, 3, B, s.Ho, s.Wo, s.Co, st));
-  IEEE_TRY(bn_bwd(s, Q, P(s.a), Q, nullptr));
+  IEEE_TRY(bn_bwd(s, Q, nullptr, Q, nullptr, 1));
   IEEE_TRY(wgrad(s, Q, P(N.x0)));
   return IEEE_OK;
 }
@@ -669,6 +713,36 @@ extern "C" int ieee_net_bind(void* handle, float* params, float* grads, float* b
   n->grads = grads;
   n->buffers = buffers;
   n->bound = true;
+  // descriptor tables for the single-launch weight packing (element offsets; dtype size applied here)
+  const int es = n->esz();
+  for (int training = 0; training < 2; ++training) {
+    std::vector<PackDescHost>& tab = training ? n->pack_train : n->pack_eval;
+    tab.clear();
+    int blocks = 0;
+    for (size_t ui = 0; ui < n->units.size(); ++ui) {
+      const ConvUnit& u = n->units[ui];
+      const bool used = n->interaction || ((int)ui != n->u_one && (int)ui != n->u_rest);
+      if (!used) continue;
+      for (int mode = 0; mode < 2; ++mode) {
+        if (mode == 1 && (!training || !u.need_dgrad)) continue;
+        PackDescHost d;
+        const int64_t ld = ieee_conv_packed_ld(n->dtype, mode == 0 ? u.Ci : u.Co, u.R, u.S);
+        const int rows = mode == 0 ? u.Co : u.Ci;
+        d.src_off = n->slot_off[u.s_w];
+        d.src_gs = n->slot_off[u.s_w + 1] - n->slot_off[u.s_w];
+        d.dst_off = (int64_t)((mode == 0 ? u.wf.off : u.wd.off) / es);
+        d.dst_gs = rows * ld;
+        d.Co = u.Co; d.Ci = u.Ci; d.R = u.R; d.S = u.S; d.ld = (int)ld; d.mode = mode;
+        d.Ci_src = u.Ci_src; d.S_src = u.S_src;
+        d.block_begin = blocks;
+        d.pad_ = 0;
+        blocks += cdiv(rows * ld, 256);
+        tab.push_back(d);
+      }
+    }
+    (training ? n->pack_blocks_train : n->pack_blocks_eval) = blocks;
+  }
+  n->pack_uploaded_ws = nullptr;
   return IEEE_OK;
 }
 

@@ -88,6 +88,21 @@ int64_t ieee_conv_packed_ld(int dtype, int64_t inner_channels, int64_t R, int64_
 int ieee_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int mode, int64_t groups, int64_t Co,
                           int64_t Ci, int64_t R, int64_t S, int64_t w_gs, int64_t dst_gs, void* stream);
 
+/* same, zero-padding the input-channel and kernel-width axes to (Ci, S) >= (Ci_src, S_src); and its inverse
+ * for the weight gradient (dw_padded [Co][Ci][R][S] -> dw [Co][Ci_src][R][S_src]) */
+int ieee_pack_conv_weight_padded(const float* w_oihw, void* dst, int dtype, int mode, int64_t groups, int64_t Co,
+                                 int64_t Ci_src, int64_t R, int64_t S_src, int64_t Ci, int64_t S, int64_t w_gs,
+                                 int64_t dst_gs, void* stream);
+int ieee_unpad_weight_grad(const float* dw_padded, float* dw, int64_t groups, int64_t Co, int64_t Ci, int64_t R,
+                           int64_t S, int64_t Ci_src, int64_t S_src, int64_t dwp_gs, int64_t dw_gs, int accumulate,
+                           void* stream);
+
+/* every conv weight of the network in ONE launch: `descs` is a device array of packing descriptors built by
+ * the executor (ieee_pack_desc_bytes() each); offsets are elements relative to `params` / `ws_base` */
+int64_t ieee_pack_desc_bytes(void);
+int ieee_pack_all_weights(const float* params, void* ws_base, const void* descs, int64_t ndesc,
+                          int64_t total_blocks, int dtype, void* stream);
+
 /* y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w), no bias (every conv on the path is bias-free) */
 int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N,
                     int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride,
@@ -122,19 +137,22 @@ int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int dtype, int
                   int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
                   float* running_mean, float* running_var, int64_t buf_gs, float* stats, float* partial,
                   float momentum, float eps, int training, int relu, void* stream);
-/* backward of out = [relu](bn(y) [+ residual]): g = dout * [out_mask > 0] (out_mask NULL = no ReLU);
+/* backward of out = [relu](bn(y) [+ residual]): g = dout * [out_mask > 0] (out_mask NULL = no ReLU, or,
+ * with mask_from_y = 1, the mask is recomputed as [y*scale+shift > 0], valid when there was no residual);
  * dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); g_out (optional) receives g, which is also
  * the gradient of the residual branch.  dgamma/dbeta fp32 at grad_gs (NULL to skip).
  * coef: scratch groups x [3][C]. */
 int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
                   int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
                   const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, float* partial,
-                  float* coef, int accumulate, void* stream);
+                  float* coef, int accumulate, int mask_from_y, void* stream);
 
 /* ---- stem plumbing ----------------------------------------------------------- */
-/* three fp32 NCHW image tensors (batch dict 'img' = [RGB, NI, TI], dataset.py:338-351) -> [3][B][H][W][C] */
+/* three fp32 NCHW image tensors (batch dict 'img' = [RGB, NI, TI], dataset.py:338-351) -> [3][B][H][W][Cpad]
+ * (channels C..Cpad-1 zero: the stem runs as a 7x8 conv over 8 channels so that one k-tile is 8 contiguous
+ * pixels of one input row) */
 int ieee_nchw_to_nhwc3(const float* x_rgb, const float* x_ni, const float* x_ti, void* out, int dtype,
-                       int64_t B, int64_t C, int64_t H, int64_t W, void* stream);
+                       int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cpad, void* stream);
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:501); argmax holds the window-local index of the first maximum */
 int ieee_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int dtype, int64_t groups, int64_t B,
                           int64_t Hi, int64_t Wi, int64_t C, void* stream);

@@ -81,3 +81,44 @@ def test_conv_exact_integer_data_fp32():
     wp = _ops.pack_conv_weight(w.cuda(), torch.float32, 0)
     y = _ops.conv2d_fwd(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, 128, 3, 3, 1, 1).cpu().permute(0, 3, 1, 2)
     assert torch.equal(y, y_ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_padded_stem_equals_7x7_conv(dtype):
+    """the stem runs as a 7x8 conv over 8 zero-padded channels (one k-tile = 8 contiguous pixels of a row)"""
+    import ctypes
+    from ieee_amd import _lib as L, _ops
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(7)
+    rt = (lambda t: t.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else (lambda t: t)
+    G, N, H, W, Co = 3, 2, 32, 16, 64
+    x = rt(torch.randn(G, N, 3, H, W, generator=g))
+    w = rt(torch.randn(G, Co, 3, 7, 7, generator=g) * 0.1)
+    dy = rt(torch.randn(G, N, Co, H // 2, W // 2, generator=g))
+    refs = [_ref(x[i], w[i], dy[i], 2, 3) for i in range(G)]
+    dt = L.IEEE_BF16 if dtype == torch.bfloat16 else L.IEEE_F32
+    xs = [x[i].contiguous().cuda() for i in range(G)]
+    x8 = torch.empty(G, N, H, W, 8, device="cuda", dtype=dtype)
+    L.check(lib.ieee_nchw_to_nhwc3(L.ptr(xs[0]), L.ptr(xs[1]), L.ptr(xs[2]), L.ptr(x8), dt, N, 3, H, W, 8, L.stream()))
+    assert float(x8[..., 3:].abs().max()) == 0.0
+    ld = lib.ieee_conv_packed_ld(dt, 8, 7, 8)
+    wp = torch.empty(G, Co, ld, device="cuda", dtype=dtype)
+    wd = w.cuda().contiguous()
+    L.check(lib.ieee_pack_conv_weight_padded(L.ptr(wd), L.ptr(wp), dt, 0, G, Co, 3, 7, 7, 8, 8, Co * 3 * 49, Co * ld, L.stream()))
+    y = torch.empty(G, N, H // 2, W // 2, Co, device="cuda", dtype=dtype)
+    L.check(lib.ieee_conv2d_fwd(L.ptr(x8), L.ptr(wp), L.ptr(y), dt, G, N, H, W, 8, Co, 7, 8, 2, 3, N * H * W * 8, Co * ld,
+                                y[0].numel(), L.stream()))
+    tol = dict(rtol=2e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    for i in range(G):
+        torch.testing.assert_close(y[i].float().cpu().permute(0, 3, 1, 2), refs[i][0], **tol)
+    dyd = dy.permute(0, 1, 3, 4, 2).contiguous().cuda().to(dtype)
+    nbytes = lib.ieee_conv2d_wgrad_workspace_bytes(dt, G, N, H // 2, W // 2, 8, Co, 7, 8)
+    work = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dwp = torch.zeros(G, Co, 8, 7, 8, device="cuda")
+    L.check(lib.ieee_conv2d_wgrad(L.ptr(dyd), L.ptr(x8), L.ptr(dwp), L.ptr(work), dt, G, N, H, W, 8, Co, 7, 8, 2, 3,
+                                  dyd[0].numel(), x8[0].numel(), dwp[0].numel(), 0, L.stream()))
+    dw = torch.zeros(G, Co, 3, 7, 7, device="cuda")
+    L.check(lib.ieee_unpad_weight_grad(L.ptr(dwp), L.ptr(dw), G, Co, 8, 7, 8, 3, 7, dwp[0].numel(), dw[0].numel(), 0, L.stream()))
+    wtol = dict(rtol=2e-2, atol=0.5) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-3)
+    for i in range(G):
+        torch.testing.assert_close(dw[i].cpu(), refs[i][2], **wtol)
