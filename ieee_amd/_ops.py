@@ -45,7 +45,7 @@ def conv2d_fwd(x, wp, Co, R, S, stride, pad):
     shape = (G, N, Ho, Wo, Co) if x.dim() == 5 else (N, Ho, Wo, Co)
     y = torch.empty(shape, dtype=x.dtype, device=x.device)
     _lib.check(lib.ieee_conv2d_fwd(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), _dt(x), G, N, H, W, Ci, Co, R, S, stride,
-                                   pad, xgs, wp.stride(0) if wp.dim() == 3 else 0, N * Ho * Wo * Co, _lib.stream()))
+                                   pad, xgs, wp.stride(0) if wp.dim() == 3 else 0, N * Ho * Wo * Co, None, _lib.stream()))
     return y
 
 

@@ -7,7 +7,7 @@
 
 namespace ieee {
 
-constexpr int RED_MAX_BLOCKS = 1536;
+constexpr int RED_MAX_BLOCKS = 768;
 
 struct RedGeom {
   int M, C;        // rows, channels
@@ -295,16 +295,17 @@ extern "C" int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C) {
 extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
                              int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
                              float* running_mean, float* running_var, int64_t buf_gs, float* stats, float* partial,
-                             float momentum, float eps, int training, int relu, void* stream) {
+                             float momentum, float eps, int training, int relu, int64_t stats_rblocks, void* stream) {
   IEEE_REQUIRE(y && gamma && beta && stats, "bn2d_fwd: null pointer");
   IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_fwd: bad dtype");
   IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_fwd: C %ld not a multiple of %d", (long)C, vec_of(dtype));
   IEEE_REQUIRE(training || (running_mean && running_var), "bn2d_fwd: eval mode needs running stats");
   IEEE_REQUIRE(!training || partial, "bn2d_fwd: training needs the partial-sum scratch");
   hipStream_t st = (hipStream_t)stream;
-  const RedGeom g = red_geom(M, (int)C, vec_of(dtype));
+  RedGeom g = red_geom(M, (int)C, vec_of(dtype));
+  if (stats_rblocks > 0) g.rblocks = (int)stats_rblocks;   // partial sums already emitted by the producing conv
   const int64_t partial_gs = (int64_t)g.rblocks * 2 * C;
-  if (training) {
+  if (training && stats_rblocks <= 0) {
     dim3 grid(g.cblocks * g.rblocks, (unsigned)groups);
     if (dtype == IEEE_F32) bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float*)y, act_gs, g, partial, partial_gs);
     else bn_stats_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y, act_gs, g, partial, partial_gs);

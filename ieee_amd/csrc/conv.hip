@@ -29,6 +29,7 @@ __device__ __forceinline__ void tile_map_xy(int tiles_m, int tiles_n, int group,
 
 // C[m][n..n+3] store with optional residual addend (same layout/dtype as the output).
 template <typename T> struct StoreEpi {
+  static constexpr bool kStaged = false;
   T* out;
   const T* addend;
   int64_t ld;
@@ -57,7 +58,93 @@ template <typename T> struct StoreEpi {
   }
 };
 
+// Tile epilogue through LDS: the accumulators (4 consecutive channels of one pixel per lane) are written
+// to an LDS image of the C tile, then every thread stores full 16-byte, row-contiguous chunks (a wave
+// instruction covers 4 rows x 256 B) instead of 8-byte pieces scattered over 16 rows.  Optionally adds a
+// residual tensor and, for a conv that feeds a train-mode BatchNorm, emits the tile's per-channel
+// sum / sum-of-squares (of the ROUNDED stored values) so that no separate statistics pass is needed:
+// bn_partial[group][tile_m][2][N].
+template <typename T, bool STATS> struct StagedStoreEpi {
+  static constexpr bool kStaged = true;
+  T* out;
+  const T* addend;
+  float* bn_partial;   // this group's [tiles_m][2][N] block (STATS only)
+  int64_t ld;
+  int M, N, tile_m;
+  template <int BM, int BN, int FM, int FN>
+  __device__ __forceinline__ void finish(f32x4 (&acc)[FM][FN], char* smem, int m0, int n0) const {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int ROWB = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 16 : 0);   // padded row (bf16); fp32 fills 64 KB
+    constexpr int CPRW = BN / VEC;                                          // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CPRW;                                         // rows per pass of the block
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    __syncthreads();   // every wave is done reading the operand stages
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int r = wm * (BM / 2) + i * 16 + (lane & 15);
+        const int c = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+        char* p = smem + r * ROWB + c * (int)sizeof(T);
+        if constexpr (sizeof(T) == 4) {
+          *(float4*)p = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        } else {
+          *(uint2*)p = make_uint2(Vec16<bf16>::pk(acc[i][j][0], acc[i][j][1]), Vec16<bf16>::pk(acc[i][j][2], acc[i][j][3]));
+        }
+      }
+    __syncthreads();
+    const int ch = t % CPRW, r0 = t / CPRW;
+    const int n = n0 + ch * VEC;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (n < N) {
+#pragma unroll
+      for (int pss = 0; pss < BM / RPP; ++pss) {
+        const int r = r0 + RPP * pss;
+        const int m = m0 + r;
+        if (m >= M) continue;
+        uint4 v = *(const uint4*)(smem + r * ROWB + ch * 16);
+        T* o = out + (int64_t)m * ld + n;
+        if (addend != nullptr || STATS) {
+          float f[VEC];
+          Vec16<T>::unpack(v, f);
+          if (addend != nullptr) {
+            float a[VEC];
+            Vec16<T>::unpack(*(const uint4*)(addend + (int64_t)m * ld + n), a);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] += a[e];
+            v = Vec16<T>::pack(f);
+            if (STATS) Vec16<T>::unpack(v, f);
+          }
+          if (STATS) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+          }
+        }
+        *(uint4*)o = v;
+      }
+    }
+    if constexpr (STATS) {
+      // reduce over the RPP row-lanes that share a chunk, through LDS (the staged tile is consumed)
+      __syncthreads();
+      float* red = (float*)smem;   // [RPP][CPRW][2*VEC]
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { red[(r0 * CPRW + ch) * 2 * VEC + e] = s1[e]; red[(r0 * CPRW + ch) * 2 * VEC + VEC + e] = s2[e]; }
+      __syncthreads();
+      for (int idx = t; idx < BN * 2; idx += 256) {
+        const int q = idx / BN, c = idx % BN;          // quantity, channel within the tile
+        const int cc = c / VEC, e = c % VEC;
+        float s = 0.f;
+        for (int y = 0; y < RPP; ++y) s += red[(y * CPRW + cc) * 2 * VEC + q * VEC + e];
+        if (n0 + c < N) bn_partial[((int64_t)tile_m * 2 + q) * N + n0 + c] = s;
+      }
+    }
+  }
+};
+
 struct SlabEpi {
+  static constexpr bool kStaged = false;
   float* out;
   int64_t ld;
   int M, N;
@@ -81,10 +168,10 @@ struct ConvArgs {
 };
 
 // forward and dgrad share this kernel (they differ only in the gather geometry)
-template <typename T, int BN, bool SLOW>
+template <typename T, int BN, bool SLOW, bool STATS>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
                                                           T* __restrict__ dst, const T* __restrict__ addend,
-                                                          ConvArgs a) {
+                                                          float* __restrict__ bn_partial, ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   tile_map_xy(a.tiles_m, a.tiles_n, 8, tm, tn);
@@ -94,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ 
   w += z * a.w_gs;
   dst += z * a.dst_gs;
   if (addend != nullptr) addend += z * a.dst_gs;
-  StoreEpi<T> epi{dst, addend, a.N, a.M, a.N};
+  StagedStoreEpi<T, STATS> epi{dst, addend, STATS ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm};
   if constexpr (kUseDma && !SLOW && sizeof(T) == 2) {   // bf16 fast path: both operands through LDS-DMA
     const int ch = nt_dma_chunk(threadIdx.x);
     LoaderPlainNT<T, BN / 32> lbd;
@@ -269,7 +356,7 @@ template <typename T> static int conv_bk() { return ImgNT<T>::BK; }
 template <typename T>
 static int launch_gather(const T* src, const T* w, T* dst, const T* addend, const GatherGeom& g, int M, int N,
                          int Ktrue, int ldw, int groups, int64_t src_gs, int64_t w_gs, int64_t dst_gs, bool slow,
-                         hipStream_t st) {
+                         hipStream_t st, float* bn_partial = nullptr) {
   const int BK = ImgNT<T>::BK;
   ConvArgs a;
   a.g = g;
@@ -289,16 +376,21 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   const size_t smem = (size_t)stages * (128 + (narrow ? 64 : 128)) * 128;
   static bool attr_done = false;
   if (!attr_done) {   // > 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
-    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  const bool stats = bn_partial != nullptr;
+  if (stats && (slow || sizeof(T) != 2)) {
+    set_error(IEEE_ERR_UNSUPPORTED, "conv: fused BN statistics need the bf16 vector path");
+    return IEEE_ERR_UNSUPPORTED;
+  }
   if (narrow) {
-    if (slow) conv_gather_kernel<T, 64, true><<<grid, 256, smem, st>>>(src, w, dst, addend, a);
-    else conv_gather_kernel<T, 64, false><<<grid, 256, smem, st>>>(src, w, dst, addend, a);
+    if (slow) conv_gather_kernel<T, 64, true, false><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a);
+    else if (stats) conv_gather_kernel<T, 64, false, true><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a);
+    else conv_gather_kernel<T, 64, false, false><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a);
   } else {
-    if (slow) conv_gather_kernel<T, 128, true><<<grid, 256, smem, st>>>(src, w, dst, addend, a);
-    else conv_gather_kernel<T, 128, false><<<grid, 256, smem, st>>>(src, w, dst, addend, a);
+    if (slow) conv_gather_kernel<T, 128, true, false><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a);
+    else if (stats) conv_gather_kernel<T, 128, false, true><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a);
+    else conv_gather_kernel<T, 128, false, false><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a);
   }
   return launch_status("conv_gather_kernel");
 }
@@ -401,7 +493,7 @@ extern "C" int ieee_pack_conv_weight(const float* w_oihw, void* dst, int dtype, 
 
 extern "C" int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N,
                                int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride,
-                               int64_t pad, int64_t x_gs, int64_t w_gs, int64_t y_gs, void* stream) {
+                               int64_t pad, int64_t x_gs, int64_t w_gs, int64_t y_gs, float* bn_partial, void* stream) {
   IEEE_REQUIRE(x && w_packed && y, "conv2d_fwd: null pointer");
   Dims d;
   IEEE_TRY(check_dims("conv2d_fwd", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
@@ -414,10 +506,10 @@ extern "C" int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IEEE_F32)
     return launch_gather<float>((const float*)x, (const float*)w_packed, (float*)y, nullptr, g, g.npix, d.Co,
-                                d.R * d.S * d.Ci, ldw, (int)groups, x_gs, w_gs, y_gs, slow, st);
+                                d.R * d.S * d.Ci, ldw, (int)groups, x_gs, w_gs, y_gs, slow, st, bn_partial);
   if (dtype == IEEE_BF16)
     return launch_gather<bf16>((const bf16*)x, (const bf16*)w_packed, (bf16*)y, nullptr, g, g.npix, d.Co,
-                               d.R * d.S * d.Ci, ldw, (int)groups, x_gs, w_gs, y_gs, slow, st);
+                               d.R * d.S * d.Ci, ldw, (int)groups, x_gs, w_gs, y_gs, slow, st, bn_partial);
   IEEE_REQUIRE(false, "conv2d_fwd: bad dtype %d", dtype);
 }
 
@@ -454,6 +546,10 @@ static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups,
   if (want > 1024) want = 1024;
   return (int)want;
 }
+
+/* floats of BN partial sums per group that ieee_conv2d_fwd emits when bn_partial != NULL, and the row-block
+ * count to hand to ieee_bn2d_fwd(stats_rblocks) */
+extern "C" int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t Wo) { return (N * Ho * Wo + 127) / 128; }
 
 extern "C" int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, int64_t N, int64_t Ho, int64_t Wo,
                                                      int64_t Ci, int64_t Co, int64_t R, int64_t S) {

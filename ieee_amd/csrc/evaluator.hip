@@ -22,6 +22,7 @@ __device__ __forceinline__ void tile_map(int tiles_m, int tiles_n, int group, in
 }
 
 struct DistEpi {
+  static constexpr bool kStaged = false;
   float* out;
   const float* qn;
   const float* gn;

@@ -170,11 +170,15 @@ __device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, in
     __syncthreads();
   }
 
+  if constexpr (Epi::kStaged) {
+    epi.template finish<BM, BN, FM, FN>(acc, smem, m0, n0);
+  } else {
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
-      epi(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, acc[i][j]);
+      for (int j = 0; j < FN; ++j)
+        epi(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, acc[i][j]);
+  }
 }
 
 // TN core: 128x128 tile only.
@@ -345,11 +349,15 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
     }
   }
 
+  if constexpr (Epi::kStaged) {
+    epi.template finish<BM, BN, FM, FN>(acc, smem, m0, n0);
+  } else {
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
-      epi(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, acc[i][j]);
+      for (int j = 0; j < FN; ++j)
+        epi(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, acc[i][j]);
+  }
 }
 
 template <int STAGES, class LA, class LB, class Epi>

@@ -196,6 +196,7 @@ extern "C" int64_t ieee_conv_packed_ld(int dtype, int64_t inner_channels, int64_
 extern "C" int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, int64_t N, int64_t Ho, int64_t Wo,
                                                      int64_t Ci, int64_t Co, int64_t R, int64_t S);
 extern "C" int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C);
+extern "C" int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t Wo);
 
 void Net::plan() {
   ws_bytes = 0;
@@ -215,6 +216,7 @@ void Net::plan() {
     if (u.need_dgrad) max_act = std::max(max_act, (int64_t)3 * B * u.Hi * u.Wi * u.Ci);
     max_slab = std::max(max_slab, ieee_conv2d_wgrad_workspace_bytes(dt, 3, B, u.Ho, u.Wo, u.Ci, u.Co, u.R, u.S));
     max_part = std::max(max_part, 3 * ieee_bn_partial_floats(dt, u.M(B), u.Co));
+    max_part = std::max(max_part, 3 * ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) * 2 * u.Co);
     max_c = std::max(max_c, (int64_t)u.Co);
   }
   const ConvUnit& st = units[u_stem];
@@ -314,17 +316,22 @@ struct Run {
     (void)hipEventRecord(n.ev_pool[n.ev_used + 1], (hipStream_t)st);
     n.ev_used += 2;
   }
-  int conv(const ConvUnit& u, const void* in) {
+  // fused_stats: the conv epilogue emits the BN partial sums (bf16 training path) -> bn() skips its stats pass
+  bool fused_stats = false;
+  int conv(const ConvUnit& u, const void* in, bool want_stats = false) {
     const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
+    fused_stats = want_stats && n.dtype == IEEE_BF16;
     prof_begin(0, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_fwd(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
-                           (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, st);
+                           (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, fused_stats ? F(n.bnpart) : nullptr, st);
   }
   int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training) {
+    const int64_t rb = (training && fused_stats) ? ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) : 0;
+    fused_stats = false;
     return ieee_bn2d_fwd(P(u.y), residual, out, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b),
                          gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), F(n.bnpart), n.bn_mom, n.bn_eps,
-                         training, relu, st);
+                         training, relu, rb, st);
   }
   // backward of out = [relu](bn(y) [+res]); dy may alias dout
   int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0) {
@@ -384,24 +391,25 @@ int Run::forward(const float* xr, const float* xn, const float* xt, int training
   IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, 8, st));
   // stem: conv7x7/2 -> BN -> ReLU -> maxpool3x3/2   (resnet.py:622-626)
   const ConvUnit& s = N.units[N.u_stem];
-  IEEE_TRY(conv(s, P(N.x0)));
+  IEEE_TRY(conv(s, P(N.x0), training != 0));
   IEEE_TRY(bn(s, nullptr, P(s.a), 1, training));
   IEEE_TRY(ieee_maxpool3x3s2_fwd(P(s.a), P(N.pool), (uint8_t*)P(N.pool_arg), dt, 3, B, s.Ho, s.Wo, s.Co, st));
   const void* x = P(N.pool);
   for (const Block& b : N.blocks) {   // Bottleneck.forward, resnet.py:164-184
     const ConvUnit &c1 = N.units[b.c1], &c2 = N.units[b.c2], &c3 = N.units[b.c3];
-    IEEE_TRY(conv(c1, x));
+    const bool ws_ = training != 0;
+    IEEE_TRY(conv(c1, x, ws_));
     IEEE_TRY(bn(c1, nullptr, P(c1.a), 1, training));
-    IEEE_TRY(conv(c2, P(c1.a)));
+    IEEE_TRY(conv(c2, P(c1.a), ws_));
     IEEE_TRY(bn(c2, nullptr, P(c2.a), 1, training));
-    IEEE_TRY(conv(c3, P(c2.a)));
     const void* identity = x;
-    if (b.ds >= 0) {
+    if (b.ds >= 0) {   // downsample branch first: its conv+BN pair must not sit between conv3 and bn3 (shared scratch)
       const ConvUnit& d = N.units[b.ds];
-      IEEE_TRY(conv(d, x));
+      IEEE_TRY(conv(d, x, ws_));
       IEEE_TRY(bn(d, nullptr, P(d.a), 0, training));
       identity = P(d.a);
     }
+    IEEE_TRY(conv(c3, P(c2.a), ws_));
     IEEE_TRY(bn(c3, identity, P(c3.a), 1, training));
     x = P(c3.a);
   }
@@ -413,14 +421,10 @@ int Run::forward(const float* xr, const float* xn, const float* xt, int training
   IEEE_TRY(ieee_gpool_sum_others(Fm, N.interaction ? P(N.S) : nullptr, F(N.Gp), dt, B, Hh_, Ww, C, st));
   const int mode = !N.interaction ? 2 : (N.attention ? 0 : 1);
   if (N.interaction) {
-    IEEE_TRY(conv(uo, Fm));
-    IEEE_TRY(ieee_bn2d_fwd(P(uo.y), nullptr, nullptr, dt, 3, uo.M(B), C, uo.M(B) * C, par(uo.s_g), par(uo.s_b), gs(uo.s_g),
-                           buf(uo.s_rm), buf(uo.s_rv), gs(uo.s_rm), F(uo.stats), F(N.bnpart), N.bn_mom, N.bn_eps, training,
-                           1, st));
-    IEEE_TRY(conv(ur, P(N.S)));
-    IEEE_TRY(ieee_bn2d_fwd(P(ur.y), nullptr, nullptr, dt, 3, ur.M(B), C, ur.M(B) * C, par(ur.s_g), par(ur.s_b), gs(ur.s_g),
-                           buf(ur.s_rm), buf(ur.s_rv), gs(ur.s_rm), F(ur.stats), F(N.bnpart), N.bn_mom, N.bn_eps, training,
-                           1, st));
+    IEEE_TRY(conv(uo, Fm, training != 0));
+    IEEE_TRY(bn(uo, nullptr, nullptr, 1, training));    // statistics only: the CIM tail applies scale/shift itself
+    IEEE_TRY(conv(ur, P(N.S), training != 0));
+    IEEE_TRY(bn(ur, nullptr, nullptr, 1, training));
     if (N.attention) {   // ChannelAttention.forward :277-282
       IEEE_TRY(ieee_ca_pool(P(ur.y), F(ur.stats), F(N.avgmax), F(N.avgmax) + BC, 2 * BC, (int32_t*)P(N.amax), dt, B, Hh_,
                             Ww, C, st));

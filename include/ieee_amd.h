@@ -106,7 +106,11 @@ int ieee_pack_all_weights(const float* params, void* ws_base, const void* descs,
 /* y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w), no bias (every conv on the path is bias-free) */
 int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N,
                     int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride,
-                    int64_t pad, int64_t x_gs, int64_t w_gs, int64_t y_gs, void* stream);
+                    int64_t pad, int64_t x_gs, int64_t w_gs, int64_t y_gs, float* bn_partial, void* stream);
+/* bn_partial (bf16 vector path only, else NULL): the conv also emits, per group, [rblocks][2][Co] per-channel
+ * sum / sum-of-squares of the stored outputs, rblocks = ieee_conv2d_fwd_stats_rblocks(); hand the same buffer
+ * and rblocks to ieee_bn2d_fwd(stats_rblocks) and the separate statistics pass disappears */
+int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t Wo);
 
 /* dx[N,Hi,Wi,Ci] = conv_transpose(dy) (+ addend, same layout as dx, may be NULL): the
  * residual-branch gradient of Bottleneck (resnet.py:181 `out += identity`) is folded in here */
@@ -130,13 +134,14 @@ int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work,
  * unbiased for running_var.  groups x [M][C] activations, stride act_gs;
  * gamma/beta at param_gs, running stats at buf_gs.
  * stats  : out, groups x [4][C] = mean, invstd, scale, shift (kept for backward)
- * partial: scratch of groups * ieee_bn_partial_floats() floats
+ * partial: scratch of groups * ieee_bn_partial_floats() floats; with stats_rblocks > 0 it already holds the
+ *          [stats_rblocks][2][C] sums emitted by ieee_conv2d_fwd and the statistics kernel is skipped
  * out = [relu]( y*scale + shift [+ residual] ); out NULL = statistics only.  training=0 uses running stats. */
 int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C);
 int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
                   int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
                   float* running_mean, float* running_var, int64_t buf_gs, float* stats, float* partial,
-                  float momentum, float eps, int training, int relu, void* stream);
+                  float momentum, float eps, int training, int relu, int64_t stats_rblocks, void* stream);
 /* backward of out = [relu](bn(y) [+ residual]): g = dout * [out_mask > 0] (out_mask NULL = no ReLU, or,
  * with mask_from_y = 1, the mask is recomputed as [y*scale+shift > 0], valid when there was no residual);
  * dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); g_out (optional) receives g, which is also

@@ -107,7 +107,7 @@ def test_padded_stem_equals_7x7_conv(dtype):
     L.check(lib.ieee_pack_conv_weight_padded(L.ptr(wd), L.ptr(wp), dt, 0, G, Co, 3, 7, 7, 8, 8, Co * 3 * 49, Co * ld, L.stream()))
     y = torch.empty(G, N, H // 2, W // 2, Co, device="cuda", dtype=dtype)
     L.check(lib.ieee_conv2d_fwd(L.ptr(x8), L.ptr(wp), L.ptr(y), dt, G, N, H, W, 8, Co, 7, 8, 2, 3, N * H * W * 8, Co * ld,
-                                y[0].numel(), L.stream()))
+                                y[0].numel(), None, L.stream()))
     tol = dict(rtol=2e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
     for i in range(G):
         torch.testing.assert_close(y[i].float().cpu().permute(0, 3, 1, 2), refs[i][0], **tol)

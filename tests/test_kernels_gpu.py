@@ -58,7 +58,7 @@ def test_bn2d_fwd_bwd(dtype, G, M, C, residual, relu):
     npart = lib.ieee_bn_partial_floats(dt, M, C)
     part = torch.empty(G * npart + 64, device=dev)
     L.check(lib.ieee_bn2d_fwd(L.ptr(yd), L.ptr(resd), L.ptr(out), dt, G, M, C, M * C, L.ptr(gd), L.ptr(bd), C,
-                              L.ptr(rmd), L.ptr(rvd), C, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, int(relu), L.stream()))
+                              L.ptr(rmd), L.ptr(rvd), C, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, int(relu), 0, L.stream()))
     tol = dict(rtol=2e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(out.float().cpu(), out_ref.detach(), **tol)
     torch.testing.assert_close(rmd.cpu(), rmr, rtol=1e-4, atol=1e-5)
@@ -155,7 +155,7 @@ def test_cim_tail_chain_fwd_bwd_fp32(mode):
     for y, ga, be, st in ((y1, w["g1"], w["b1"], st1), (y2, w["g2"], w["b2"], st2)):
         gd, bd = ga.detach().to(dev), be.detach().to(dev)
         L.check(lib.ieee_bn2d_fwd(L.ptr(y), None, None, 0, 3, B * P, C, B * P * C, L.ptr(gd), L.ptr(bd), C, None, None, 0,
-                                  L.ptr(st), L.ptr(part), 0.1, 1e-5, 1, 1, L.stream()))
+                                  L.ptr(st), L.ptr(part), 0.1, 1e-5, 1, 1, 0, L.stream()))
     avgmax = torch.empty(3, 2 * B, C, device=dev)
     amax = torch.empty(3, B, C, device=dev, dtype=torch.int32)
     att = torch.zeros(3, B, C, device=dev)
