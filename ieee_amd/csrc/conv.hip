@@ -208,7 +208,7 @@ struct WgradArgs {
   GatherGeom g;       // forward geometry of the conv
   int Co, ncols;      // GEMM M (= Cout), N (= R*S*Cin)
   int npix, kchunk;   // GEMM K (= N*Ho*Wo) and the K range per split
-  int tiles_n;
+  int tiles_n, tiles, nsplit, groups, xcd_group;
   int64_t dy_gs, x_gs, slab_gs;   // per-modality strides; slab_gs covers all splits of one modality
 };
 
@@ -216,8 +216,20 @@ template <typename T, bool SLOW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          float* __restrict__ slab, WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tm = blockIdx.x / a.tiles_n, tn = blockIdx.x % a.tiles_n;
-  const int ks = blockIdx.y, z = blockIdx.z;
+  // XCD-aware order: every tile of one (k-split, modality) reads the same pixel range of dY and X, so all of
+  // them go to ONE XCD (blocks b, b+8, ... share an XCD/L2) and that range is fetched into one L2 only.
+  int kzi, tile;
+  if (a.xcd_group) {
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    kzi = (j / a.tiles) * 8 + xcd;
+    tile = j % a.tiles;
+  } else {   // few (split, modality) groups: grouping them per XCD would unbalance the 8 XCDs
+    kzi = blockIdx.x / a.tiles;
+    tile = blockIdx.x % a.tiles;
+  }
+  if (kzi >= a.nsplit * a.groups) return;
+  const int tm = tile / a.tiles_n, tn = tile % a.tiles_n;
+  const int ks = kzi % a.nsplit, z = kzi / a.nsplit;
   const int m0 = tm * 128, n0 = tn * 128;
   dy += z * a.dy_gs;
   x += z * a.x_gs;
@@ -575,11 +587,16 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   a.kchunk = cdiv(cdiv(a.npix, splitk), bk) * bk;
   const int nsplit = cdiv(a.npix, a.kchunk);
   a.tiles_n = cdiv(a.ncols, 128);
+  a.tiles = cdiv(d.Co, 128) * a.tiles_n;
+  a.nsplit = nsplit;
+  a.groups = (int)groups;
   a.dy_gs = dy_gs;
   a.x_gs = x_gs;
   a.slab_gs = (int64_t)nsplit * d.Co * a.ncols;
   const bool slow = (Ci % elem_vec(dtype)) != 0;
-  dim3 grid(cdiv(d.Co, 128) * a.tiles_n, nsplit, (unsigned)groups);
+  const int nkz = nsplit * (int)groups;
+  a.xcd_group = (nkz >= 24 || nkz % 8 == 0) ? 1 : 0;
+  dim3 grid((unsigned)(a.tiles * (a.xcd_group ? cdiv(nkz, 8) * 8 : nkz)));
   const size_t smem = (kUseDma && dtype == IEEE_BF16 && !slow) ? (size_t)DMA_STAGES * 32 * 1024 : 64 * 1024;
   static bool attr_done = false;
   if (!attr_done) {
