@@ -179,8 +179,15 @@ def main():
     g_ms, g_fl, g_n, w_ms, w_fl, w_n = list(out6)
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    traffic = None      # HBM bytes per launch of this kernel from the committed PMC passes (rocprofv3 --pmc
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # FETCH_SIZE / WRITE_SIZE, FETCH doubled per guide)
+    if args.dtype == "bf16" and B == 64 and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))["conv_gather"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": None, "kernel": "conv_gather_kernel (implicit-GEMM forward + dgrad)",
+                "traffic": traffic, "kernel": "conv_gather_kernel (implicit-GEMM forward + dgrad)",
                 "launches": int(g_n), "avg_launch_us": g_ms * 1e3 / max(g_n, 1),
                 "flops_per_launch": g_fl / max(g_n, 1),
                 "wgrad": {"achieved": (w_fl / (w_ms * 1e-3) / 1e12) if w_ms > 0 else 0.0, "launches": int(w_n),

@@ -19,11 +19,16 @@ def env_world():
 def init_from_env(backend=None):
     """initialise torch.distributed from torchrun's environment; returns (world, rank, local_rank)"""
     world, rank, local = env_world()
+    # test hooks: IEEE_DIST_BACKEND=gloo and IEEE_FORCE_DEVICE=0 let several ranks share one GPU (RCCL refuses
+    # two ranks on one device), which is how the N>1 step is exercised on a 1-GPU box
+    backend = os.environ.get("IEEE_DIST_BACKEND", backend)
+    if "IEEE_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["IEEE_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
