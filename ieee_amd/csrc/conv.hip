@@ -6,6 +6,8 @@
 // launch: blockIdx.y = modality, pointers advance by per-modality strides.
 // Replaces torch's conv2d / conv2d backward as dispatched from the reference's
 // torchreid/models/resnet.py:164-184,622-631 and ieee3modalPart.py:427-435.
+#include <stdlib.h>
+
 #include "gemm_core.h"
 
 namespace ieee {
@@ -164,6 +166,7 @@ struct ConvArgs {
   int M, N;          // GEMM rows (pixels) / cols (output channels of this GEMM)
   int ldw, ktiles;   // packed-weight row length (elements), number of k-tiles
   int tiles_m, tiles_n;
+  int dbg;           // tuning experiments only (IEEE_DBG)
   int64_t src_gs, w_gs, dst_gs;   // per-modality strides (elements)
 };
 
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ 
   } else {
     LoaderIm2colNT<T, 4> la;
     la.init(src, a.g, m0);
-    gemm_nt<T, 128, BN>(la, lb, epi, a.ktiles, m0, n0, smem);
+    gemm_nt<T, 128, BN>(la, lb, epi, a.ktiles, m0, n0, smem, a.dbg & 1);
   }
 }
 
@@ -376,6 +379,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   a.N = N;
   a.ldw = ldw;
   a.ktiles = cdiv(Ktrue, BK);
+  { const char* e = getenv("IEEE_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.src_gs = src_gs;
   a.w_gs = w_gs;
   a.dst_gs = dst_gs;

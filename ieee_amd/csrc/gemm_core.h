@@ -102,6 +102,7 @@ template <> struct ImgTN<float> {
   }
 };
 
+__device__ int g_dbg_nok_dummy;
 // ------------------------------------------------------------------ cores
 // Loader contract:  uint4 load(int slot)  -> 16 bytes of the CURRENT k-tile for
 // this thread's slot (zero-filled when out of range);  void next()  -> advance
@@ -110,7 +111,7 @@ template <> struct ImgTN<float> {
 // Epilogue contract: epi(m, n, f32x4 v): v[r] is C[m][n+r] (global indices).
 
 template <typename T, int BM, int BN, class LA, class LB, class Epi>
-__device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem) {
+__device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem, int g_dbg_nok = 0) {
   typedef ImgNT<T> Img;
   constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;
   constexpr int FM = BM / 32, FN = BN / 32;
@@ -140,8 +141,7 @@ __device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, in
     char* nxt = smem + ((kt + 1) & 1) * STAGE;
     const bool has_next = (kt + 1) < ktiles;
     if (has_next) {
-      la.next();
-      lb.next();
+      if (!g_dbg_nok) { la.next(); lb.next(); }
 #pragma unroll
       for (int i = 0; i < ACH; ++i) ra[i] = la.load(i);
 #pragma unroll
@@ -460,17 +460,27 @@ struct GatherGeom {
 
 // Fast path: either Cs % BK == 0 (a k-tile stays inside one tap) or BK % Cs == 0 with S % (BK/Cs) == 0
 // (a k-tile covers BK/Cs consecutive horizontal taps of one row: the channel-padded stem, Cs = 8).
+// All per-pixel work is done once: each slot keeps a 32-bit element offset of its (un-tapped) source pixel
+// and a bit mask of the taps that fall inside the image; per k-tile the tap contributes one wave-uniform
+// offset, so a load costs a shift/test and one add (the 64-bit multiplies of a per-tile decode used to
+// rival the MFMA time of the tile).  Requires R*S <= 64 and < 2^31 elements per modality tensor.
 template <typename T, int NCH> struct LoaderIm2colNT {
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int BK = ImgNT<T>::BK;
-  const T* p[NCH];
-  int hb[NCH], wb[NCH];
-  int r, s, ci0;
-  int ds;              // this thread's tap offset inside the k-tile (0 when Cs >= BK)
-  int tpt;             // taps per k-tile
+  const T* src;
+  int off[NCH];                 // element offset of pixel (hb, wb) [halved for div 2] + this thread's chunk
+  unsigned long long vm[NCH];   // bit (r*S + s): tap (r, s) is in range (and parity-aligned for div 2)
+  int r, s, ci0, tap;           // current tap (wave-uniform)
+  int toff;                     // wave-uniform element offset of the current tap
+  int ds, tpt;
   GatherGeom g;
-  __device__ __forceinline__ void init(const T* src, const GatherGeom& g_, int m0, int chunk = -1) {
+  __device__ __forceinline__ int tap_off(int rr, int ss) const {
+    const int re = g.div == 2 ? (rr >> 1) : rr, se = g.div == 2 ? (ss >> 1) : ss;
+    return g.sgn * (re * g.Ws + se) * g.Cs;
+  }
+  __device__ __forceinline__ void init(const T* src_, const GatherGeom& g_, int m0, int chunk = -1) {
     g = g_;
+    src = src_;
     const int t = threadIdx.x;
     const int hw = g.Ho * g.Wo;
     const int ch = chunk < 0 ? (t & 7) : chunk;
@@ -481,31 +491,33 @@ template <typename T, int NCH> struct LoaderIm2colNT {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int m = m0 + (t >> 3) + 32 * i;
+      off[i] = 0;
+      vm[i] = 0ull;
       if (m < g.npix) {
         const int n = m / hw, rem = m - n * hw;
         const int pp = rem / g.Wo, qq = rem - pp * g.Wo;
-        p[i] = src + (int64_t)n * g.Hs * g.Ws * g.Cs + coff;
-        hb[i] = pp * g.mul + g.off;
-        wb[i] = qq * g.mul + g.off;
-      } else {
-        p[i] = nullptr; hb[i] = 0; wb[i] = 0;
+        const int hb = pp * g.mul + g.off, wb = qq * g.mul + g.off + g.sgn * ds;
+        const int he = g.div == 2 ? (hb >> 1) : hb, we = g.div == 2 ? (wb >> 1) : wb;
+        off[i] = ((n * g.Hs + he) * g.Ws + we) * g.Cs + coff;
+        for (int rr = 0; rr < g.R; ++rr)
+          for (int ss = 0; ss < g.S; ++ss) {
+            int h = hb + g.sgn * rr, w = wb + g.sgn * ss;
+            bool ok = true;
+            if (g.div == 2) { ok = !((h | w) & 1); h >>= 1; w >>= 1; }
+            ok = ok && (unsigned)h < (unsigned)g.Hs && (unsigned)w < (unsigned)g.Ws;
+            if (ok) vm[i] |= 1ull << (rr * g.S + ss);
+          }
       }
     }
-    r = 0; s = 0; ci0 = 0;
+    r = 0; s = 0; ci0 = 0; tap = 0; toff = 0;
   }
   __device__ __forceinline__ const void* addr(int i) const {
-    if (p[i] == nullptr || r >= g.R) return zero_page();
-    int h = hb[i] + g.sgn * r, w = wb[i] + g.sgn * (s + ds);
-    if (g.div == 2) {
-      if ((h | w) & 1) return zero_page();
-      h >>= 1; w >>= 1;
-    }
-    if ((unsigned)h >= (unsigned)g.Hs || (unsigned)w >= (unsigned)g.Ws) return zero_page();
-    return (const void*)(p[i] + ((int64_t)h * g.Ws + w) * g.Cs + ci0);
+    if (!((vm[i] >> tap) & 1ull)) return zero_page();
+    return (const void*)(src + (off[i] + toff + ci0));
   }
   __device__ __forceinline__ uint4 load(int i) const {
-    const void* a = addr(i);
-    return a == zero_page() ? make_uint4(0, 0, 0, 0) : *(const uint4*)a;
+    if (!((vm[i] >> tap) & 1ull)) return make_uint4(0, 0, 0, 0);
+    return *(const uint4*)(src + (off[i] + toff + ci0));
   }
   __device__ __forceinline__ void next() {
     if (g.Cs < BK) {
@@ -513,8 +525,12 @@ template <typename T, int NCH> struct LoaderIm2colNT {
       if (s >= g.S) { s = 0; ++r; }
     } else {
       ci0 += BK;
-      if (ci0 >= g.Cs) { ci0 = 0; if (++s == g.S) { s = 0; ++r; } }
+      if (ci0 < g.Cs) return;
+      ci0 = 0;
+      if (++s == g.S) { s = 0; ++r; }
     }
+    tap = r < g.R ? r * g.S + s : 63;     // past the last tap: bit 63 is never set (R*S <= 56 on this path)
+    toff = tap_off(r, s);
   }
 };
 
