@@ -662,7 +662,9 @@ template <typename T> struct LoaderIm2colTN {
     }
     const int h = pp * g.mul + g.off + r, w = qq * g.mul + g.off + s;
     if ((unsigned)h >= (unsigned)g.Hs || (unsigned)w >= (unsigned)g.Ws) return zero_page();
-    return (const void*)(src + (((int64_t)n * g.Hs + h) * g.Ws + w) * g.Cs + ci);
+    // 32-bit element offset with 24-bit multiplies (every factor < 2^24; tensors hold < 2^31 elements)
+    const int o = __mul24(__mul24(n, g.Hs) + h, g.Ws) + w;
+    return (const void*)(src + (__mul24(o, g.Cs) + ci));
   }
   __device__ __forceinline__ void next() { k0 += BK; }
 };
