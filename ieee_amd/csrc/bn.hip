@@ -330,15 +330,18 @@ extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int
 extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
                              int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma,
                              int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
-                             float* partial, float* coef, int accumulate, int mask_from_y, void* stream) {
+                             float* partial, float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks,
+                             void* stream) {
   IEEE_REQUIRE(dout && y && dy && gamma && stats && partial && coef, "bn2d_bwd: null pointer");
   IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_bwd: bad dtype");
   IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_bwd: C not a multiple of the vector width");
   hipStream_t st = (hipStream_t)stream;
-  const RedGeom g = red_geom(M, (int)C, vec_of(dtype));
+  RedGeom g = red_geom(M, (int)C, vec_of(dtype));
+  if (stats_rblocks > 0) g.rblocks = (int)stats_rblocks;   // sums already emitted by the producing dgrad
   const int64_t partial_gs = (int64_t)g.rblocks * 2 * C;
   dim3 rgrid(g.cblocks * g.rblocks, (unsigned)groups);
-  if (dtype == IEEE_F32)
+  if (stats_rblocks > 0) {
+  } else if (dtype == IEEE_F32)
     bn_bwd_reduce_kernel<float><<<rgrid, 256, 0, st>>>((const float*)dout, (const float*)out_mask, (const float*)y,
                                                        act_gs, g, partial, partial_gs, stats, 4 * C, mask_from_y);
   else

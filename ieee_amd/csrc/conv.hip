@@ -66,13 +66,19 @@ template <typename T> struct StoreEpi {
 // residual tensor and, for a conv that feeds a train-mode BatchNorm, emits the tile's per-channel
 // sum / sum-of-squares (of the ROUNDED stored values) so that no separate statistics pass is needed:
 // bn_partial[group][tile_m][2][N].
-template <typename T, bool STATS> struct StagedStoreEpi {
+template <typename T, int MODE> struct StagedStoreEpi {
   static constexpr bool kStaged = true;
+  static constexpr bool STATS = MODE != 0;
   T* out;
   const T* addend;
-  float* bn_partial;   // this group's [tiles_m][2][N] block (STATS only)
+  float* bn_partial;   // this group's [tiles_m][2][N] block (MODE 1: sum v, sum v^2; MODE 2: sum g, sum g*y)
   int64_t ld;
   int M, N, tile_m;
+  // MODE 2 (dgrad feeding the BatchNorm backward of the PREVIOUS unit): g = v * [relu mask]; the mask comes from
+  // the stored activation (bmask) or is recomputed from y and that unit's scale/shift (bstats = [4][N])
+  const T* by;
+  const T* bmask;
+  const float* bstats;
   template <int BM, int BN, int FM, int FN>
   __device__ __forceinline__ void finish(f32x4 (&acc)[FM][FN], char* smem, int m0, int n0) const {
     constexpr int VEC = 16 / sizeof(T);
@@ -119,9 +125,23 @@ template <typename T, bool STATS> struct StagedStoreEpi {
             v = Vec16<T>::pack(f);
             if (STATS) Vec16<T>::unpack(v, f);
           }
-          if (STATS) {
+          if constexpr (MODE == 1) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+          } else if constexpr (MODE == 2) {
+            float yv[VEC];
+            Vec16<T>::unpack(*(const uint4*)(by + (int64_t)m * ld + n), yv);
+            if (bmask != nullptr) {
+              float mk[VEC];
+              Vec16<T>::unpack(*(const uint4*)(bmask + (int64_t)m * ld + n), mk);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) f[e] = mk[e] > 0.f ? f[e] : 0.f;
+            } else if (bstats != nullptr) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) f[e] = (yv[e] * bstats[2 * N + n + e] + bstats[3 * N + n + e]) > 0.f ? f[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { s1[e] += f[e]; s2[e] += f[e] * yv[e]; }
           }
         }
         *(uint4*)o = v;
@@ -171,10 +191,17 @@ struct ConvArgs {
 };
 
 // forward and dgrad share this kernel (they differ only in the gather geometry)
-template <typename T, int BN, bool SLOW, bool STATS>
+struct BwdStats {            // MODE 2 operands (per-group strides in elements / floats)
+  const void* y;
+  const void* mask;
+  const float* stats;
+  int64_t act_gs, stats_gs;
+};
+
+template <typename T, int BN, bool SLOW, int MODE>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
                                                           T* __restrict__ dst, const T* __restrict__ addend,
-                                                          float* __restrict__ bn_partial, ConvArgs a) {
+                                                          float* __restrict__ bn_partial, ConvArgs a, BwdStats bs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   tile_map_xy(a.tiles_m, a.tiles_n, 8, tm, tn);
@@ -184,7 +211,10 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ 
   w += z * a.w_gs;
   dst += z * a.dst_gs;
   if (addend != nullptr) addend += z * a.dst_gs;
-  StagedStoreEpi<T, STATS> epi{dst, addend, STATS ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm};
+  StagedStoreEpi<T, MODE> epi{dst, addend, MODE ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm,
+                              MODE == 2 ? (const T*)bs.y + z * bs.act_gs : nullptr,
+                              (MODE == 2 && bs.mask) ? (const T*)bs.mask + z * bs.act_gs : nullptr,
+                              (MODE == 2 && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
   if constexpr (kUseDma && !SLOW && sizeof(T) == 2) {   // bf16 fast path: both operands through LDS-DMA
     const int ch = nt_dma_chunk(threadIdx.x);
     LoaderPlainNT<T, BN / 32> lbd;
@@ -371,7 +401,7 @@ template <typename T> static int conv_bk() { return ImgNT<T>::BK; }
 template <typename T>
 static int launch_gather(const T* src, const T* w, T* dst, const T* addend, const GatherGeom& g, int M, int N,
                          int Ktrue, int ldw, int groups, int64_t src_gs, int64_t w_gs, int64_t dst_gs, bool slow,
-                         hipStream_t st, float* bn_partial = nullptr) {
+                         hipStream_t st, float* bn_partial = nullptr, const BwdStats* bwd = nullptr) {
   const int BK = ImgNT<T>::BK;
   ConvArgs a;
   a.g = g;
@@ -399,14 +429,18 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
     set_error(IEEE_ERR_UNSUPPORTED, "conv: fused BN statistics need the bf16 vector path");
     return IEEE_ERR_UNSUPPORTED;
   }
+  BwdStats bs{nullptr, nullptr, nullptr, 0, 0};
+  if (bwd) bs = *bwd;
   if (narrow) {
-    if (slow) conv_gather_kernel<T, 64, true, false><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a);
-    else if (stats) conv_gather_kernel<T, 64, false, true><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a);
-    else conv_gather_kernel<T, 64, false, false><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a);
+    if (slow) conv_gather_kernel<T, 64, true, 0><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a, bs);
+    else if (stats && bwd) conv_gather_kernel<T, 64, false, 2><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
+    else if (stats) conv_gather_kernel<T, 64, false, 1><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
+    else conv_gather_kernel<T, 64, false, 0><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a, bs);
   } else {
-    if (slow) conv_gather_kernel<T, 128, true, false><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a);
-    else if (stats) conv_gather_kernel<T, 128, false, true><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a);
-    else conv_gather_kernel<T, 128, false, false><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a);
+    if (slow) conv_gather_kernel<T, 128, true, 0><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a, bs);
+    else if (stats && bwd) conv_gather_kernel<T, 128, false, 2><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
+    else if (stats) conv_gather_kernel<T, 128, false, 1><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
+    else conv_gather_kernel<T, 128, false, 0><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a, bs);
   }
   return launch_status("conv_gather_kernel");
 }
@@ -532,8 +566,10 @@ extern "C" int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int
 extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
                                  int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
                                  int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
+                                 float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
                                  void* stream) {
   IEEE_REQUIRE(dy && w_packed_d && dx, "conv2d_dgrad: null pointer");
+  IEEE_REQUIRE(!bn_partial || bn_y, "conv2d_dgrad: fused BN-backward sums need the BN input tensor");
   Dims d;
   IEEE_TRY(check_dims("conv2d_dgrad", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
   IEEE_REQUIRE(Co % elem_bk(dtype) == 0, "conv2d_dgrad: Cout %ld must be a multiple of %d", (long)Co, elem_bk(dtype));
@@ -545,9 +581,12 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
   if (dtype == IEEE_F32)
     return launch_gather<float>((const float*)dy, (const float*)w_packed_d, (float*)dx, (const float*)addend, g,
                                 g.npix, d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st);
-  if (dtype == IEEE_BF16)
+  if (dtype == IEEE_BF16) {
+    BwdStats bs{bn_y, bn_mask, bn_stats, dx_gs, 4 * Ci};
     return launch_gather<bf16>((const bf16*)dy, (const bf16*)w_packed_d, (bf16*)dx, (const bf16*)addend, g, g.npix,
-                               d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st);
+                               d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st, bn_partial,
+                               bn_partial ? &bs : nullptr);
+  }
   IEEE_REQUIRE(false, "conv2d_dgrad: bad dtype %d", dtype);
 }
 

@@ -334,9 +334,12 @@ struct Run {
                          training, relu, rb, st);
   }
   // backward of out = [relu](bn(y) [+res]); dy may alias dout
+  bool fused_bwd = false;   // the last dgrad already emitted the BN-backward sums of the unit bn_bwd() is called for
   int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0) {
+    const int64_t rb = fused_bwd ? (u.M(B) + 127) / 128 : 0;
+    fused_bwd = false;
     return ieee_bn2d_bwd(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
-                         F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), F(n.bnpart), F(n.bncoef), 0, mask_from_y, st);
+                         F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), F(n.bnpart), F(n.bncoef), 0, mask_from_y, rb, st);
   }
   int wgrad(const ConvUnit& u, const void* dy, const void* x) {
     prof_begin(1, u);
@@ -351,12 +354,19 @@ struct Run {
     return ieee_conv2d_wgrad(dy, x, grd(u.s_w), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride,
                              u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, gs(u.s_w), 0, st);
   }
-  int dgrad(const ConvUnit& u, const void* dy, void* dx, const void* addend) {
+  // prev: the unit whose BN(+ReLU) output is this conv's input; when given (bf16), the dgrad epilogue also emits
+  // that BN's backward sums so that the following bn_bwd(prev) skips its reduction pass
+  int dgrad(const ConvUnit& u, const void* dy, void* dx, const void* addend, const ConvUnit* prev = nullptr,
+            bool prev_mask_tensor = false) {
     const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.S);
+    const bool fuse = prev != nullptr && n.dtype == IEEE_BF16;
+    fused_bwd = fuse;
     prof_begin(0, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_dgrad(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
-                             u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, st);
+                             u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, fuse ? F(n.bnpart) : nullptr,
+                             fuse ? P(prev->y) : nullptr, (fuse && prev_mask_tensor) ? P(prev->a) : nullptr,
+                             (fuse && !prev_mask_tensor) ? F(prev->stats) : nullptr, st);
   }
   // grouped fp32 GEMM over the 3 modalities with uniform strides
   int gemm3(const float* A, int64_t a_gs, const float* Bm, int64_t b_gs, float* C, int64_t c_gs, const float* bias,
@@ -640,10 +650,10 @@ int Run::backward(const float* dlogits, const float* dfeats) {
     // out = relu(bn3(y3) + identity): g = dout*[out>0] -> Q ; dy3 -> X (in place)
     IEEE_TRY(bn_bwd(c3, X, P(c3.a), X, Q));
     IEEE_TRY(wgrad(c3, X, P(c2.a)));
-    IEEE_TRY(dgrad(c3, X, Rb, nullptr));
+    IEEE_TRY(dgrad(c3, X, Rb, nullptr, &c2));
     IEEE_TRY(bn_bwd(c2, Rb, nullptr, Rb, nullptr, 1));   // relu mask recomputed from y2 (no residual)
     IEEE_TRY(wgrad(c2, Rb, P(c1.a)));
-    IEEE_TRY(dgrad(c2, Rb, U, nullptr));
+    IEEE_TRY(dgrad(c2, Rb, U, nullptr, &c1));
     IEEE_TRY(bn_bwd(c1, U, nullptr, U, nullptr, 1));
     IEEE_TRY(wgrad(c1, U, xin));
     const void* addend = Q;
@@ -654,7 +664,10 @@ int Run::backward(const float* dlogits, const float* dfeats) {
       IEEE_TRY(dgrad(d, Q, V, nullptr));
       addend = V;
     }
-    IEEE_TRY(dgrad(c1, U, X, addend));   // d(block input) = dgrad(conv1) + identity-branch gradient
+    // d(block input) = dgrad(conv1) + identity-branch gradient; it is d(out) of the previous block, whose bn3
+    // backward sums (mask = that block's stored output) are emitted here too
+    const ConvUnit* pc3 = bi > 0 ? &N.units[N.blocks[bi - 1].c3] : nullptr;
+    IEEE_TRY(dgrad(c1, U, X, addend, pc3, true));
   }
   // stem: maxpool -> ReLU/BN -> conv wgrad (no dgrad: the input is the image)
   const ConvUnit& s = N.units[N.u_stem];

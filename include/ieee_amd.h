@@ -117,7 +117,12 @@ int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t Wo);
 int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
                       int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
                       int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
+                      float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
                       void* stream);
+/* bn_partial != NULL (bf16 only): dx is the gradient w.r.t. the output of a BN(+ReLU) whose input is bn_y; the
+ * dgrad epilogue also emits that BN's backward sums [rblocks][2][Ci] (sum g, sum g*y; g = dx * [mask], mask from
+ * bn_mask > 0, or from bn_y*scale+shift > 0 with bn_stats = that BN's [4][Ci] stats, or none), rblocks =
+ * ceil(N*Hi*Wi/128): pass it to ieee_bn2d_bwd(stats_rblocks) and the separate reduction pass disappears */
 
 /* dw (fp32, OIHW, the layout of param.grad) = or += sum over pixels; deterministic split-K:
  * partial slabs in `work` (size from the query below) are reduced in a fixed order */
@@ -150,7 +155,7 @@ int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int dtype, int
 int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
                   int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
                   const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, float* partial,
-                  float* coef, int accumulate, int mask_from_y, void* stream);
+                  float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks, void* stream);
 
 /* ---- stem plumbing ----------------------------------------------------------- */
 /* three fp32 NCHW image tensors (batch dict 'img' = [RGB, NI, TI], dataset.py:338-351) -> [3][B][H][W][Cpad]

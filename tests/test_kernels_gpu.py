@@ -72,7 +72,7 @@ def test_bn2d_fwd_bwd(dtype, G, M, C, residual, relu):
     coef = torch.empty(G, 3, C, device=dev)
     L.check(lib.ieee_bn2d_bwd(L.ptr(dd), L.ptr(mask), L.ptr(yd), L.ptr(dy), L.ptr(gout), dt, G, M, C, M * C,
                               L.ptr(gd), C, L.ptr(stats), L.ptr(dgam), L.ptr(dbet), C, L.ptr(part), L.ptr(coef), 0,
-                              0, L.stream()))
+                              0, 0, L.stream()))
     btol = dict(rtol=3e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=2e-4, atol=2e-4)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, **btol)
     gtol = dict(rtol=3e-2, atol=0.5) if dtype == torch.bfloat16 else dict(rtol=1e-3, atol=5e-3)
@@ -206,7 +206,7 @@ def test_cim_tail_chain_fwd_bwd_fp32(mode):
         gd = ga.detach().to(dev)
         dg, db = torch.zeros(3, C, device=dev), torch.zeros(3, C, device=dev)
         L.check(lib.ieee_bn2d_bwd(L.ptr(gq), None, L.ptr(y), L.ptr(gq), None, 0, 3, B * P, C, B * P * C, L.ptr(gd), C,
-                                  L.ptr(st), L.ptr(dg), L.ptr(db), C, L.ptr(part), L.ptr(coef), 0, 0, L.stream()))
+                                  L.ptr(st), L.ptr(dg), L.ptr(db), C, L.ptr(part), L.ptr(coef), 0, 0, 0, L.stream()))
         res["dy" + name], res["dg" + name], res["db" + name] = gq, dg, db
     back = lambda t: t.cpu().permute(0, 1, 4, 2, 3)
     torch.testing.assert_close(back(res["dy1"]), w["y1"].grad, rtol=2e-3, atol=2e-5)
