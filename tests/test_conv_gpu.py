@@ -122,3 +122,50 @@ def test_padded_stem_equals_7x7_conv(dtype):
     wtol = dict(rtol=2e-2, atol=0.5) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-3)
     for i in range(G):
         torch.testing.assert_close(dw[i].cpu(), refs[i][2], **wtol)
+
+
+def test_fused_bn_partials_in_conv_epilogues():
+    """bf16: the forward epilogue's per-tile BN sums (sum y, sum y^2) and the dgrad epilogue's BN-backward sums
+    (sum g, sum g*y with the three mask sources) against direct sums over the tensors the kernels stored"""
+    from ieee_amd import _lib as L, _ops
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(21)
+    G, N, H, W, Ci, Co = 3, 5, 12, 10, 64, 192          # M = 600 rows: 5 row tiles, the last one partial
+    dt = torch.bfloat16
+    x = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
+    w = (torch.randn(G, Co, Ci, 3, 3, generator=g) * 0.05).cuda()
+    wp, wpd = _ops.pack_conv_weight(w, dt, 0), _ops.pack_conv_weight(w, dt, 1)
+    M = N * H * W
+    rb = lib.ieee_conv2d_fwd_stats_rblocks(N, H, W)
+    part = torch.zeros(G, rb, 2, Co, device="cuda")
+    y = torch.empty(G, N, H, W, Co, device="cuda", dtype=dt)
+    L.check(lib.ieee_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(y), L.IEEE_BF16, G, N, H, W, Ci, Co, 3, 3, 1, 1, x[0].numel(),
+                                wp.stride(0), y[0].numel(), L.ptr(part), L.stream()))
+    yf = y.float().view(G, M, Co)
+    torch.testing.assert_close(part[:, :, 0].sum(1), yf.sum(1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(part[:, :, 1].sum(1), (yf * yf).sum(1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(y.float(), _ops.conv2d_fwd(x, wp, Co, 3, 3, 1, 1).float())   # same stores as unfused
+    # dgrad: dx = grad w.r.t. x; pretend x = relu(bn(ypre)) of a previous unit
+    dy = torch.randn(G, N, H, W, Co, generator=g).cuda().to(dt)
+    ypre = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
+    amask = (torch.randn(G, N, H, W, Ci, generator=g) > 0).cuda().to(dt)
+    stats = torch.randn(G, 4, Ci, generator=g).cuda()
+    addend = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
+    dx_ref = _ops.conv2d_dgrad(dy, wpd, (H, W), Ci, 3, 3, 1, 1, addend=addend)
+    for mode in ("mask", "stats", "none"):
+        p2 = torch.zeros(G, rb, 2, Ci, device="cuda")
+        dx = torch.empty_like(dx_ref)
+        L.check(lib.ieee_conv2d_dgrad(L.ptr(dy), L.ptr(wpd), L.ptr(dx), L.ptr(addend), L.IEEE_BF16, G, N, H, W, Ci, Co, 3, 3,
+                                      1, 1, dy[0].numel(), wpd.stride(0), dx[0].numel(), L.ptr(p2), L.ptr(ypre),
+                                      L.ptr(amask) if mode == "mask" else None, L.ptr(stats) if mode == "stats" else None,
+                                      L.stream()))
+        assert torch.equal(dx, dx_ref)
+        d, yv = dx.float().view(G, M, Ci), ypre.float().view(G, M, Ci)
+        if mode == "mask":
+            gq = d * (amask.float().view(G, M, Ci) > 0)
+        elif mode == "stats":
+            gq = d * ((yv * stats[:, 2:3] + stats[:, 3:4]) > 0)
+        else:
+            gq = d
+        torch.testing.assert_close(p2[:, :, 0].sum(1), gq.sum(1), rtol=1e-3, atol=5e-2)
+        torch.testing.assert_close(p2[:, :, 1].sum(1), (gq * yv).sum(1), rtol=1e-3, atol=5e-2)
