@@ -56,7 +56,10 @@ def cpu_baseline_train(seconds_budget=25.0):
     B = 8
     xs = [torch.from_numpy(x) for x in detgen.generate_images(B, 0)]
     pids = torch.arange(B) // 4
-    threads = torch.get_num_threads()
+    # torch's default (one thread per hardware thread, 128 on the GPU box) oversubscribes these small convs
+    # and is ~5x slower than 16 threads; the baseline uses 16 and says so
+    threads = min(16, torch.get_num_threads())
+    torch.set_num_threads(threads)
     om.train_step(sd, xs, pids, C)                       # warm-up
     t0, n = time.time(), 0
     while n < 2 or (time.time() - t0 < seconds_budget and n < 6):
