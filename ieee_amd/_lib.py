@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libieee_amd.so")
+LIB_PATH = os.environ.get("IEEE_AMD_LIB", os.path.join(_HERE, "libieee_amd.so"))   # override: kernel A/B experiments
 _lib = None
 
 c_void_p, c_int, c_int64, c_float, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,

@@ -379,21 +379,33 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   }
   const PackDesc d = descs[lo];
   const int z = blockIdx.y;
-  const int rows = d.mode == 0 ? d.Co : d.Ci;
-  const int64_t total = (int64_t)rows * d.ld;
-  const int64_t i = (int64_t)(b - d.block_begin) * 256 + threadIdx.x;
+  const unsigned rows = d.mode == 0 ? d.Co : d.Ci;
+  const unsigned total = rows * (unsigned)d.ld;                 // < 2^31 for every layer: 32-bit index math
+  const unsigned i = (unsigned)(b - d.block_begin) * 256u + threadIdx.x;
   if (i >= total) return;
-  const int row = (int)(i / d.ld), col = (int)(i % d.ld);
-  const int inner = d.mode == 0 ? d.Ci : d.Co;
-  float v = 0.f;
-  if (col < d.R * d.S * inner) {
-    const int tap = col / inner, c = col % inner;
-    const int co = d.mode == 0 ? row : c, ci = d.mode == 0 ? c : row;
-    const int rr = tap / d.S, ss = tap % d.S;
-    if (ci < d.Ci_src && ss < d.S_src)
-      v = params[d.src_off + z * d.src_gs + (((int64_t)co * d.Ci_src + ci) * d.R + rr) * d.S_src + ss];
+  const float* src = params + d.src_off + z * d.src_gs;
+  T* dst = (T*)ws + d.dst_off + z * d.dst_gs;
+  const unsigned RS = (unsigned)(d.R * d.S);
+  if (RS == 1 && d.ld == (d.mode == 0 ? d.Ci : d.Co) && d.Ci_src == d.Ci) {
+    if (d.mode == 0) {                      // 1x1 forward operand: same layout, just the dtype changes
+      dst[i] = from_f32<T>(src[i]);
+    } else {                                // 1x1 dgrad operand: [ci][co] = transpose of [co][ci]
+      const unsigned ci = i / (unsigned)d.Co, co = i - ci * (unsigned)d.Co;
+      dst[i] = from_f32<T>(src[co * (unsigned)d.Ci + ci]);
+    }
+    return;
   }
-  ((T*)ws)[d.dst_off + z * d.dst_gs + i] = from_f32<T>(v);
+  const unsigned row = i / (unsigned)d.ld, col = i - row * (unsigned)d.ld;
+  const unsigned inner = d.mode == 0 ? d.Ci : d.Co;
+  float v = 0.f;
+  if (col < RS * inner) {
+    const unsigned tap = col / inner, c = col - tap * inner;
+    const unsigned co = d.mode == 0 ? row : c, ci = d.mode == 0 ? c : row;
+    const unsigned rr = tap / (unsigned)d.S, ss = tap - rr * (unsigned)d.S;
+    if (ci < (unsigned)d.Ci_src && ss < (unsigned)d.S_src)
+      v = src[((co * (unsigned)d.Ci_src + ci) * (unsigned)d.R + rr) * (unsigned)d.S_src + ss];
+  }
+  dst[i] = from_f32<T>(v);
 }
 
 template <typename T> static int conv_bk() { return ImgNT<T>::BK; }
@@ -419,9 +431,13 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   dim3 grid(a.tiles_m * a.tiles_n, groups);
   const bool dma = kUseDma && !slow && sizeof(T) == 2;             // bf16 fast path: DMA_STAGES-deep LDS ring
   const int stages = dma ? DMA_STAGES : 2;
-  const size_t smem = (size_t)stages * (128 + (narrow ? 64 : 128)) * 128;
+  size_t smem = (size_t)stages * (128 + (narrow ? 64 : 128)) * 128;
+  if (const char* e = getenv("IEEE_DBG_LDS")) smem = (size_t)atoi(e);   // occupancy experiments
   static bool attr_done = false;
   if (!attr_done) {   // > 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
+    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, 128, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, 128, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, 128, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const bool stats = bn_partial != nullptr;

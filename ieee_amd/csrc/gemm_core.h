@@ -149,6 +149,27 @@ __device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, in
     }
     const char* At = cur + (wm * (BM / 2)) * 128;
     const char* Bt = cur + BM * 128 + (wn * (BN / 2)) * 128;
+#ifdef IEEE_VARIANT_B
+    if constexpr (Img::KSTEPS == 2) {   // bf16: issue every fragment read of the k-tile before the first MFMA
+      typename Img::Frag fa0[FM], fb0[FN], fa1[FM], fb1[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa0[i] = Img::frag(At, i * 16, 0, lane);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb0[j] = Img::frag(Bt, j * 16, 0, lane);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa1[i] = Img::frag(At, i * 16, 1, lane);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb1[j] = Img::frag(Bt, j * 16, 1, lane);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb0[j], fa0[i], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb1[j], fa1[i], acc[i][j]);
+    } else
+#endif
 #pragma unroll
     for (int kk = 0; kk < Img::KSTEPS; ++kk) {
       typename Img::Frag fa[FM], fb[FN];
