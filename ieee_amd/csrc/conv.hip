@@ -241,7 +241,7 @@ struct WgradArgs {
   GatherGeom g;       // forward geometry of the conv
   int Co, ncols;      // GEMM M (= Cout), N (= R*S*Cin)
   int npix, kchunk;   // GEMM K (= N*Ho*Wo) and the K range per split
-  int tiles_n, tiles, nsplit, groups, xcd_group;
+  int tiles_n, tiles, nsplit, groups, xcd_group, plain_x;
   int64_t dy_gs, x_gs, slab_gs;   // per-modality strides; slab_gs covers all splits of one modality
 };
 
@@ -281,6 +281,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ d
   }
   LoaderColsTN<T> la;
   la.init(dy, a.Co, m0, a.Co, kbeg, kend);
+  if (!SLOW && a.plain_x) {   // 1x1 / stride 1 / no padding: im2col(X) is X itself, a plain [pixels][Cin] matrix
+    LoaderColsTN<T> lb;
+    lb.init(x, a.ncols, n0, a.ncols, kbeg, kend);
+    gemm_tn<T>(la, lb, epi, ktiles, m0, n0, smem);
+    return;
+  }
   if constexpr (SLOW) {
     LoaderIm2colSlowTN<T> lb;
     lb.init(x, a.g, n0, kbeg, kend);
@@ -653,6 +659,7 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   a.x_gs = x_gs;
   a.slab_gs = (int64_t)nsplit * d.Co * a.ncols;
   const bool slow = (Ci % elem_vec(dtype)) != 0;
+  a.plain_x = (d.R == 1 && d.S == 1 && d.stride == 1 && d.pad == 0) ? 1 : 0;
   const int nkz = nsplit * (int)groups;
   a.xcd_group = (nkz >= 24 || nkz % 8 == 0) ? 1 : 0;
   dim3 grid((unsigned)(a.tiles * (a.xcd_group ? cdiv(nkz, 8) * 8 : nkz)));
