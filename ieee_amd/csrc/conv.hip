@@ -229,11 +229,11 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ 
   if constexpr (SLOW) {
     LoaderIm2colSlowNT<T, 4> la;
     la.init(src, a.g, m0);
-    gemm_nt<T, 128, BN>(la, lb, epi, a.ktiles, m0, n0, smem);
+    gemm_nt<T, 128, BN, (sizeof(T) == 2 ? 1 : 2)>(la, lb, epi, a.ktiles, m0, n0, smem);
   } else {
     LoaderIm2colNT<T, 4> la;
     la.init(src, a.g, m0);
-    gemm_nt<T, 128, BN>(la, lb, epi, a.ktiles, m0, n0, smem, a.dbg & 1);
+    gemm_nt<T, 128, BN, (sizeof(T) == 2 ? 1 : 2)>(la, lb, epi, a.ktiles, m0, n0, smem, a.dbg & 1);
   }
 }
 
@@ -284,17 +284,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ d
   if (!SLOW && a.plain_x) {   // 1x1 / stride 1 / no padding: im2col(X) is X itself, a plain [pixels][Cin] matrix
     LoaderColsTN<T> lb;
     lb.init(x, a.ncols, n0, a.ncols, kbeg, kend);
-    gemm_tn<T>(la, lb, epi, ktiles, m0, n0, smem);
+    gemm_tn<T, (sizeof(T) == 2 ? 1 : 2)>(la, lb, epi, ktiles, m0, n0, smem);
     return;
   }
   if constexpr (SLOW) {
     LoaderIm2colSlowTN<T> lb;
     lb.init(x, a.g, n0, kbeg, kend);
-    gemm_tn<T>(la, lb, epi, ktiles, m0, n0, smem);
+    gemm_tn<T, (sizeof(T) == 2 ? 1 : 2)>(la, lb, epi, ktiles, m0, n0, smem);
   } else {
     LoaderIm2colTN<T> lb;
     lb.init(x, a.g, n0, kbeg, kend);
-    gemm_tn<T>(la, lb, epi, ktiles, m0, n0, smem);
+    gemm_tn<T, (sizeof(T) == 2 ? 1 : 2)>(la, lb, epi, ktiles, m0, n0, smem);
   }
 }
 
@@ -436,8 +436,15 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   a.tiles_n = cdiv(N, narrow ? 64 : 128);
   dim3 grid(a.tiles_m * a.tiles_n, groups);
   const bool dma = kUseDma && !slow && sizeof(T) == 2;             // bf16 fast path: DMA_STAGES-deep LDS ring
-  const int stages = dma ? DMA_STAGES : 2;
+  const int stages = dma ? DMA_STAGES : (sizeof(T) == 2 ? 1 : 2);   // bf16: single LDS stage (see gemm_nt)
   size_t smem = (size_t)stages * (128 + (narrow ? 64 : 128)) * 128;
+  {   // the LDS-staged epilogue needs the C tile: bf16 rows padded by 16 B, fp32 rows unpadded
+    const size_t bn = narrow ? 64 : 128;
+    const size_t epi_bytes = 128 * (bn * sizeof(T) + (sizeof(T) == 2 ? 16 : 0));
+    const size_t red_bytes = 16 * 1024;   // BN-sum reduction scratch
+    if (smem < epi_bytes) smem = epi_bytes;
+    if (smem < red_bytes) smem = red_bytes;
+  }
   if (const char* e = getenv("IEEE_DBG_LDS")) smem = (size_t)atoi(e);   // occupancy experiments
   static bool attr_done = false;
   if (!attr_done) {   // > 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
@@ -663,7 +670,8 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   const int nkz = nsplit * (int)groups;
   a.xcd_group = (nkz >= 24 || nkz % 8 == 0) ? 1 : 0;
   dim3 grid((unsigned)(a.tiles * (a.xcd_group ? cdiv(nkz, 8) * 8 : nkz)));
-  const size_t smem = (kUseDma && dtype == IEEE_BF16 && !slow) ? (size_t)DMA_STAGES * 32 * 1024 : 64 * 1024;
+  const size_t smem = (kUseDma && dtype == IEEE_BF16 && !slow) ? (size_t)DMA_STAGES * 32 * 1024
+                                                               : (dtype == IEEE_BF16 ? 32 * 1024 : 64 * 1024);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

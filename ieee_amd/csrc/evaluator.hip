@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void distmat_kernel(const T* q, const T* g, co
   const int m0 = tm * 128, n0 = tn * 128;
   LoaderPlainNT<T, 4> la, lb;
   DistEpi epi{out, qn, gn, ldo, m, n, metric};
-  if constexpr (sizeof(T) == 2) {   // bf16: operands through LDS-DMA
+  if constexpr (false && sizeof(T) == 2) {   // LDS-DMA variant (not faster in practice; kept for the next tuning round)
     const int ch = nt_dma_chunk(threadIdx.x);
     la.init(q, d, m0, m, d, ch);
     lb.init(g, d, n0, n, d, ch);
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void distmat_kernel(const T* q, const T* g, co
   }
   la.init(q, d, m0, m, d);
   lb.init(g, d, n0, n, d);
-  gemm_nt<T, 128, 128>(la, lb, epi, (d + ImgNT<T>::BK - 1) / ImgNT<T>::BK, m0, n0, smem);
+  gemm_nt<T, 128, 128, (sizeof(T) == 2 ? 1 : 2)>(la, lb, epi, (d + ImgNT<T>::BK - 1) / ImgNT<T>::BK, m0, n0, smem);
 }
 
 // one wave per row: sum of squares (metric 0) or 1/max(norm, 1e-12) (metric 1)
@@ -292,7 +292,7 @@ extern "C" int ieee_sqeuclid_distmat(const void* q, const void* g, int64_t m, in
   float* qn = (float*)work;
   float* gn = qn + m;
   const int tiles_m = cdiv(m, 128), tiles_n = cdiv(n, 128);
-  const size_t smem = (dtype == IEEE_BF16 ? DMA_STAGES : 2) * 256 * 128;
+  const size_t smem = (dtype == IEEE_BF16 ? 1 : 2) * 256 * 128;   // bf16: single LDS stage (see gemm_nt)
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)distmat_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

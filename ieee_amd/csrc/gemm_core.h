@@ -110,7 +110,10 @@ __device__ int g_dbg_nok_dummy;
 // TN slots: k-row = t/CPR + (256/CPR)*slot, chunk = t%CPR.
 // Epilogue contract: epi(m, n, f32x4 v): v[r] is C[m][n+r] (global indices).
 
-template <typename T, int BM, int BN, class LA, class LB, class Epi>
+// STAGES = 2: double-buffered LDS, one barrier per k-tile.  STAGES = 1: one LDS stage and two barriers per
+// k-tile — half the LDS, so twice the workgroups per CU; measured faster for every bf16 conv shape of the net
+// (occupancy hides the load latency better than the second buffer does).
+template <typename T, int BM, int BN, int STAGES, class LA, class LB, class Epi>
 __device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem, int g_dbg_nok = 0) {
   typedef ImgNT<T> Img;
   constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;
@@ -137,8 +140,8 @@ __device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, in
   __syncthreads();
 
   for (int kt = 0; kt < ktiles; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE;
-    char* nxt = smem + ((kt + 1) & 1) * STAGE;
+    char* cur = STAGES == 1 ? smem : smem + (kt & 1) * STAGE;
+    char* nxt = STAGES == 1 ? smem : smem + ((kt + 1) & 1) * STAGE;
     const bool has_next = (kt + 1) < ktiles;
     if (has_next) {
       if (!g_dbg_nok) { la.next(); lb.next(); }
@@ -149,27 +152,6 @@ __device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, in
     }
     const char* At = cur + (wm * (BM / 2)) * 128;
     const char* Bt = cur + BM * 128 + (wn * (BN / 2)) * 128;
-#ifdef IEEE_VARIANT_B
-    if constexpr (Img::KSTEPS == 2) {   // bf16: issue every fragment read of the k-tile before the first MFMA
-      typename Img::Frag fa0[FM], fb0[FN], fa1[FM], fb1[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) fa0[i] = Img::frag(At, i * 16, 0, lane);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) fb0[j] = Img::frag(Bt, j * 16, 0, lane);
-#pragma unroll
-      for (int i = 0; i < FM; ++i) fa1[i] = Img::frag(At, i * 16, 1, lane);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) fb1[j] = Img::frag(Bt, j * 16, 1, lane);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb0[j], fa0[i], acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb1[j], fa1[i], acc[i][j]);
-    } else
-#endif
 #pragma unroll
     for (int kk = 0; kk < Img::KSTEPS; ++kk) {
       typename Img::Frag fa[FM], fb[FN];
@@ -182,6 +164,7 @@ __device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, in
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
     }
+    if constexpr (STAGES == 1) __syncthreads();   // everyone is done reading the single stage before it is overwritten
     if (has_next) {
 #pragma unroll
       for (int i = 0; i < ACH; ++i) Img::store(nxt, srow + 32 * i, sc, ra[i]);
@@ -203,7 +186,7 @@ __device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, in
 }
 
 // TN core: 128x128 tile only.
-template <typename T, class LA, class LB, class Epi>
+template <typename T, int STAGES, class LA, class LB, class Epi>
 __device__ __forceinline__ void gemm_tn(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem) {
   typedef ImgTN<T> Img;
   constexpr int CPR = Img::CPR;
@@ -232,8 +215,8 @@ __device__ __forceinline__ void gemm_tn(LA& la, LB& lb, Epi& epi, int ktiles, in
   __syncthreads();
 
   for (int kt = 0; kt < ktiles; ++kt) {
-    char* cur = smem + (kt & 1) * STAGE;
-    char* nxt = smem + ((kt + 1) & 1) * STAGE;
+    char* cur = STAGES == 1 ? smem : smem + (kt & 1) * STAGE;
+    char* nxt = STAGES == 1 ? smem : smem + ((kt + 1) & 1) * STAGE;
     const bool has_next = (kt + 1) < ktiles;
     if (has_next) {
       la.next();
@@ -255,6 +238,7 @@ __device__ __forceinline__ void gemm_tn(LA& la, LB& lb, Epi& epi, int ktiles, in
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
     }
+    if constexpr (STAGES == 1) __syncthreads();
     if (has_next) {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) Img::store(nxt, skr + RPP * i, sc, ra[i]);
