@@ -61,6 +61,11 @@ class NativeNet:
         _lib.check(self.lib.ieee_net_backward(self.handle, _lib.ptr(self.workspace), _lib.ptr(dlogits),
                                               _lib.ptr(dfeats), _lib.stream()))
 
+    def backward_part(self, dlogits, dfeats, part):
+        """staged backward (include/ieee_amd.h: ieee_net_backward_part); parts 0..4 in order"""
+        _lib.check(self.lib.ieee_net_backward_part(self.handle, _lib.ptr(self.workspace), _lib.ptr(dlogits),
+                                                   _lib.ptr(dfeats), part, _lib.stream()))
+
     def tensor(self, name):
         """a named intermediate as a torch view of the workspace (parity tests / debugging)"""
         off, numel, dt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()

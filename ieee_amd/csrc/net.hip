@@ -71,6 +71,7 @@ struct Net {
   std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
   int pack_blocks_train = 0, pack_blocks_eval = 0;
   const void* pack_uploaded_ws = nullptr;
+  bool fused_bwd_state = false;   // survives between the staged ieee_net_backward_part calls
   Tensor Gp, avgmax, amax, Hh, Hs, att, Pp, Zg, Zp, glob, part, sv_g, sv_p, rr, part2, fcraw, sv_fc, featcat, fcall,
       logits, featn, norms;
   Tensor dfeatcat, dfcraw, dpart2, dr, dglob, dZp, dZg, dPp, dGp, datt, dHs, dH, davgmax, remwork;
@@ -334,7 +335,7 @@ struct Run {
                          training, relu, rb, st);
   }
   // backward of out = [relu](bn(y) [+res]); dy may alias dout
-  bool fused_bwd = false;   // the last dgrad already emitted the BN-backward sums of the unit bn_bwd() is called for
+  bool& fused_bwd = n.fused_bwd_state;   // the last dgrad already emitted the BN-backward sums of the next bn_bwd()
   int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0) {
     const int64_t rb = fused_bwd ? (u.M(B) + 127) / 128 : 0;
     fused_bwd = false;
@@ -377,7 +378,8 @@ struct Run {
     return ieee_sgemm_grouped(3, a, b, c, bias ? bi : nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 1.0f, relu, acc, st);
   }
   int forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out);
-  int backward(const float* dlogits, const float* dfeats);
+  int backward(const float* dlogits, const float* dfeats, int part = -1);
+  int backward_head(const float* dlogits, const float* dfeats);
 };
 
 int Run::forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out) {
@@ -517,8 +519,58 @@ int Run::forward(const float* xr, const float* xn, const float* xt, int training
   return IEEE_OK;
 }
 
-int Run::backward(const float* dlogits, const float* dfeats) {
+// part -1: everything.  part 0: head + CIM (leaves d(trunk output) in gbuf[0]); parts 1..4: the bottleneck blocks
+// of layer4, layer3, layer2, layer1 (+ stem), in that order.  After part p every parameter gradient of that part
+// is final, so a data-parallel caller can start all-reducing it while the next part runs.
+int Run::backward(const float* dlogits, const float* dfeats, int part) {
   Net& N = n;
+  const int dt = N.dtype;
+  if (part <= 0) IEEE_TRY(backward_head(dlogits, dfeats));
+  if (part == 0) return IEEE_OK;
+  static const int first_block[5] = {0, 3, 7, 13, 16};   // layer1..4 start indices ([3,4,6,3] blocks)
+  int hi = (int)N.blocks.size() - 1, lo = 0;
+  if (part > 0) { hi = first_block[5 - part] - 1; lo = first_block[4 - part]; }
+  // trunk backward (Bottleneck blocks in reverse); X holds d(out) of the current block
+  void* X = P(N.gbuf[0]);
+  void *Q = P(N.gbuf[1]), *Rb = P(N.gbuf[2]), *U = P(N.gbuf[3]), *V = P(N.gbuf[4]);
+  for (int bi = hi; bi >= lo; --bi) {
+    const Block& b = N.blocks[bi];
+    const ConvUnit &c1 = N.units[b.c1], &c2 = N.units[b.c2], &c3 = N.units[b.c3];
+    const void* xin = bi == 0 ? P(N.pool) : P(N.units[N.blocks[bi - 1].c3].a);
+    // out = relu(bn3(y3) + identity): g = dout*[out>0] -> Q ; dy3 -> X (in place)
+    IEEE_TRY(bn_bwd(c3, X, P(c3.a), X, Q));
+    IEEE_TRY(wgrad(c3, X, P(c2.a)));
+    IEEE_TRY(dgrad(c3, X, Rb, nullptr, &c2));
+    IEEE_TRY(bn_bwd(c2, Rb, nullptr, Rb, nullptr, 1));   // relu mask recomputed from y2 (no residual)
+    IEEE_TRY(wgrad(c2, Rb, P(c1.a)));
+    IEEE_TRY(dgrad(c2, Rb, U, nullptr, &c1));
+    IEEE_TRY(bn_bwd(c1, U, nullptr, U, nullptr, 1));
+    IEEE_TRY(wgrad(c1, U, xin));
+    const void* addend = Q;
+    if (b.ds >= 0) {
+      const ConvUnit& d = N.units[b.ds];
+      IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
+      IEEE_TRY(wgrad(d, Q, xin));
+      IEEE_TRY(dgrad(d, Q, V, nullptr));
+      addend = V;
+    }
+    // d(block input) = dgrad(conv1) + identity-branch gradient; it is d(out) of the previous block, whose bn3
+    // backward sums (mask = that block's stored output) are emitted here too
+    const ConvUnit* pc3 = bi > 0 ? &N.units[N.blocks[bi - 1].c3] : nullptr;
+    IEEE_TRY(dgrad(c1, U, X, addend, pc3, true));
+  }
+  if (lo > 0) return IEEE_OK;
+  // stem: maxpool -> ReLU/BN -> conv wgrad (no dgrad: the input is the image)
+  const ConvUnit& s = N.units[N.u_stem];
+  IEEE_TRY(ieee_maxpool3x3s2_bwd(X, (const uint8_t*)P(N.pool_arg), Q, dt, 3, B, s.Ho, s.Wo, s.Co, st));
+  IEEE_TRY(bn_bwd(s, Q, nullptr, Q, nullptr, 1));
+  IEEE_TRY(wgrad(s, Q, P(N.x0)));
+  return IEEE_OK;
+}
+
+int Run::backward_head(const float* dlogits, const float* dfeats) {
+  Net& N = n;
+  fused_bwd = false;
   const int dt = N.dtype;
   const int R = N.rdim, D = N.cdim, C = N.fdim, PB = N.parts * B, NC = N.num_classes;
   const int64_t BC = (int64_t)B * C;
@@ -640,40 +692,6 @@ int Run::backward(const float* dlogits, const float* dfeats) {
                                  P(N.gbuf[1]), nullptr, dt, B, Hh_, Ww, C, N.parts, 2, st));
     IEEE_TRY(ieee_cim_bwd_combine(P(N.gbuf[1]), nullptr, F(N.dGp), dF, dt, B, Hh_, Ww, C, 2, st));
   }
-  // trunk backward (Bottleneck blocks in reverse); X holds d(out) of the current block
-  void* X = P(N.gbuf[0]);
-  void *Q = P(N.gbuf[1]), *Rb = P(N.gbuf[2]), *U = P(N.gbuf[3]), *V = P(N.gbuf[4]);
-  for (int bi = (int)N.blocks.size() - 1; bi >= 0; --bi) {
-    const Block& b = N.blocks[bi];
-    const ConvUnit &c1 = N.units[b.c1], &c2 = N.units[b.c2], &c3 = N.units[b.c3];
-    const void* xin = bi == 0 ? P(N.pool) : P(N.units[N.blocks[bi - 1].c3].a);
-    // out = relu(bn3(y3) + identity): g = dout*[out>0] -> Q ; dy3 -> X (in place)
-    IEEE_TRY(bn_bwd(c3, X, P(c3.a), X, Q));
-    IEEE_TRY(wgrad(c3, X, P(c2.a)));
-    IEEE_TRY(dgrad(c3, X, Rb, nullptr, &c2));
-    IEEE_TRY(bn_bwd(c2, Rb, nullptr, Rb, nullptr, 1));   // relu mask recomputed from y2 (no residual)
-    IEEE_TRY(wgrad(c2, Rb, P(c1.a)));
-    IEEE_TRY(dgrad(c2, Rb, U, nullptr, &c1));
-    IEEE_TRY(bn_bwd(c1, U, nullptr, U, nullptr, 1));
-    IEEE_TRY(wgrad(c1, U, xin));
-    const void* addend = Q;
-    if (b.ds >= 0) {
-      const ConvUnit& d = N.units[b.ds];
-      IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
-      IEEE_TRY(wgrad(d, Q, xin));
-      IEEE_TRY(dgrad(d, Q, V, nullptr));
-      addend = V;
-    }
-    // d(block input) = dgrad(conv1) + identity-branch gradient; it is d(out) of the previous block, whose bn3
-    // backward sums (mask = that block's stored output) are emitted here too
-    const ConvUnit* pc3 = bi > 0 ? &N.units[N.blocks[bi - 1].c3] : nullptr;
-    IEEE_TRY(dgrad(c1, U, X, addend, pc3, true));
-  }
-  // stem: maxpool -> ReLU/BN -> conv wgrad (no dgrad: the input is the image)
-  const ConvUnit& s = N.units[N.u_stem];
-  IEEE_TRY(ieee_maxpool3x3s2_bwd(X, (const uint8_t*)P(N.pool_arg), Q, dt, 3, B, s.Ho, s.Wo, s.Co, st));
-  IEEE_TRY(bn_bwd(s, Q, nullptr, Q, nullptr, 1));
-  IEEE_TRY(wgrad(s, Q, P(N.x0)));
   return IEEE_OK;
 }
 
@@ -779,6 +797,16 @@ extern "C" int ieee_net_backward(void* handle, void* workspace, const float* dlo
   IEEE_REQUIRE(workspace && dlogits && dfeats, "net_backward: null pointer");
   Run r(*n, workspace, stream);
   return r.backward(dlogits, dfeats);
+}
+
+extern "C" int ieee_net_backward_part(void* handle, void* workspace, const float* dlogits, const float* dfeats, int part,
+                                      void* stream) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && n->bound && n->grads, "net_backward_part: network not bound (or no gradient buffer)");
+  IEEE_REQUIRE(workspace && part >= 0 && part <= 4, "net_backward_part: bad arguments");
+  IEEE_REQUIRE(part > 0 || (dlogits && dfeats), "net_backward_part: part 0 needs the loss gradients");
+  Run r(*n, workspace, stream);
+  return r.backward(dlogits, dfeats, part);
 }
 
 extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {

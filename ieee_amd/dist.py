@@ -1,5 +1,6 @@
-"""Data parallelism for the train step: one process per GPU, replicated weights, ONE all-reduce (sum)
-of the flat fp32 gradient buffer per step over RCCL/xGMI (backend "nccl" is RCCL on ROCm), replacing
+"""Data parallelism for the train step: one process per GPU, replicated weights, ONE pass of all-reduce (sum)
+over the flat fp32 gradient buffer per step over RCCL/xGMI (issued as 13 slices, each as soon as the staged
+backward has finished it, so the transfer overlaps the rest of the backward; engine.py) (backend "nccl" is RCCL on ROCm), replacing
 the reference's single-process nn.DataParallel (scripts/mainMultiModal.py:219-220: per-step parameter
 broadcast + scatter + gather + reduce-add to GPU0).  Loss scaling: CE is a batch MEAN
 (cross_entropy_loss.py:50) so each rank scales it by 1/world; 3M is a SUM over identities

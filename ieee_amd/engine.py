@@ -313,8 +313,21 @@ class _FusedStepMixin(object):
         else:
             df.zero_()
             out3.zero_()
-        net.backward(dl, df)
-        ddp.allreduce_sum_(m._flat_grads)            # the step's single collective (RCCL over xGMI)
+        if ddp.world_size() == 1:
+            net.backward(dl, df)
+        else:
+            # data parallel: the backward runs in 5 parts; as soon as a part is done its (final) slice of the flat
+            # gradient is all-reduced (sum) asynchronously over RCCL/xGMI while the next part computes.  Together
+            # the slices are exactly one pass over the 438 MB buffer; torch orders each collective after the
+            # kernels already enqueued on the compute stream, and wait() orders the SGD step after them.
+            handles = []
+            for part, ranges in enumerate(m.grad_part_ranges()):
+                net.backward_part(dl, df, part)
+                for a, b in ranges:
+                    handles.append(torch.distributed.all_reduce(m._flat_grads[a:b], op=torch.distributed.ReduceOp.SUM,
+                                                                async_op=True))
+            for h in handles:
+                h.wait()
         self.optimizer.step()
         return small, out3
 

@@ -194,6 +194,29 @@ class IEEE3modalPart(nn.Module):
             runs.append((start, pos))
         return runs
 
+    def grad_part_ranges(self):
+        """[start, end) element ranges of the flat gradient buffer that are final after each of the 5 staged
+        backward parts (0: head + CIM, 1: layer4, 2: layer3, 3: layer2, 4: layer1 + stem; three ranges per
+        trunk part, one per modality)"""
+        if not hasattr(self, "_grad_parts"):
+            def part_of(key):
+                if not key.startswith("backbone."):
+                    return 0
+                sub = key.split(".")[2]
+                return {"layer4": 1, "layer3": 2, "layer2": 3}.get(sub, 4)
+            parts = [[] for _ in range(5)]
+            pos, cur, start = 0, None, 0
+            for key, p in self._param_items:
+                pid = part_of(key)
+                if pid != cur:
+                    if cur is not None:
+                        parts[cur].append((start, pos))
+                    cur, start = pid, pos
+                pos += p.numel()
+            parts[cur].append((start, pos))
+            self._grad_parts = parts
+        return self._grad_parts
+
     def native_net(self, batch, height, width):
         _lib.require_gpu()
         if self._flat_params.device.type != "cuda":

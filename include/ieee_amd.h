@@ -268,6 +268,11 @@ int ieee_net_bind(void* handle, float* params, float* grads, float* buffers, con
 int ieee_net_forward(void* handle, void* workspace, const float* x_rgb, const float* x_ni, const float* x_ti,
                      int training, float* logits, float* feats, void* stream);
 int ieee_net_backward(void* handle, void* workspace, const float* dlogits, const float* dfeats, void* stream);
+/* the same backward in 5 consecutive parts (0: head + CIM, 1: layer4, 2: layer3, 3: layer2, 4: layer1 + stem; call
+ * them in this order): after part p all gradients of that part are final, so a data-parallel caller overlaps
+ * their all-reduce with the remaining parts (ieee_amd/engine.py) */
+int ieee_net_backward_part(void* handle, void* workspace, const float* dlogits, const float* dfeats, int part,
+                           void* stream);
 /* measurement: enable=1 starts recording a HIP event pair (on the launch stream) around every conv
  * launch of subsequent forward/backward calls; enable=0 stops, synchronises the device and returns
  * out6 = {ms, algorithmic FLOPs, launches} for [0] forward+dgrad (conv_gather_kernel) and
