@@ -388,6 +388,31 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   }
   const PackDesc d = descs[lo];
   const int z = blockIdx.y;
+  if (d.pad_ == 1) {
+    // 1x1 dgrad operand as a 64x64 LDS-tiled transpose: coalesced 256-B row reads of [co][ci], coalesced 16-byte
+    // (bf16: 128-B row) writes of [ci][co]; the untiled version read with a stride of Ci floats
+    __shared__ float tile[64][65];
+    const int tiles_ci = d.Ci / 64;
+    const int tb = b - d.block_begin, tco = tb / tiles_ci, tci = tb - tco * tiles_ci;
+    const float* src = params + d.src_off + z * d.src_gs + ((int64_t)tco * 64) * d.Ci + tci * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (t >> 4) + 16 * i, c4 = (t & 15) * 4;
+      const float4 v = *(const float4*)(src + (int64_t)r * d.Ci + c4);
+      tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+    T* dst = (T*)ws + d.dst_off + z * d.dst_gs + ((int64_t)tci * 64) * d.ld + tco * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = (t >> 3) + 32 * i, r8 = (t & 7) * 8;   // dst row = ci (tile column), 8 consecutive co
+      T* o = dst + (int64_t)c * d.ld + r8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(tile[r8 + e][c]);
+    }
+    return;
+  }
   const unsigned rows = d.mode == 0 ? d.Co : d.Ci;
   const unsigned total = rows * (unsigned)d.ld;                 // < 2^31 for every layer: 32-bit index math
   const unsigned i = (unsigned)(b - d.block_begin) * 256u + threadIdx.x;
@@ -398,7 +423,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   if (RS == 1 && d.ld == (d.mode == 0 ? d.Ci : d.Co) && d.Ci_src == d.Ci) {
     if (d.mode == 0) {                      // 1x1 forward operand: same layout, just the dtype changes
       dst[i] = from_f32<T>(src[i]);
-    } else {                                // 1x1 dgrad operand: [ci][co] = transpose of [co][ci]
+    } else {                                // 1x1 dgrad operand, untiled fallback: [ci][co] = transpose of [co][ci]
       const unsigned ci = i / (unsigned)d.Co, co = i - ci * (unsigned)d.Co;
       dst[i] = from_f32<T>(src[co * (unsigned)d.Ci + ci]);
     }

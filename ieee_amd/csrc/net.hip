@@ -770,8 +770,11 @@ extern "C" int ieee_net_bind(void* handle, float* params, float* grads, float* b
         d.Co = u.Co; d.Ci = u.Ci; d.R = u.R; d.S = u.S; d.ld = (int)ld; d.mode = mode;
         d.Ci_src = u.Ci_src; d.S_src = u.S_src;
         d.block_begin = blocks;
-        d.pad_ = 0;
-        blocks += cdiv(rows * ld, 256);
+        // 1x1 dgrad operands go through the 64x64 LDS-tiled transpose of pack_all_kernel (pad_ = 1)
+        const bool tiled = mode == 1 && u.R == 1 && u.S == 1 && u.Co % 64 == 0 && u.Ci % 64 == 0 && ld == u.Co &&
+                           u.Ci == u.Ci_src;
+        d.pad_ = tiled ? 1 : 0;
+        blocks += tiled ? (u.Co / 64) * (u.Ci / 64) : cdiv(rows * ld, 256);
         tab.push_back(d);
       }
     }
