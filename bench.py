@@ -93,6 +93,17 @@ def bench_distmat(device):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         out[name] = {"ms": ms, "GFLOP/s": 2.0 * Q * G * D / ms / 1e6}
+    # the model's real descriptor width (2304 = 3 x 768, ieee3modalPart.py:502), fp32, smaller gallery
+    g2 = torch.Generator(device="cpu").manual_seed(2)
+    q3, g3 = torch.randn(10000, 2304, generator=g2).abs().to(device), torch.randn(50000, 2304, generator=g2).abs().to(device)
+    compute_distance_matrix(q3, g3)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    compute_distance_matrix(q3, g3)
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) * 1e3
+    out["fp32_d2304"] = {"ms": ms, "GFLOP/s": 2.0 * 10000 * 50000 * 2304 / ms / 1e6, "workload": "10000 x 50000 x 2304"}
+    del q3, g3
     dm = compute_distance_matrix(qf, gf)
     evaluate_rank(dm, qp, gp, qc, gc)
     torch.cuda.synchronize()

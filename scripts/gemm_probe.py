@@ -38,6 +38,18 @@ def main():
         if "fwd" in which:
             us = timeit(lambda: _ops.conv2d_fwd(x, wp, Co, R, R, st, pad))
             out += "  fwd %7.1f us %6.0f TF" % (us, fl / us / 1e6)
+        if "fwdstats" in which:
+            from ieee_amd import _lib as L
+            lib = L.load()
+            rb = lib.ieee_conv2d_fwd_stats_rblocks(B, H // st, W // st)
+            part = torch.zeros(3, rb, 2, Co, device="cuda")
+            yy = torch.empty_like(y)
+
+            def f():
+                L.check(lib.ieee_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(yy), L.IEEE_BF16, 3, B, H, W, Ci, Co, R, R, st, pad,
+                                            x[0].numel(), wp.stride(0), yy[0].numel(), L.ptr(part), L.stream()))
+            us = timeit(f)
+            out += "  fwd+stats %7.1f us" % us
         if "dgrad" in which:
             us = timeit(lambda: _ops.conv2d_dgrad(y, wpd, (H, W), Ci, R, R, st, pad))
             out += "  dgrad %7.1f us %6.0f TF" % (us, fl / us / 1e6)
