@@ -3,6 +3,8 @@
 // Semantics: torch.nn.BatchNorm2d defaults as used by the reference (torchreid/models/resnet.py:151,
 // 164-184; ieee3modalPart.py:38): eps 1e-5, momentum 0.1, biased variance for normalisation,
 // unbiased for the running estimate.  HBM-bound streaming kernels, 16 bytes per lane.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ieee {
@@ -275,8 +277,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 static int ew_blocks(int64_t chunks) {
+  static const int64_t cap = getenv("IEEE_EW_BLOCKS") ? atoll(getenv("IEEE_EW_BLOCKS")) : 4096;
   int64_t b = (chunks + 255) / 256;
-  if (b > 2048) b = 2048;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }

@@ -187,6 +187,7 @@ struct ConvArgs {
   int ldw, ktiles;   // packed-weight row length (elements), number of k-tiles
   int tiles_m, tiles_n;
   int dbg;           // tuning experiments only (IEEE_DBG)
+  int group;         // m-tiles per group in the grouped tile order
   int64_t src_gs, w_gs, dst_gs;   // per-modality strides (elements)
 };
 
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ 
                                                           float* __restrict__ bn_partial, ConvArgs a, BwdStats bs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
-  tile_map_xy(a.tiles_m, a.tiles_n, 8, tm, tn);
+  tile_map_xy(a.tiles_m, a.tiles_n, a.group, tm, tn);
   const int m0 = tm * 128, n0 = tn * BN;
   const int z = blockIdx.y;
   src += z * a.src_gs;
@@ -456,6 +457,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   a.ldw = ldw;
   a.ktiles = cdiv(Ktrue, BK);
   { const char* e = getenv("IEEE_DBG"); a.dbg = e ? atoi(e) : 0; }
+  { static const int grp = getenv("IEEE_TILE_GROUP") ? atoi(getenv("IEEE_TILE_GROUP")) : 8; a.group = grp; }
   a.src_gs = src_gs;
   a.w_gs = w_gs;
   a.dst_gs = dst_gs;
