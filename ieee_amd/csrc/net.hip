@@ -70,8 +70,32 @@ struct Net {
   Tensor x0, pool, pool_arg, S, gbuf[5], slab, bnpart, bncoef, packtab;
   std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
   int pack_blocks_train = 0, pack_blocks_eval = 0;
+  // training: the layer3 / layer4 / CIM operands (90 % of the bytes) are packed on the side stream while the
+  // caller's stream runs the stem, layer1 and layer2; pack_late = those descriptors with their own block numbering
+  std::vector<PackDescHost> pack_late;
+  int pack_late_first = 0, pack_late_unit = 0, pack_blocks_early = 0, pack_blocks_late = 0;
+  hipEvent_t pack_ev[2] = {nullptr, nullptr};
   const void* pack_uploaded_ws = nullptr;
   bool fused_bwd_state = false;   // survives between the staged ieee_net_backward_part calls
+  // Weight-gradient kernels run on a second (low-priority) HIP stream: nothing on the dgrad / BN-backward chain
+  // depends on them, so they fill the tails and the HBM-bound phases of that chain.  side_ready[i] is recorded on
+  // the caller's stream when wgrad i's dY operand is final; gbuf_read[b] on the side stream after the last wgrad
+  // that reads gradient buffer b (the caller's stream waits on it before it overwrites b).
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> side_ready;
+  hipEvent_t gbuf_read[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t side_done = nullptr;
+  bool gbuf_pending[5] = {false, false, false, false, false};
+  bool side_dirty = false;
+  size_t side_used = 0;
+  ~Net() {
+    for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : side_ready) (void)hipEventDestroy(e);
+    for (hipEvent_t e : gbuf_read) if (e) (void)hipEventDestroy(e);
+    if (side_done) (void)hipEventDestroy(side_done);
+    for (hipEvent_t e : pack_ev) if (e) (void)hipEventDestroy(e);
+    if (side) (void)hipStreamDestroy(side);
+  }
   Tensor Gp, avgmax, amax, Hh, Hs, att, Pp, Zg, Zp, glob, part, sv_g, sv_p, rr, part2, fcraw, sv_fc, featcat, fcall,
       logits, featn, norms;
   Tensor dfeatcat, dfcraw, dpart2, dr, dglob, dZp, dZg, dPp, dGp, datt, dHs, dH, davgmax, remwork;
@@ -268,7 +292,7 @@ void Net::plan() {
   dH = alloc("dH", 3 * 2 * Bq * hid, IEEE_F32);
   davgmax = alloc("davgmax", 3 * 2 * Bq * fdim, IEEE_F32);
   remwork = alloc("", 3 * Bq + 64, IEEE_F32);
-  packtab = alloc("", (int64_t)(2 * 2 * units.size() + 8) * sizeof(PackDescHost) / 4, IEEE_F32);
+  packtab = alloc("", (int64_t)(5 * units.size() + 8) * sizeof(PackDescHost) / 4, IEEE_F32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -339,10 +363,71 @@ struct Run {
   int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0) {
     const int64_t rb = fused_bwd ? (u.M(B) + 127) / 128 : 0;
     fused_bwd = false;
+    will_write(dy);
+    if (gout) will_write(gout);
     return ieee_bn2d_bwd(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
                          F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), F(n.bnpart), F(n.bncoef), 0, mask_from_y, rb, st);
   }
+  // --- second stream for the weight gradients (see Net::side)
+  int gbuf_index(const void* p) const {
+    for (int i = 0; i < 5; ++i) if (p == (const void*)(ws + n.gbuf[i].off)) return i;
+    return -1;
+  }
+  bool side_enabled() {
+    static const bool on = !(getenv("IEEE_WGRAD_ASYNC") && atoi(getenv("IEEE_WGRAD_ASYNC")) == 0);
+    if (!on || n.profiling) return false;   // the per-launch timing table needs one ordered stream
+    if (n.side == nullptr) {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      const int prio = getenv("IEEE_SIDE_PRIO") ? atoi(getenv("IEEE_SIDE_PRIO")) : least;
+      if (hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, prio) != hipSuccess) { n.side = nullptr; return false; }
+      for (int i = 0; i < 5; ++i) (void)hipEventCreateWithFlags(&n.gbuf_read[i], hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&n.side_done, hipEventDisableTiming);
+      for (int i = 0; i < 2; ++i) (void)hipEventCreateWithFlags(&n.pack_ev[i], hipEventDisableTiming);
+    }
+    return true;
+  }
+  // the caller's stream is about to overwrite p: wait for the side-stream wgrad that still reads it
+  void will_write(const void* p) {
+    const int b = gbuf_index(p);
+    if (b < 0 || !n.gbuf_pending[b]) return;
+    (void)hipStreamWaitEvent((hipStream_t)st, n.gbuf_read[b], 0);
+    n.gbuf_pending[b] = false;
+  }
+  // every weight gradient issued so far is final for work submitted to the caller's stream after this
+  void side_join() {
+    if (!n.side_dirty) return;
+    (void)hipEventRecord(n.side_done, n.side);
+    (void)hipStreamWaitEvent((hipStream_t)st, n.side_done, 0);
+    n.side_dirty = false;
+    n.side_used = 0;
+    for (int b = 0; b < 5; ++b) n.gbuf_pending[b] = false;
+  }
   int wgrad(const ConvUnit& u, const void* dy, const void* x) {
+    if (side_enabled()) {
+      if (n.side_used == n.side_ready.size()) {
+        hipEvent_t e;
+        IEEE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        n.side_ready.push_back(e);
+      }
+      hipEvent_t ready = n.side_ready[n.side_used++];
+      IEEE_HIP(hipEventRecord(ready, (hipStream_t)st));
+      IEEE_HIP(hipStreamWaitEvent(n.side, ready, 0));
+      void* main_st = st;
+      st = (void*)n.side;
+      const int rc = wgrad_on(u, dy, x);
+      st = main_st;
+      n.side_dirty = true;
+      const int b = gbuf_index(dy);
+      if (b >= 0) {
+        IEEE_HIP(hipEventRecord(n.gbuf_read[b], n.side));
+        n.gbuf_pending[b] = true;
+      }
+      return rc;
+    }
+    return wgrad_on(u, dy, x);
+  }
+  int wgrad_on(const ConvUnit& u, const void* dy, const void* x) {
     prof_begin(1, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     if (u.Ci != u.Ci_src || u.S != u.S_src) {   // padded stem: gradient of the padded operand, then drop the padding
@@ -362,6 +447,7 @@ struct Run {
     const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.S);
     const bool fuse = prev != nullptr && n.dtype == IEEE_BF16;
     fused_bwd = fuse;
+    will_write(dx);
     prof_begin(0, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_dgrad(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
@@ -377,24 +463,48 @@ struct Run {
     for (int m = 0; m < 3; ++m) { a[m] = A + m * a_gs; b[m] = Bm + m * b_gs; c[m] = C + m * c_gs; bi[m] = bias ? bias + m * bias_gs : nullptr; }
     return ieee_sgemm_grouped(3, a, b, c, bias ? bi : nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 1.0f, relu, acc, st);
   }
-  int forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out);
-  int backward(const float* dlogits, const float* dfeats, int part = -1);
+  bool late_pack_pending = false;
+  int forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out) {
+    const int rc = forward_impl(xr, xn, xt, training, logits_out, feats_out);
+    if (late_pack_pending) {   // error before layer3: still order the side-stream packing before anything later
+      (void)hipStreamWaitEvent((hipStream_t)st, n.pack_ev[1], 0);
+      late_pack_pending = false;
+    }
+    return rc;
+  }
+  int forward_impl(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out);
+  int backward(const float* dlogits, const float* dfeats, int part = -1) {
+    const int rc = backward_impl(dlogits, dfeats, part);
+    side_join();   // also after an error: no side-stream work may outlive the call
+    return rc;
+  }
+  int backward_impl(const float* dlogits, const float* dfeats, int part);
   int backward_head(const float* dlogits, const float* dfeats);
 };
 
-int Run::forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out) {
+int Run::forward_impl(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out) {
   Net& N = n;
   const int dt = N.dtype;
   {   // one launch packs every conv weight (forward operand; + dgrad operand when training)
     char* tab_dev = ws + N.packtab.off;
     const size_t bytes_eval = N.pack_eval.size() * sizeof(PackDescHost);
+    const size_t bytes_train = N.pack_train.size() * sizeof(PackDescHost);
     if (N.pack_uploaded_ws != (const void*)ws) {
       IEEE_HIP(hipMemcpyAsync(tab_dev, N.pack_eval.data(), bytes_eval, hipMemcpyHostToDevice, (hipStream_t)st));
-      IEEE_HIP(hipMemcpyAsync(tab_dev + bytes_eval, N.pack_train.data(), N.pack_train.size() * sizeof(PackDescHost),
+      IEEE_HIP(hipMemcpyAsync(tab_dev + bytes_eval, N.pack_train.data(), bytes_train, hipMemcpyHostToDevice, (hipStream_t)st));
+      IEEE_HIP(hipMemcpyAsync(tab_dev + bytes_eval + bytes_train, N.pack_late.data(), N.pack_late.size() * sizeof(PackDescHost),
                               hipMemcpyHostToDevice, (hipStream_t)st));
       N.pack_uploaded_ws = ws;
     }
-    if (training)
+    if (training && side_enabled() && !N.pack_late.empty()) {
+      IEEE_HIP(hipEventRecord(N.pack_ev[0], (hipStream_t)st));   // parameters (and the tables) are final here
+      IEEE_HIP(hipStreamWaitEvent(N.side, N.pack_ev[0], 0));
+      IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev + bytes_eval + bytes_train, (int64_t)N.pack_late.size(),
+                                     N.pack_blocks_late, dt, (void*)N.side));
+      IEEE_HIP(hipEventRecord(N.pack_ev[1], N.side));
+      late_pack_pending = true;
+      IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev + bytes_eval, (int64_t)N.pack_late_first, N.pack_blocks_early, dt, st));
+    } else if (training)
       IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev + bytes_eval, (int64_t)N.pack_train.size(), N.pack_blocks_train,
                                      dt, st));
     else
@@ -409,6 +519,10 @@ int Run::forward(const float* xr, const float* xn, const float* xt, int training
   const void* x = P(N.pool);
   for (const Block& b : N.blocks) {   // Bottleneck.forward, resnet.py:164-184
     const ConvUnit &c1 = N.units[b.c1], &c2 = N.units[b.c2], &c3 = N.units[b.c3];
+    if (late_pack_pending && b.c1 >= N.pack_late_unit) {   // first layer3 block: its operands come from the side stream
+      IEEE_HIP(hipStreamWaitEvent((hipStream_t)st, N.pack_ev[1], 0));
+      late_pack_pending = false;
+    }
     const bool ws_ = training != 0;
     IEEE_TRY(conv(c1, x, ws_));
     IEEE_TRY(bn(c1, nullptr, P(c1.a), 1, training));
@@ -522,7 +636,7 @@ int Run::forward(const float* xr, const float* xn, const float* xt, int training
 // part -1: everything.  part 0: head + CIM (leaves d(trunk output) in gbuf[0]); parts 1..4: the bottleneck blocks
 // of layer4, layer3, layer2, layer1 (+ stem), in that order.  After part p every parameter gradient of that part
 // is final, so a data-parallel caller can start all-reducing it while the next part runs.
-int Run::backward(const float* dlogits, const float* dfeats, int part) {
+int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
   Net& N = n;
   const int dt = N.dtype;
   if (part <= 0) IEEE_TRY(backward_head(dlogits, dfeats));
@@ -562,6 +676,7 @@ int Run::backward(const float* dlogits, const float* dfeats, int part) {
   if (lo > 0) return IEEE_OK;
   // stem: maxpool -> ReLU/BN -> conv wgrad (no dgrad: the input is the image)
   const ConvUnit& s = N.units[N.u_stem];
+  will_write(Q);
   IEEE_TRY(ieee_maxpool3x3s2_bwd(X, (const uint8_t*)P(N.pool_arg), Q, dt, 3, B, s.Ho, s.Wo, s.Co, st));
   IEEE_TRY(bn_bwd(s, Q, nullptr, Q, nullptr, 1));
   IEEE_TRY(wgrad(s, Q, P(N.x0)));
@@ -779,6 +894,28 @@ extern "C" int ieee_net_bind(void* handle, float* params, float* grads, float* b
       }
     }
     (training ? n->pack_blocks_train : n->pack_blocks_eval) = blocks;
+  }
+  {   // split of the training table at the first layer3 unit
+    n->pack_late_unit = n->blocks.size() > 7 ? n->blocks[7].c1 : (int)n->units.size();
+    n->pack_late.clear();
+    n->pack_late_first = (int)n->pack_train.size();
+    size_t ti = 0;
+    for (size_t ui = 0; ui < n->units.size(); ++ui) {
+      const ConvUnit& u = n->units[ui];
+      const bool used = n->interaction || ((int)ui != n->u_one && (int)ui != n->u_rest);
+      if (!used) continue;
+      const int nd = u.need_dgrad ? 2 : 1;
+      if ((int)ui >= n->pack_late_unit && n->pack_late_first == (int)n->pack_train.size()) n->pack_late_first = (int)ti;
+      ti += nd;
+    }
+    n->pack_blocks_early = n->pack_late_first < (int)n->pack_train.size() ? n->pack_train[n->pack_late_first].block_begin
+                                                                          : n->pack_blocks_train;
+    for (size_t i = n->pack_late_first; i < n->pack_train.size(); ++i) {
+      PackDescHost d = n->pack_train[i];
+      d.block_begin -= n->pack_blocks_early;
+      n->pack_late.push_back(d);
+    }
+    n->pack_blocks_late = n->pack_blocks_train - n->pack_blocks_early;
   }
   n->pack_uploaded_ws = nullptr;
   return IEEE_OK;
