@@ -97,11 +97,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, 
 
 // sum the per-row-block partials of channel c: 32 lanes stride over the row blocks, then a shuffle tree.
 // block = 8 channels x 32 lanes; returns the totals in every lane of the channel's 32-lane group.
-__device__ __forceinline__ void sum_partials(const float* p, int rblocks, int C, int c, int lane32, double& s1,
-                                             double& s2) {
+// transposed = 0: p[rblock][2][C] (the reduction kernels of this file); 1: p[2][C][rblocks] (conv epilogues)
+__device__ __forceinline__ void sum_partials(const float* p, int rblocks, int C, int c, int lane32, int transposed,
+                                             double& s1, double& s2) {
   double a1 = 0.0, a2 = 0.0;
-  if (c < C)
-    for (int r = lane32; r < rblocks; r += 32) { a1 += p[(int64_t)r * 2 * C + c]; a2 += p[(int64_t)r * 2 * C + C + c]; }
+  if (c < C) {
+    if (transposed) {
+      const float* p1 = p + (int64_t)c * rblocks;
+      const float* p2 = p1 + (int64_t)C * rblocks;
+      for (int r = lane32; r < rblocks; r += 32) { a1 += p1[r]; a2 += p2[r]; }
+    } else {
+      for (int r = lane32; r < rblocks; r += 32) { a1 += p[(int64_t)r * 2 * C + c]; a2 += p[(int64_t)r * 2 * C + C + c]; }
+    }
+  }
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
   s1 = a1; s2 = a2;
@@ -113,12 +121,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
                                                           int C, const float* gamma, const float* beta,
                                                           int64_t param_gs, float* running_mean, float* running_var,
                                                           int64_t buf_gs, float* stats, int64_t stats_gs,
-                                                          float momentum, float eps, int training) {
+                                                          float momentum, float eps, int training, int transposed) {
   const int lane32 = threadIdx.x & 31;
   const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int z = blockIdx.y;
   double s1 = 0.0, s2 = 0.0;
-  if (training) sum_partials(partial + z * partial_gs, rblocks, C, c, lane32, s1, s2);
+  if (training) sum_partials(partial + z * partial_gs, rblocks, C, c, lane32, transposed, s1, s2);
   if (c >= C || lane32 != 0) return;
   const float ga = gamma[z * param_gs + c], be = beta[z * param_gs + c];
   float* st = stats + z * stats_gs;
@@ -212,12 +220,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
                                                               int M, int C, const float* gamma, int64_t param_gs,
                                                               const float* stats, int64_t stats_gs, float* dgamma,
                                                               float* dbeta, int64_t grad_gs, float* coef,
-                                                              int64_t coef_gs, int accumulate) {
+                                                              int64_t coef_gs, int accumulate, int transposed) {
   const int lane32 = threadIdx.x & 31;
   const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int z = blockIdx.y;
   double s1, s2;
-  sum_partials(partial + z * partial_gs, rblocks, C, c, lane32, s1, s2);
+  sum_partials(partial + z * partial_gs, rblocks, C, c, lane32, transposed, s1, s2);
   if (c >= C || lane32 != 0) return;
   const float* st = stats + z * stats_gs;
   const double mean = st[c], invstd = st[C + c];
@@ -316,7 +324,7 @@ extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int
   }
   bn_finalize_kernel<<<dim3(cdiv(C, 8), (unsigned)groups), 256, 0, st>>>(
       partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, beta, param_gs, running_mean, running_var, buf_gs, stats,
-      4 * C, momentum, eps, training);
+      4 * C, momentum, eps, training, stats_rblocks > 0 ? 1 : 0);
   IEEE_TRY(launch_status("bn_finalize_kernel"));
   if (out == nullptr) return IEEE_OK;   // statistics only: the consumer applies scale/shift itself
   const int64_t chunks = M * C / vec_of(dtype);
@@ -353,7 +361,7 @@ extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void*
   IEEE_TRY(launch_status("bn_bwd_reduce_kernel"));
   bn_bwd_finalize_kernel<<<dim3(cdiv(C, 8), (unsigned)groups), 256, 0, st>>>(
       partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, param_gs, stats, 4 * C, dgamma, dbeta, grad_gs, coef,
-      3 * C, accumulate);
+      3 * C, accumulate, stats_rblocks > 0 ? 1 : 0);
   IEEE_TRY(launch_status("bn_bwd_finalize_kernel"));
   const int64_t chunks = M * C / vec_of(dtype);
   dim3 grid(ew_blocks(chunks), (unsigned)groups);

@@ -12,9 +12,6 @@
 
 namespace ieee {
 
-// LDS-DMA staging (gemm_nt_dma / gemm_tn_dma) measured equal to register staging on isolated launches and
-// ~8 % slower inside the full step (profiles/r01 notes); kept selectable for the next tuning round.
-constexpr bool kUseDma = false;
 
 __device__ __forceinline__ void tile_map_xy(int tiles_m, int tiles_n, int group, int& tm, int& tn) {
   const int nwg = tiles_m * tiles_n;
@@ -65,15 +62,16 @@ template <typename T> struct StoreEpi {
 // instruction covers 4 rows x 256 B) instead of 8-byte pieces scattered over 16 rows.  Optionally adds a
 // residual tensor and, for a conv that feeds a train-mode BatchNorm, emits the tile's per-channel
 // sum / sum-of-squares (of the ROUNDED stored values) so that no separate statistics pass is needed:
-// bn_partial[group][tile_m][2][N].
+// bn_partial[group][2][N][tiles_m] (row tiles innermost: the finalize kernel reads one channel's partials as
+// one contiguous run instead of a stride-2N walk, which took 15-70 us on the 1024-4096 row tiles of layer1/stem).
 template <typename T, int MODE> struct StagedStoreEpi {
   static constexpr bool kStaged = true;
   static constexpr bool STATS = MODE != 0;
   T* out;
   const T* addend;
-  float* bn_partial;   // this group's [tiles_m][2][N] block (MODE 1: sum v, sum v^2; MODE 2: sum g, sum g*y)
+  float* bn_partial;   // this group's [2][N][tiles_m] block (MODE 1: sum v, sum v^2; MODE 2: sum g, sum g*y)
   int64_t ld;
-  int M, N, tile_m;
+  int M, N, tile_m, tiles_m;
   // MODE 2 (dgrad feeding the BatchNorm backward of the PREVIOUS unit): g = v * [relu mask]; the mask comes from
   // the stored activation (bmask) or is recomputed from y and that unit's scale/shift (bstats = [4][N])
   const T* by;
@@ -159,7 +157,7 @@ template <typename T, int MODE> struct StagedStoreEpi {
         const int cc = c / VEC, e = c % VEC;
         float s = 0.f;
         for (int y = 0; y < RPP; ++y) s += red[(y * CPRW + cc) * 2 * VEC + q * VEC + e];
-        if (n0 + c < N) bn_partial[((int64_t)tile_m * 2 + q) * N + n0 + c] = s;
+        if (n0 + c < N) bn_partial[((int64_t)q * N + n0 + c) * tiles_m + tile_m] = s;
       }
     }
   }
@@ -200,7 +198,10 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
 };
 
 // (forcing 4 waves per SIMD here spills 80 VGPRs and is 2.5x slower; the default allocation gives 3)
-template <typename T, int BN, bool SLOW, int MODE>
+// PIPE = 0: register staging, one LDS stage (high occupancy: the many-workgroup layers).  PIPE = 2..4: LDS-DMA ring
+// of PIPE stages with PIPE-1 k-tiles in flight (few-workgroup layers, where no co-resident workgroup hides the
+// load latency of a one-tile-deep pipeline); bf16 fast path only.
+template <typename T, int BN, bool SLOW, int MODE, int PIPE = 0>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
                                                           T* __restrict__ dst, const T* __restrict__ addend,
                                                           float* __restrict__ bn_partial, ConvArgs a, BwdStats bs) {
@@ -213,19 +214,20 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ 
   w += z * a.w_gs;
   dst += z * a.dst_gs;
   if (addend != nullptr) addend += z * a.dst_gs;
-  StagedStoreEpi<T, MODE> epi{dst, addend, MODE ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm,
+  StagedStoreEpi<T, MODE> epi{dst, addend, MODE ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
                               MODE == 2 ? (const T*)bs.y + z * bs.act_gs : nullptr,
                               (MODE == 2 && bs.mask) ? (const T*)bs.mask + z * bs.act_gs : nullptr,
                               (MODE == 2 && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
-  if constexpr (kUseDma && !SLOW && sizeof(T) == 2) {   // bf16 fast path: both operands through LDS-DMA
+  if constexpr (PIPE > 0) {   // both operands through LDS-DMA
+    static_assert(!SLOW && sizeof(T) == 2, "the LDS-DMA ring is the bf16 vector path");
     const int ch = nt_dma_chunk(threadIdx.x);
     LoaderPlainNT<T, BN / 32> lbd;
     lbd.init(w, a.ldw, n0, a.N, a.ldw, ch);
     LoaderIm2colNT<T, 4> la;
     la.init(src, a.g, m0, ch);
-    gemm_nt_dma<128, BN, DMA_STAGES>(la, lbd, epi, a.ktiles, m0, n0, smem);
+    gemm_nt_dma<128, BN, PIPE>(la, lbd, epi, a.ktiles, m0, n0, smem);
     return;
-  }
+  } else {
   LoaderPlainNT<T, BN / 32> lb;
   lb.init(w, a.ldw, n0, a.N, a.ldw);
   if constexpr (SLOW) {
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ 
     LoaderIm2colNT<T, 4> la;
     la.init(src, a.g, m0);
     gemm_nt<T, 128, BN, (sizeof(T) == 2 ? 1 : 2)>(la, lb, epi, a.ktiles, m0, n0, smem, a.dbg & 1);
+  }
   }
 }
 
@@ -249,18 +252,30 @@ struct WgradArgs {
 
 // 3 waves per SIMD (148 VGPRs, no spill) instead of the 2 the default allocation settles on: +5-10 %
 #define WGRAD_BOUNDS __launch_bounds__(256, 3)
-template <typename T, bool SLOW>
+template <typename T, bool SLOW, int PIPE = 0>
 __global__ WGRAD_BOUNDS void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          float* __restrict__ slab, WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware order: every tile of one (k-split, modality) reads the same pixel range of dY and X, so all of
   // them go to ONE XCD (blocks b, b+8, ... share an XCD/L2) and that range is fetched into one L2 only.
   int kzi, tile;
-  if (a.xcd_group) {
+  if (a.xcd_group == 1) {
     const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
     kzi = (j / a.tiles) * 8 + xcd;
     tile = j % a.tiles;
-  } else {   // few (split, modality) groups: grouping them per XCD would unbalance the 8 XCDs
+  } else if (a.xcd_group == 2) {
+    // few (split, modality) groups: each XCD takes one contiguous eighth of the (group, tile) list, and inside a
+    // group the tiles are walked in bands of 8 m-tiles, so the ~100 workgroups resident on one XCD form a compact
+    // 2-D patch of the tile grid and share their dY / X panels in that XCD's L2
+    const int total = a.tiles * a.nsplit * a.groups;
+    const int bid = blockIdx.x, xcd = bid & 7, q = total >> 3, r = total & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    kzi = lin / a.tiles;
+    tile = lin - kzi * a.tiles;
+    const int tiles_m = a.tiles / a.tiles_n, per = 8 * a.tiles_n;
+    const int gi = tile / per, first = gi * 8, gsz = min(tiles_m - first, 8), in = tile - gi * per;
+    tile = (first + in % gsz) * a.tiles_n + in / gsz;
+  } else {
     kzi = blockIdx.x / a.tiles;
     tile = blockIdx.x % a.tiles;
   }
@@ -274,13 +289,14 @@ __global__ WGRAD_BOUNDS void conv_wgrad_kernel(const T* __restrict__ dy, const T
   const int kbeg = ks * a.kchunk, kend = min(a.npix, kbeg + a.kchunk);
   const int ktiles = (kend - kbeg + ImgTN<T>::BK - 1) / ImgTN<T>::BK;
   SlabEpi epi{slab, a.ncols, a.Co, a.ncols};
-  if constexpr (kUseDma && !SLOW && sizeof(T) == 2) {
+  if constexpr (PIPE > 0) {   // LDS-DMA ring (see conv_gather_kernel)
+    static_assert(!SLOW && sizeof(T) == 2, "the LDS-DMA ring is the bf16 vector path");
     const int ch = tn_dma_chunk(threadIdx.x);
     LoaderColsTN<T> lad;
     lad.init(dy, a.Co, m0, a.Co, kbeg, kend, ch);
     LoaderIm2colTN<T> lbd;
     lbd.init(x, a.g, n0, kbeg, kend, ch);
-    gemm_tn_dma<DMA_STAGES>(lad, lbd, epi, ktiles, m0, n0, smem);
+    gemm_tn_dma<PIPE>(lad, lbd, epi, ktiles, m0, n0, smem);
     return;
   }
   LoaderColsTN<T> la;
@@ -445,6 +461,43 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 
 template <typename T> static int conv_bk() { return ImgNT<T>::BK; }
 
+// one instantiation of the gather kernel; > 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
+template <typename T, int BN, bool SLOW, int MODE, int PIPE>
+static void launch_gather_inst(dim3 grid, size_t smem, hipStream_t st, const T* src, const T* w, T* dst, const T* addend,
+                               float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, BN, SLOW, MODE, PIPE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  conv_gather_kernel<T, BN, SLOW, MODE, PIPE><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
+}
+
+template <typename T, int BN, int PIPE>
+static void launch_gather_mode(int mode, dim3 grid, size_t smem, hipStream_t st, const T* src, const T* w, T* dst,
+                               const T* addend, float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
+  if (mode == 2) launch_gather_inst<T, BN, false, 2, PIPE>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
+  else if (mode == 1) launch_gather_inst<T, BN, false, 1, PIPE>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
+  else launch_gather_inst<T, BN, false, 0, PIPE>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
+}
+
+// Tile / pipeline choice of one gather launch (bf16 vector path).  wgs = workgroups of the 128x128 tiling.
+struct GatherPlan { int bn, pipe; };
+static GatherPlan plan_gather(int M, int N, int ktiles, int groups) {
+  GatherPlan p{N <= 64 ? 64 : 128, 0};
+  static const int f_pipe = getenv("IEEE_GATHER_PIPE") ? atoi(getenv("IEEE_GATHER_PIPE")) : -1;
+  static const int f_narrow = getenv("IEEE_GATHER_NARROW") ? atoi(getenv("IEEE_GATHER_NARROW")) : -1;
+  static const int f_maxwg = getenv("IEEE_GATHER_MAXWG") ? atoi(getenv("IEEE_GATHER_MAXWG")) : 1 << 30;
+  const int64_t wgs = (int64_t)cdiv(M, 128) * cdiv(N, 128) * groups;
+  if (wgs <= f_maxwg) {   // tuning overrides apply to launches of at most IEEE_GATHER_MAXWG workgroups
+    if (f_narrow == 1) p.bn = 64;
+    if (f_pipe >= 0) p.pipe = f_pipe;
+  }
+  if (ktiles < 2) p.pipe = 0;
+  return p;
+}
+
 template <typename T>
 static int launch_gather(const T* src, const T* w, T* dst, const T* addend, const GatherGeom& g, int M, int N,
                          int Ktrue, int ldw, int groups, int64_t src_gs, int64_t w_gs, int64_t dst_gs, bool slow,
@@ -462,27 +515,21 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   a.w_gs = w_gs;
   a.dst_gs = dst_gs;
   a.tiles_m = cdiv(M, 128);
-  const bool narrow = N <= 64;
-  a.tiles_n = cdiv(N, narrow ? 64 : 128);
+  GatherPlan plan{N <= 64 ? 64 : 128, 0};
+  if (sizeof(T) == 2 && !slow) plan = plan_gather(M, N, a.ktiles, groups);
+  const bool narrow = plan.bn == 64;
+  a.tiles_n = cdiv(N, plan.bn);
   dim3 grid(a.tiles_m * a.tiles_n, groups);
-  const bool dma = kUseDma && !slow && sizeof(T) == 2;             // bf16 fast path: DMA_STAGES-deep LDS ring
-  const int stages = dma ? DMA_STAGES : (sizeof(T) == 2 ? 1 : 2);   // bf16: single LDS stage (see gemm_nt)
-  size_t smem = (size_t)stages * (128 + (narrow ? 64 : 128)) * 128;
+  const int stages = plan.pipe ? plan.pipe : (sizeof(T) == 2 ? 1 : 2);   // bf16: single LDS stage (see gemm_nt)
+  size_t smem = (size_t)stages * (128 + plan.bn) * 128;
   {   // the LDS-staged epilogue needs the C tile: bf16 rows padded by 16 B, fp32 rows unpadded
-    const size_t bn = narrow ? 64 : 128;
+    const size_t bn = plan.bn;
     const size_t epi_bytes = 128 * (bn * sizeof(T) + (sizeof(T) == 2 ? 16 : 0));
     const size_t red_bytes = 16 * 1024;   // BN-sum reduction scratch
     if (smem < epi_bytes) smem = epi_bytes;
     if (smem < red_bytes) smem = red_bytes;
   }
   if (const char* e = getenv("IEEE_DBG_LDS")) smem = (size_t)atoi(e);   // occupancy experiments
-  static bool attr_done = false;
-  if (!attr_done) {   // > 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
-    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, 128, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, 128, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, 128, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
   const bool stats = bn_partial != nullptr;
   if (stats && (slow || sizeof(T) != 2)) {
     set_error(IEEE_ERR_UNSUPPORTED, "conv: fused BN statistics need the bf16 vector path");
@@ -490,16 +537,32 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   }
   BwdStats bs{nullptr, nullptr, nullptr, 0, 0};
   if (bwd) bs = *bwd;
-  if (narrow) {
-    if (slow) conv_gather_kernel<T, 64, true, 0><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a, bs);
-    else if (stats && bwd) conv_gather_kernel<T, 64, false, 2><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
-    else if (stats) conv_gather_kernel<T, 64, false, 1><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
-    else conv_gather_kernel<T, 64, false, 0><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a, bs);
+  const int mode = (stats && bwd) ? 2 : (stats ? 1 : 0);
+  if (slow) {
+    if (narrow) launch_gather_inst<T, 64, true, 0, 0>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
+    else launch_gather_inst<T, 128, true, 0, 0>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
+  } else if constexpr (sizeof(T) == 2) {
+#define IEEE_GATHER_CASE(BN_, PIPE_) \
+    launch_gather_mode<T, BN_, PIPE_>(mode, grid, smem, st, src, w, dst, addend, bn_partial, a, bs)
+    if (narrow) {
+      switch (plan.pipe) {
+        case 2: IEEE_GATHER_CASE(64, 2); break;
+        case 3: IEEE_GATHER_CASE(64, 3); break;
+        case 4: IEEE_GATHER_CASE(64, 4); break;
+        default: IEEE_GATHER_CASE(64, 0); break;
+      }
+    } else {
+      switch (plan.pipe) {
+        case 2: IEEE_GATHER_CASE(128, 2); break;
+        case 3: IEEE_GATHER_CASE(128, 3); break;
+        case 4: IEEE_GATHER_CASE(128, 4); break;
+        default: IEEE_GATHER_CASE(128, 0); break;
+      }
+    }
+#undef IEEE_GATHER_CASE
   } else {
-    if (slow) conv_gather_kernel<T, 128, true, 0><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a, bs);
-    else if (stats && bwd) conv_gather_kernel<T, 128, false, 2><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
-    else if (stats) conv_gather_kernel<T, 128, false, 1><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
-    else conv_gather_kernel<T, 128, false, 0><<<grid, 256, smem, st>>>(src, w, dst, addend, nullptr, a, bs);
+    if (narrow) launch_gather_mode<T, 64, 0>(mode, grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
+    else launch_gather_mode<T, 128, 0>(mode, grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
   }
   return launch_status("conv_gather_kernel");
 }
@@ -699,13 +762,16 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   const bool slow = (Ci % elem_vec(dtype)) != 0;
   a.plain_x = (d.R == 1 && d.S == 1 && d.stride == 1 && d.pad == 0) ? 1 : 0;
   const int nkz = nsplit * (int)groups;
-  a.xcd_group = (nkz >= 24 || nkz % 8 == 0) ? 1 : 0;
-  dim3 grid((unsigned)(a.tiles * (a.xcd_group ? cdiv(nkz, 8) * 8 : nkz)));
-  const size_t smem = (kUseDma && dtype == IEEE_BF16 && !slow) ? (size_t)DMA_STAGES * 32 * 1024
-                                                               : (dtype == IEEE_BF16 ? 32 * 1024 : 64 * 1024);
+  static const int f_map = getenv("IEEE_WGRAD_MAP") ? atoi(getenv("IEEE_WGRAD_MAP")) : 2;
+  a.xcd_group = (nkz >= 24 || nkz % 8 == 0) ? 1 : f_map;
+  dim3 grid((unsigned)(a.tiles * (a.xcd_group == 1 ? cdiv(nkz, 8) * 8 : nkz)));
+  static const int f_pipe = getenv("IEEE_WGRAD_PIPE") ? atoi(getenv("IEEE_WGRAD_PIPE")) : 0;
+  const int pipe = (dtype == IEEE_BF16 && !slow) ? f_pipe : 0;
+  const size_t smem = pipe ? (size_t)pipe * 32 * 1024 : (dtype == IEEE_BF16 ? 32 * 1024 : 64 * 1024);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -715,6 +781,9 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
     else conv_wgrad_kernel<float, false><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
   } else if (dtype == IEEE_BF16) {
     if (slow) conv_wgrad_kernel<bf16, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
+    else if (pipe == 2) conv_wgrad_kernel<bf16, false, 2><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
+    else if (pipe == 3) conv_wgrad_kernel<bf16, false, 3><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
+    else if (pipe == 4) conv_wgrad_kernel<bf16, false, 4><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
     else conv_wgrad_kernel<bf16, false><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
   } else {
     IEEE_REQUIRE(false, "conv2d_wgrad: bad dtype %d", dtype);

@@ -266,9 +266,19 @@ __device__ __attribute__((aligned(16))) static const unsigned int g_zero_page[4]
 
 __device__ __forceinline__ const void* zero_page() { return (const void*)g_zero_page; }
 
+// Issued from inline asm on purpose: for an LDS-DMA issued through __builtin_amdgcn_global_load_lds hipcc waits
+// vmcnt(0) before the next ds_read of ANY LDS address (it cannot tell the ring stages apart), which drains the
+// whole ring every k-tile.  Hidden in asm, the DMA is ordered by the counted s_waitcnt vmcnt(N) + s_barrier of
+// the cores below and nothing else.  M0 carries the wave-uniform LDS byte address; it is compiler-reserved, so
+// it is saved and restored inside the statement.
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+  const unsigned dst =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
 }
 
 // NT logical chunk of thread t (same for every slot: rows advance by 32, the key (row>>1)&7 does not change)

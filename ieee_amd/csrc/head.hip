@@ -20,55 +20,99 @@ struct SgemmArgs {
   int64_t sam, sak, sbn, sbk, ldc;
   float alpha;
   int relu, accumulate;
+  // split-K (long K, few tiles: the pooled-vector GEMMs of the head): block z = group * splitk + ks works on
+  // k in [ks*kchunk, +kchunk) and stores its raw partial tile to slab[z][M][N]; sgemm_splitk_reduce_kernel adds the
+  // slabs in a fixed order and applies alpha / bias / accumulate / relu
+  int splitk, kchunk, vec_a, vec_b;
+  float* slab;
 };
 
+// 64x64 tile, BK = 32, fp32 MFMA 16x16x4.  Operand tiles are fetched as two 16-byte vectors per thread along
+// whichever axis is contiguous (vec_* = 1: k contiguous, 2: row contiguous, 0: scalar fallback for unaligned or
+// generic strides) and kept one k-tile ahead in registers.
 __global__ __launch_bounds__(256) void sgemm_grouped_kernel(SgemmArgs a) {
-  __shared__ float As[2][64][17];
-  __shared__ float Bs[2][64][17];
-  const int g = blockIdx.z;
+  __shared__ float As[2][64][33];
+  __shared__ float Bs[2][64][33];
+  const int g = blockIdx.z / a.splitk, ks = blockIdx.z - g * a.splitk;
   const float* A = (const float*)a.A.p[g];
   const float* B = (const float*)a.B.p[g];
-  float* C = (float*)a.C.p[g];
-  const float* bias = (const float*)a.bias.p[g];
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-  // element -> thread mapping chosen so the contiguous axis runs across lanes
-  const bool a_kc = a.sak == 1, b_kc = a.sbk == 1;
-  int ar[4], ak[4], br[4], bk[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (a_kc) { ak[i] = t & 15; ar[i] = (t >> 4) + 16 * i; } else { ar[i] = t & 63; ak[i] = (t >> 6) + 4 * i; }
-    if (b_kc) { bk[i] = t & 15; br[i] = (t >> 4) + 16 * i; } else { br[i] = t & 63; bk[i] = (t >> 6) + 4 * i; }
-  }
+  const int kbeg = ks * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+  const int ktiles = (kend - kbeg + 31) / 32;
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ra[4], rb[4];
-  const int ktiles = (a.K + 15) / 16;
-  auto gload = [&](int kt) {
+  float ra[8], rb[8];
+  // element e (0..7) of this thread: vec 1 -> row = (t>>3) + 32*(e>>2), k = (t&7)*4 + (e&3)
+  //                                  vec 2 -> k = (t>>4) + 16*(e>>2), row = (t&15)*4 + (e&3)
+  //                                  vec 0 -> row = t & 63, k = (t>>6) + 4*e
+  auto fetch = [&](const float* P, int vec, int64_t srow, int64_t sk, int row0, int nrows, int kt, float* r) {
+    const int k0 = kbeg + kt * 32;
+    if (vec == 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + ar[i], k = kt * 16 + ak[i];
-      ra[i] = (m < a.M && k < a.K) ? A[m * a.sam + k * a.sak] : 0.f;
-      const int n = n0 + br[i], k2 = kt * 16 + bk[i];
-      rb[i] = (n < a.N && k2 < a.K) ? B[n * a.sbn + k2 * a.sbk] : 0.f;
+      for (int h = 0; h < 2; ++h) {
+        const int row = row0 + (t >> 3) + 32 * h, k = k0 + (t & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nrows && k + 3 < kend) v = *(const float4*)(P + row * srow + k);
+        else if (row < nrows) {
+          if (k < kend) v.x = P[row * srow + k];
+          if (k + 1 < kend) v.y = P[row * srow + k + 1];
+          if (k + 2 < kend) v.z = P[row * srow + k + 2];
+        }
+        r[4 * h] = v.x; r[4 * h + 1] = v.y; r[4 * h + 2] = v.z; r[4 * h + 3] = v.w;
+      }
+    } else if (vec == 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = k0 + (t >> 4) + 16 * h, row = row0 + (t & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < kend && row + 3 < nrows) v = *(const float4*)(P + k * sk + row);
+        else if (k < kend) {
+          if (row < nrows) v.x = P[k * sk + row];
+          if (row + 1 < nrows) v.y = P[k * sk + row + 1];
+          if (row + 2 < nrows) v.z = P[k * sk + row + 2];
+        }
+        r[4 * h] = v.x; r[4 * h + 1] = v.y; r[4 * h + 2] = v.z; r[4 * h + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = row0 + (t & 63), k = k0 + (t >> 6) + 4 * e;
+        r[e] = (row < nrows && k < kend) ? P[row * srow + k * sk] : 0.f;
+      }
     }
   };
-  auto sstore = [&](int buf) {
+  auto stash = [&](float (*S)[33], int vec, const float* r) {
+    if (vec == 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { As[buf][ar[i]][ak[i]] = ra[i]; Bs[buf][br[i]][bk[i]] = rb[i]; }
+      for (int e = 0; e < 8; ++e) S[(t >> 3) + 32 * (e >> 2)][(t & 7) * 4 + (e & 3)] = r[e];
+    } else if (vec == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) S[(t & 15) * 4 + (e & 3)][(t >> 4) + 16 * (e >> 2)] = r[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) S[t & 63][(t >> 6) + 4 * e] = r[e];
+    }
   };
-  gload(0);
-  sstore(0);
+  if (ktiles > 0) {
+    fetch(A, a.vec_a, a.sam, a.sak, m0, a.M, 0, ra);
+    fetch(B, a.vec_b, a.sbn, a.sbk, n0, a.N, 0, rb);
+    stash(As[0], a.vec_a, ra);
+    stash(Bs[0], a.vec_b, rb);
+  }
   __syncthreads();
   for (int kt = 0; kt < ktiles; ++kt) {
     const int cur = kt & 1;
     const bool has_next = kt + 1 < ktiles;
-    if (has_next) gload(kt + 1);
+    if (has_next) {
+      fetch(A, a.vec_a, a.sam, a.sak, m0, a.M, kt + 1, ra);
+      fetch(B, a.vec_b, a.sbn, a.sbk, n0, a.N, kt + 1, rb);
+    }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < 8; ++kk) {
       float fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) fa[i] = As[cur][wm * 32 + i * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
@@ -79,9 +123,29 @@ __global__ __launch_bounds__(256) void sgemm_grouped_kernel(SgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
     }
-    if (has_next) sstore(cur ^ 1);
+    if (has_next) {
+      stash(As[cur ^ 1], a.vec_a, ra);
+      stash(Bs[cur ^ 1], a.vec_b, rb);
+    }
     __syncthreads();
   }
+  if (a.splitk > 1) {
+    float* S = a.slab + (int64_t)blockIdx.z * a.M * a.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm * 32 + i * 16 + (lane & 15);
+        const int n = n0 + wn * 32 + j * 16 + (lane >> 4) * 4;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) S[(int64_t)m * a.N + n + r] = acc[i][j][r];
+      }
+    return;
+  }
+  float* C = (float*)a.C.p[g];
+  const float* bias = (const float*)a.bias.p[g];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -100,6 +164,32 @@ __global__ __launch_bounds__(256) void sgemm_grouped_kernel(SgemmArgs a) {
         *c = v;
       }
     }
+}
+
+__global__ __launch_bounds__(256) void sgemm_splitk_reduce_kernel(SgemmArgs a) {
+  const int g = blockIdx.y;
+  const int64_t mn = (int64_t)a.M * a.N;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mn) return;
+  const float* S = a.slab + (int64_t)g * a.splitk * mn + i;
+  float s = 0.f;
+  for (int k = 0; k < a.splitk; ++k) s += S[k * mn];
+  const int m = (int)(i / a.N), n = (int)(i - (int64_t)m * a.N);
+  float v = a.alpha * s;
+  const float* bias = (const float*)a.bias.p[g];
+  if (bias) v += bias[n];
+  float* c = (float*)a.C.p[g] + (int64_t)m * a.ldc + n;
+  if (a.accumulate) v += *c;
+  if (a.relu) v = fmaxf(v, 0.f);
+  *c = v;
+}
+
+// zero up to MAXG float spans in one launch (hipMemsetAsync splits every odd-sized span into 3 kernels)
+struct ZeroArgs { PtrTab p; int64_t n[MAXG]; };
+__global__ void zero_spans_kernel(ZeroArgs a) {
+  float* p = (float*)a.p.p[blockIdx.y];
+  const int64_t n = a.n[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
 }
 
 // column sums (bias gradients): out[g][n] (+)= sum_m X[g](m,n)
@@ -129,27 +219,42 @@ struct RowBnArgs {
   float momentum, eps;
   int training, relu;
 };
+// block = RB_TX channels x RB_TY row lanes: the batch is only 64..384 rows, so the row loop is short and many
+// blocks (C/16 per problem) run side by side (64 x 4 took 50-85 us per launch on latency alone)
+constexpr int RB_TX = 16, RB_TY = 16;
+__device__ __forceinline__ float rb_sum(float (*red)[RB_TX], int tx) {
+  float s = 0.f;
+#pragma unroll
+  for (int y = 0; y < RB_TY; ++y) s += red[y][tx];
+  return s;
+}
 __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnArgs a) {
-  __shared__ float red[4][64];
+  __shared__ float red[RB_TY][RB_TX];
   const int g = blockIdx.y;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
+  const int tx = threadIdx.x % RB_TX, ty = threadIdx.x / RB_TX;
+  const int c = blockIdx.x * RB_TX + tx;
   const bool ok = c < a.C;
   const float* x = (const float*)a.x.p[g];
   float* out = (float*)a.out.p[g];
   float mean, invstd;
   if (a.training) {
     float s = 0.f;
-    if (ok) for (int r = ty; r < a.R; r += 4) s += x[(int64_t)r * a.ldx + c];
+    if (ok) {
+#pragma unroll 4
+      for (int r = ty; r < a.R; r += RB_TY) s += x[(int64_t)r * a.ldx + c];
+    }
     red[ty][tx] = s;
     __syncthreads();
-    mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / a.R;
+    mean = rb_sum(red, tx) / a.R;
     __syncthreads();
     float v = 0.f;
-    if (ok) for (int r = ty; r < a.R; r += 4) { const float d = x[(int64_t)r * a.ldx + c] - mean; v += d * d; }
+    if (ok) {
+#pragma unroll 4
+      for (int r = ty; r < a.R; r += RB_TY) { const float d = x[(int64_t)r * a.ldx + c] - mean; v += d * d; }
+    }
     red[ty][tx] = v;
     __syncthreads();
-    const float var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / a.R;
+    const float var = rb_sum(red, tx) / a.R;
     invstd = 1.0f / sqrtf(var + a.eps);
     if (ok && ty == 0) {
       float* rm = (float*)a.rmean.p[g];
@@ -167,7 +272,8 @@ __global__ __launch_bounds__(256) void rowbn_fwd_kernel(RowBnArgs a) {
   if (!ok) return;
   if (ty == 0 && a.save.p[g]) { float* sv = (float*)a.save.p[g]; sv[c] = mean; sv[a.C + c] = invstd; }
   const float ga = ((const float*)a.gamma.p[g])[c], be = ((const float*)a.beta.p[g])[c];
-  for (int r = ty; r < a.R; r += 4) {
+#pragma unroll 4
+  for (int r = ty; r < a.R; r += RB_TY) {
     float v = (x[(int64_t)r * a.ldx + c] - mean) * invstd * ga + be;
     if (a.relu) v = fmaxf(v, 0.f);
     out[(int64_t)r * a.ldo + c] = v;
@@ -181,10 +287,10 @@ struct RowBnBwdArgs {
   int relu, accumulate;
 };
 __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwdArgs a) {
-  __shared__ float red[2][4][64];
+  __shared__ float red[2][RB_TY][RB_TX];
   const int g = blockIdx.y;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
+  const int tx = threadIdx.x % RB_TX, ty = threadIdx.x / RB_TX;
+  const int c = blockIdx.x * RB_TX + tx;
   const bool ok = c < a.C;
   const float* dout = (const float*)a.dout.p[g];
   const float* out = (const float*)a.out.p[g];
@@ -192,18 +298,20 @@ __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwdArgs a) {
   const float* sv = (const float*)a.save.p[g];
   const float mean = ok ? sv[c] : 0.f, invstd = ok ? sv[a.C + c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  if (ok)
-    for (int r = ty; r < a.R; r += 4) {
+  if (ok) {
+#pragma unroll 4
+    for (int r = ty; r < a.R; r += RB_TY) {
       float gq = dout[(int64_t)r * a.lddo + c];
       if (a.relu && !(out[(int64_t)r * a.ldo + c] > 0.f)) gq = 0.f;
       s1 += gq;
       s2 += gq * (x[(int64_t)r * a.ldx + c] - mean) * invstd;
     }
+  }
   red[0][ty][tx] = s1;
   red[1][ty][tx] = s2;
   __syncthreads();
-  s1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
-  s2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+  s1 = rb_sum(red[0], tx);
+  s2 = rb_sum(red[1], tx);
   if (!ok) return;
   const float ga = ((const float*)a.gamma.p[g])[c];
   if (ty == 0) {
@@ -214,7 +322,8 @@ __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwdArgs a) {
   }
   float* dx = (float*)a.dx.p[g];
   const float c1 = s1 / a.R, c2 = s2 / a.R;
-  for (int r = ty; r < a.R; r += 4) {
+#pragma unroll 4
+  for (int r = ty; r < a.R; r += RB_TY) {
     float gq = dout[(int64_t)r * a.lddo + c];
     if (a.relu && !(out[(int64_t)r * a.ldo + c] > 0.f)) gq = 0.f;
     const float xh = (x[(int64_t)r * a.ldx + c] - mean) * invstd;
@@ -492,10 +601,16 @@ static int fill_tab(PtrTab* t, const void* const* src, int groups) {
   return 0;
 }
 
-extern "C" int ieee_sgemm_grouped(int64_t groups, const void* const* A, const void* const* B, void* const* C,
-                                  const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak,
-                                  int64_t sbn, int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate,
-                                  void* stream) {
+static bool aligned16(const void* const* tab, int groups) {
+  for (int i = 0; i < groups; ++i)
+    if (((uintptr_t)tab[i] & 15) != 0) return false;
+  return true;
+}
+
+extern "C" int ieee_sgemm_grouped_ws(int64_t groups, const void* const* A, const void* const* B, void* const* C,
+                                     const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak,
+                                     int64_t sbn, int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate,
+                                     void* work, int64_t work_bytes, void* stream) {
   IEEE_REQUIRE(groups >= 1 && groups <= MAXG, "sgemm_grouped: groups %ld out of range [1,%d]", (long)groups, MAXG);
   IEEE_REQUIRE(A && B && C, "sgemm_grouped: null pointer table");
   IEEE_REQUIRE(M > 0 && N > 0 && K > 0, "sgemm_grouped: empty problem");
@@ -507,9 +622,49 @@ extern "C" int ieee_sgemm_grouped(int64_t groups, const void* const* A, const vo
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.sam = sam; a.sak = sak; a.sbn = sbn; a.sbk = sbk; a.ldc = ldc;
   a.alpha = alpha; a.relu = relu; a.accumulate = accumulate;
-  dim3 grid(cdiv(N, 64), cdiv(M, 64), (unsigned)groups);
+  // 16-byte loads along the contiguous axis when every group pointer and the other stride allow it
+  a.vec_a = (sak == 1 && sam % 4 == 0 && aligned16(A, (int)groups)) ? 1
+            : (sam == 1 && sak % 4 == 0 && aligned16(A, (int)groups)) ? 2 : 0;
+  a.vec_b = (sbk == 1 && sbn % 4 == 0 && aligned16(B, (int)groups)) ? 1
+            : (sbn == 1 && sbk % 4 == 0 && aligned16(B, (int)groups)) ? 2 : 0;
+  const int64_t tiles = cdiv(N, 64) * cdiv(M, 64) * groups;
+  int64_t splitk = 1;
+  if (work && tiles < 192 && K >= 256) {
+    splitk = cdiv(384, tiles);
+    if (splitk > K / 128) splitk = K / 128;
+    if (splitk > 32) splitk = 32;
+    while (splitk > 1 && splitk * groups * M * N * 4 > work_bytes) --splitk;
+    if (splitk < 1) splitk = 1;
+  }
+  a.kchunk = (int)(cdiv(cdiv(K, splitk), 32) * 32);
+  a.splitk = (int)cdiv(K, a.kchunk);
+  a.slab = (float*)work;
+  dim3 grid(cdiv(N, 64), cdiv(M, 64), (unsigned)(groups * a.splitk));
   sgemm_grouped_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  return launch_status("sgemm_grouped_kernel");
+  IEEE_TRY(launch_status("sgemm_grouped_kernel"));
+  if (a.splitk > 1) {
+    sgemm_splitk_reduce_kernel<<<dim3(cdiv(M * N, 256), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(a);
+    return launch_status("sgemm_splitk_reduce_kernel");
+  }
+  return IEEE_OK;
+}
+
+extern "C" int ieee_sgemm_grouped(int64_t groups, const void* const* A, const void* const* B, void* const* C,
+                                  const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak,
+                                  int64_t sbn, int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate,
+                                  void* stream) {
+  return ieee_sgemm_grouped_ws(groups, A, B, C, bias, M, N, K, sam, sak, sbn, sbk, ldc, alpha, relu, accumulate, nullptr,
+                               0, stream);
+}
+
+extern "C" int ieee_zero_spans(int64_t count, void* const* ptrs, const int64_t* floats, void* stream) {
+  IEEE_REQUIRE(count >= 1 && count <= MAXG && ptrs && floats, "zero_spans: bad arguments");
+  ZeroArgs a;
+  fill_tab(&a.p, (const void* const*)ptrs, (int)count);
+  int64_t most = 1;
+  for (int i = 0; i < MAXG; ++i) { a.n[i] = i < count ? floats[i] : 0; most = a.n[i] > most ? a.n[i] : most; }
+  zero_spans_kernel<<<dim3(ewb(most), (unsigned)count), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status("zero_spans_kernel");
 }
 
 extern "C" int ieee_colsum_grouped(int64_t groups, const void* const* X, void* const* out, int64_t M, int64_t N,
@@ -539,7 +694,7 @@ extern "C" int ieee_rowbn_fwd(int64_t groups, const void* const* x, void* const*
   fill_tab(&a.save, (const void* const*)save, (int)groups);
   a.R = (int)R; a.C = (int)C; a.ldx = ldx; a.ldo = ldo; a.momentum = momentum; a.eps = eps;
   a.training = training; a.relu = relu;
-  rowbn_fwd_kernel<<<dim3(cdiv(C, 64), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(a);
+  rowbn_fwd_kernel<<<dim3(cdiv(C, RB_TX), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(a);
   return launch_status("rowbn_fwd_kernel");
 }
 
@@ -560,7 +715,7 @@ extern "C" int ieee_rowbn_bwd(int64_t groups, const void* const* dout, const voi
   fill_tab(&a.dbeta, (const void* const*)dbeta, (int)groups);
   a.R = (int)R; a.C = (int)C; a.lddo = lddo; a.ldo = ldo; a.ldx = ldx; a.lddx = lddx;
   a.relu = relu; a.accumulate = accumulate;
-  rowbn_bwd_kernel<<<dim3(cdiv(C, 64), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(a);
+  rowbn_bwd_kernel<<<dim3(cdiv(C, RB_TX), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(a);
   return launch_status("rowbn_bwd_kernel");
 }
 

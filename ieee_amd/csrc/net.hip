@@ -67,7 +67,7 @@ struct Net {
   // workspace
   size_t ws_bytes = 0;
   std::map<std::string, Tensor> tensors;
-  Tensor x0, pool, pool_arg, S, gbuf[5], slab, bnpart, bncoef, packtab;
+  Tensor x0, pool, pool_arg, S, gbuf[5], slab, bnpart, bncoef, packtab, gemm_work;
   std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
   int pack_blocks_train = 0, pack_blocks_eval = 0;
   // training: the layer3 / layer4 / CIM operands (90 % of the bytes) are packed on the side stream while the
@@ -106,6 +106,7 @@ struct Net {
   std::vector<hipEvent_t> ev_pool;
   std::vector<int> ev_cat;
   std::vector<std::string> ev_name;
+  std::vector<const char*> ev_label;
   std::vector<double> ev_flops;
   size_t ev_used = 0;
   double prof_flops[2] = {0, 0};
@@ -292,6 +293,7 @@ void Net::plan() {
   dH = alloc("dH", 3 * 2 * Bq * hid, IEEE_F32);
   davgmax = alloc("davgmax", 3 * 2 * Bq * fdim, IEEE_F32);
   remwork = alloc("", 3 * Bq + 64, IEEE_F32);
+  gemm_work = alloc("", (int64_t)4 << 20, IEEE_F32);   // split-K slabs of the head GEMMs (16 MiB)
   packtab = alloc("", (int64_t)(5 * units.size() + 8) * sizeof(PackDescHost) / 4, IEEE_F32);
 }
 
@@ -323,8 +325,9 @@ struct Run {
     }
     return IEEE_OK;
   }
-  void prof_begin(int cat, const ConvUnit& u) {
+  void prof_begin(int cat, const ConvUnit& u, const char* label = nullptr) {
     if (!n.profiling) return;
+    n.ev_label.push_back(label ? label : (cat ? "wgrad" : "fwd"));
     if (n.ev_used + 2 > n.ev_pool.size()) {
       for (int i = 0; i < 256; ++i) { hipEvent_t e; (void)hipEventCreate(&e); n.ev_pool.push_back(e); }
     }
@@ -448,7 +451,7 @@ struct Run {
     const bool fuse = prev != nullptr && n.dtype == IEEE_BF16;
     fused_bwd = fuse;
     will_write(dx);
-    prof_begin(0, u);
+    prof_begin(0, u, "dgrad");
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_dgrad(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
                              u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, fuse ? F(n.bnpart) : nullptr,
@@ -461,7 +464,8 @@ struct Run {
             int64_t ldc, int relu, int acc) {
     const void* a[3]; const void* b[3]; void* c[3]; const void* bi[3];
     for (int m = 0; m < 3; ++m) { a[m] = A + m * a_gs; b[m] = Bm + m * b_gs; c[m] = C + m * c_gs; bi[m] = bias ? bias + m * bias_gs : nullptr; }
-    return ieee_sgemm_grouped(3, a, b, c, bias ? bi : nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 1.0f, relu, acc, st);
+    return ieee_sgemm_grouped_ws(3, a, b, c, bias ? bi : nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 1.0f, relu, acc,
+                                 P(n.gemm_work), (int64_t)n.gemm_work.numel * 4, st);
   }
   bool late_pack_pending = false;
   int forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out) {
@@ -607,7 +611,8 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
         sv[g] = F(N.sv_fc) + g * 2 * D;
         o[g] = training ? (void*)(F(N.featcat) + (int64_t)m * B * R + i * D) : (void*)(F(N.fcall) + eval_off[m] + i * D);
       }
-    IEEE_TRY(ieee_sgemm_grouped(18, a, w, c, bi, B, D, R, (int64_t)N.parts * R, 1, R, 1, D, 1.0f, 0, 0, st));
+    IEEE_TRY(ieee_sgemm_grouped_ws(18, a, w, c, bi, B, D, R, (int64_t)N.parts * R, 1, R, 1, D, 1.0f, 0, 0, P(N.gemm_work),
+                                   (int64_t)N.gemm_work.numel * 4, st));
     IEEE_TRY(ieee_rowbn_fwd(18, xs, o, ga, be, rm, rv, sv, B, D, D, training ? R : 3 * R, N.bn_mom, N.bn_eps, training, 1, st));
   }
   if (!training) {
@@ -625,7 +630,8 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
         w[g] = par(N.s_clw[g]); bi[g] = par(N.s_clb[g]);
         c[g] = logits_out + (int64_t)g * B * NC;
       }
-    IEEE_TRY(ieee_sgemm_grouped(18, a, w, c, bi, B, NC, D, R, 1, D, 1, NC, 1.0f, 0, 0, st));
+    IEEE_TRY(ieee_sgemm_grouped_ws(18, a, w, c, bi, B, NC, D, R, 1, D, 1, NC, 1.0f, 0, 0, P(N.gemm_work),
+                                   (int64_t)N.gemm_work.numel * 4, st));
   }
   // F.normalize per modality   :519
   IEEE_TRY(ieee_l2norm_fwd(F(N.featcat), F(N.featn), F(N.norms), 3 * (int64_t)B, R, st));
@@ -714,16 +720,20 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
         dp2[g] = F(N.dpart2) + (int64_t)m * PB * R + i * R;
       }
     // classifier: dW = dlogits^T feat, db = colsum, dfeat += dlogits W
-    IEEE_TRY(ieee_sgemm_grouped(18, dl, fe, dw, nullptr, NC, D, B, 1, NC, 1, R, D, 1.0f, 0, 0, st));
+    IEEE_TRY(ieee_sgemm_grouped_ws(18, dl, fe, dw, nullptr, NC, D, B, 1, NC, 1, R, D, 1.0f, 0, 0, P(N.gemm_work),
+                                   (int64_t)N.gemm_work.numel * 4, st));
     IEEE_TRY(ieee_colsum_grouped(18, dl, db, B, NC, NC, 0, st));
-    IEEE_TRY(ieee_sgemm_grouped(18, dl, w, dfc, nullptr, B, D, NC, NC, 1, 1, D, R, 1.0f, 0, 1, st));
+    IEEE_TRY(ieee_sgemm_grouped_ws(18, dl, w, dfc, nullptr, B, D, NC, NC, 1, 1, D, R, 1.0f, 0, 1, P(N.gemm_work),
+                                   (int64_t)N.gemm_work.numel * 4, st));
     // fc: BN1d+ReLU backward, then Linear backward
     IEEE_TRY(ieee_rowbn_bwd(18, (const void* const*)dfc, fe, xs, ga, sv, dx, dg, dbe, B, D, R, R, D, D, 1, 0, st));
-    IEEE_TRY(ieee_sgemm_grouped(18, dfr, pp, dwf, nullptr, D, R, B, 1, D, 1, (int64_t)N.parts * R, R, 1.0f, 0, 0, st));
+    IEEE_TRY(ieee_sgemm_grouped_ws(18, dfr, pp, dwf, nullptr, D, R, B, 1, D, 1, (int64_t)N.parts * R, R, 1.0f, 0, 0, P(N.gemm_work),
+                                   (int64_t)N.gemm_work.numel * 4, st));
     IEEE_TRY(ieee_colsum_grouped(18, dfr, dbf, B, D, D, 0, st));
     const void* wf[18];
     for (int g = 0; g < 18; ++g) wf[g] = par(N.s_fcw[g]);
-    IEEE_TRY(ieee_sgemm_grouped(18, dfr, wf, dp2, nullptr, B, R, D, D, 1, 1, R, (int64_t)N.parts * R, 1.0f, 0, 0, st));
+    IEEE_TRY(ieee_sgemm_grouped_ws(18, dfr, wf, dp2, nullptr, B, R, D, D, 1, 1, R, (int64_t)N.parts * R, 1.0f, 0, 0, P(N.gemm_work),
+                                   (int64_t)N.gemm_work.numel * 4, st));
   }
   // REM backward
   bool have_dglob = false;
@@ -742,10 +752,13 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
                    R, 1, 1, R, R, 0, 0));
     have_dglob = true;
     // conv_query receives exact zeros; conv_value receives no gradient at all
+    void* zp[6];
+    int64_t zn[6];
     for (int m = 0; m < 3; ++m) {
-      IEEE_HIP(hipMemsetAsync(grd(N.s_rem_qw + m), 0, sizeof(float) * (size_t)R * R, (hipStream_t)st));
-      IEEE_HIP(hipMemsetAsync(grd(N.s_rem_qb + m), 0, sizeof(float) * (size_t)R, (hipStream_t)st));
+      zp[2 * m] = grd(N.s_rem_qw + m); zn[2 * m] = (int64_t)R * R;
+      zp[2 * m + 1] = grd(N.s_rem_qb + m); zn[2 * m + 1] = R;
     }
+    IEEE_TRY(ieee_zero_spans(6, zp, zn, st));
   }
   {   // reduce_layer BN(+ReLU) backward: parts first (overwrite), then the global vector (accumulate)
     const void *d1[3], *o1[3], *x1[3], *ga[3], *s1[3], *d2[3], *o2[3], *x2[3], *s2[3];
@@ -957,6 +970,7 @@ extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {
     n->ev_used = 0;
     n->ev_cat.clear();
     n->ev_name.clear();
+    n->ev_label.clear();
     n->ev_flops.clear();
     n->prof_flops[0] = n->prof_flops[1] = 0;
     n->prof_launches[0] = n->prof_launches[1] = 0;
@@ -977,7 +991,7 @@ extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {
       for (size_t i = 0; i + 1 < n->ev_used; i += 2) {
         float t = 0.f;
         (void)hipEventElapsedTime(&t, n->ev_pool[i], n->ev_pool[i + 1]);
-        fprintf(f, "%s,%s,%.2f,%.3f,%.1f\n", n->ev_name[i / 2].c_str(), n->ev_cat[i / 2] ? "wgrad" : "gather", t * 1e3,
+        fprintf(f, "%s,%s,%.2f,%.3f,%.1f\n", n->ev_name[i / 2].c_str(), n->ev_label[i / 2], t * 1e3,
                 n->ev_flops[i / 2] / 1e9, n->ev_flops[i / 2] / (t * 1e-3) / 1e12);
       }
       fclose(f);

@@ -107,7 +107,7 @@ int ieee_pack_all_weights(const float* params, void* ws_base, const void* descs,
 int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N,
                     int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride,
                     int64_t pad, int64_t x_gs, int64_t w_gs, int64_t y_gs, float* bn_partial, void* stream);
-/* bn_partial (bf16 vector path only, else NULL): the conv also emits, per group, [rblocks][2][Co] per-channel
+/* bn_partial (bf16 vector path only, else NULL): the conv also emits, per group, [2][Co][rblocks] per-channel
  * sum / sum-of-squares of the stored outputs, rblocks = ieee_conv2d_fwd_stats_rblocks(); hand the same buffer
  * and rblocks to ieee_bn2d_fwd(stats_rblocks) and the separate statistics pass disappears */
 int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t Wo);
@@ -120,7 +120,7 @@ int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* dx, const vo
                       float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
                       void* stream);
 /* bn_partial != NULL (bf16 only): dx is the gradient w.r.t. the output of a BN(+ReLU) whose input is bn_y; the
- * dgrad epilogue also emits that BN's backward sums [rblocks][2][Ci] (sum g, sum g*y; g = dx * [mask], mask from
+ * dgrad epilogue also emits that BN's backward sums [2][Ci][rblocks] (sum g, sum g*y; g = dx * [mask], mask from
  * bn_mask > 0, or from bn_y*scale+shift > 0 with bn_stats = that BN's [4][Ci] stats, or none), rblocks =
  * ceil(N*Hi*Wi/128): pass it to ieee_bn2d_bwd(stats_rblocks) and the separate reduction pass disappears */
 
@@ -140,7 +140,7 @@ int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work,
  * gamma/beta at param_gs, running stats at buf_gs.
  * stats  : out, groups x [4][C] = mean, invstd, scale, shift (kept for backward)
  * partial: scratch of groups * ieee_bn_partial_floats() floats; with stats_rblocks > 0 it already holds the
- *          [stats_rblocks][2][C] sums emitted by ieee_conv2d_fwd and the statistics kernel is skipped
+ *          [2][C][stats_rblocks] sums emitted by ieee_conv2d_fwd and the statistics kernel is skipped
  * out = [relu]( y*scale + shift [+ residual] ); out NULL = statistics only.  training=0 uses running stats. */
 int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C);
 int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
@@ -201,6 +201,15 @@ int ieee_sgemm_grouped(int64_t groups, const void* const* A, const void* const* 
                        const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak,
                        int64_t sbn, int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate,
                        void* stream);
+/* same, with a scratch buffer: long-K problems with few 64x64 tiles (the pooled-vector GEMMs: K = 2048 reduce
+ * conv / CA fc1, K = 768 REM / fc heads) are split along K into `work` slabs that a second kernel adds in a fixed
+ * order (deterministic); work == NULL or too small = no split.  16 MiB covers every GEMM of the head. */
+int ieee_sgemm_grouped_ws(int64_t groups, const void* const* A, const void* const* B, void* const* C,
+                          const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak,
+                          int64_t sbn, int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate, void* work,
+                          int64_t work_bytes, void* stream);
+/* zero `count` (<= IEEE_MAX_GROUPS) float spans in one launch */
+int ieee_zero_spans(int64_t count, void* const* ptrs, const int64_t* floats, void* stream);
 int ieee_colsum_grouped(int64_t groups, const void* const* X, void* const* out, int64_t M, int64_t N,
                         int64_t ldx, int accumulate, void* stream);
 /* BatchNorm over the rows of [R][C] (+ReLU): BatchNorm2d on [B,C,1,1] / [B,C,6,1] (reduce_layer, applied

@@ -137,13 +137,13 @@ def test_fused_bn_partials_in_conv_epilogues():
     wp, wpd = _ops.pack_conv_weight(w, dt, 0), _ops.pack_conv_weight(w, dt, 1)
     M = N * H * W
     rb = lib.ieee_conv2d_fwd_stats_rblocks(N, H, W)
-    part = torch.zeros(G, rb, 2, Co, device="cuda")
+    part = torch.zeros(G, 2, Co, rb, device="cuda")
     y = torch.empty(G, N, H, W, Co, device="cuda", dtype=dt)
     L.check(lib.ieee_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(y), L.IEEE_BF16, G, N, H, W, Ci, Co, 3, 3, 1, 1, x[0].numel(),
                                 wp.stride(0), y[0].numel(), L.ptr(part), L.stream()))
     yf = y.float().view(G, M, Co)
-    torch.testing.assert_close(part[:, :, 0].sum(1), yf.sum(1), rtol=1e-4, atol=1e-2)
-    torch.testing.assert_close(part[:, :, 1].sum(1), (yf * yf).sum(1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(part[:, 0].sum(-1), yf.sum(1), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(part[:, 1].sum(-1), (yf * yf).sum(1), rtol=1e-4, atol=1e-2)
     torch.testing.assert_close(y.float(), _ops.conv2d_fwd(x, wp, Co, 3, 3, 1, 1).float())   # same stores as unfused
     # dgrad: dx = grad w.r.t. x; pretend x = relu(bn(ypre)) of a previous unit
     dy = torch.randn(G, N, H, W, Co, generator=g).cuda().to(dt)
@@ -153,7 +153,7 @@ def test_fused_bn_partials_in_conv_epilogues():
     addend = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
     dx_ref = _ops.conv2d_dgrad(dy, wpd, (H, W), Ci, 3, 3, 1, 1, addend=addend)
     for mode in ("mask", "stats", "none"):
-        p2 = torch.zeros(G, rb, 2, Ci, device="cuda")
+        p2 = torch.zeros(G, 2, Ci, rb, device="cuda")
         dx = torch.empty_like(dx_ref)
         L.check(lib.ieee_conv2d_dgrad(L.ptr(dy), L.ptr(wpd), L.ptr(dx), L.ptr(addend), L.IEEE_BF16, G, N, H, W, Ci, Co, 3, 3,
                                       1, 1, dy[0].numel(), wpd.stride(0), dx[0].numel(), L.ptr(p2), L.ptr(ypre),
@@ -167,5 +167,5 @@ def test_fused_bn_partials_in_conv_epilogues():
             gq = d * ((yv * stats[:, 2:3] + stats[:, 3:4]) > 0)
         else:
             gq = d
-        torch.testing.assert_close(p2[:, :, 0].sum(1), gq.sum(1), rtol=1e-3, atol=5e-2)
-        torch.testing.assert_close(p2[:, :, 1].sum(1), (gq * yv).sum(1), rtol=1e-3, atol=5e-2)
+        torch.testing.assert_close(p2[:, 0].sum(-1), gq.sum(1), rtol=1e-3, atol=5e-2)
+        torch.testing.assert_close(p2[:, 1].sum(-1), (gq * yv).sum(1), rtol=1e-3, atol=5e-2)

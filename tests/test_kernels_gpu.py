@@ -342,3 +342,54 @@ def test_fused_sgd_matches_torch_sgd():
         opt.step()
         L.check(lib.ieee_sgd_nesterov_step(L.ptr(pd), L.ptr(gr.cuda()), L.ptr(buf), n, 1e-2, 0.9, 5e-4, 1, L.stream()))
     torch.testing.assert_close(pd.cpu(), p.detach(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["nt", "tn", "nn_strided"])
+def test_sgemm_grouped_splitk_matches_matmul(layout):
+    """grouped fp32 GEMM (ieee_sgemm_grouped_ws): 16-byte operand loads along either axis, the scalar fallback,
+    and the deterministic split-K path (long K, few tiles) against torch.matmul in fp64"""
+    from ieee_amd import _lib as L
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(5)
+    G, M, N, K = 3, 70, 130, 2048 + 36      # ragged in every dimension
+    A = torch.randn(G, M, K, generator=g).cuda()
+    Bm = torch.randn(G, N, K, generator=g).cuda()
+    bias = torch.randn(G, N, generator=g).cuda()
+    C0 = torch.randn(G, M, N, generator=g).cuda()
+    ref = torch.relu((0.5 * (A.double() @ Bm.double().transpose(1, 2)) + bias.double()[:, None, :]) + C0.double())
+
+    def tab(ts):
+        return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    if layout == "nt":            # both operands k-contiguous
+        a, b, sa, sb = A, Bm, (K, 1), (K, 1)
+    elif layout == "tn":          # both operands stored [K][rows] (row-contiguous)
+        a, b = A.transpose(1, 2).contiguous(), Bm.transpose(1, 2).contiguous()
+        sa, sb = (1, M), (1, N)
+        # M = 70, N = 130 are not multiples of 4 -> scalar fallback for the strides; exercise the vector path too
+    else:                         # odd pointer offset: unaligned -> scalar path
+        pa = torch.zeros(G, M * K + 1, device="cuda"); pa[:, 1:] = A.reshape(G, -1)
+        a, b, sa, sb = pa[:, 1:], Bm, (K, 1), (K, 1)
+    work = torch.empty(16 << 20, dtype=torch.uint8, device="cuda")
+    outs = []
+    for w in (work, None):
+        C = C0.clone()
+        L.check(lib.ieee_sgemm_grouped_ws(G, tab([a[i] for i in range(G)]), tab([b[i] for i in range(G)]), tab(list(C)),
+                                          tab(list(bias)), M, N, K, sa[0], sa[1], sb[0], sb[1], N, 0.5, 1, 1,
+                                          L.ptr(w) if w is not None else None, work.numel() if w is not None else 0,
+                                          L.stream()))
+        torch.testing.assert_close(C.double(), ref, rtol=1e-4, atol=2e-3)
+        outs.append(C)
+    # split-K is deterministic: same bits on a second run
+    C = C0.clone()
+    L.check(lib.ieee_sgemm_grouped_ws(G, tab([a[i] for i in range(G)]), tab([b[i] for i in range(G)]), tab(list(C)),
+                                      tab(list(bias)), M, N, K, sa[0], sa[1], sb[0], sb[1], N, 0.5, 1, 1, L.ptr(work),
+                                      work.numel(), L.stream()))
+    assert torch.equal(C, outs[0])
+    if layout == "tn":            # aligned row-contiguous operands (vector path along rows)
+        M2, N2 = 64, 128
+        a2, b2 = a[:, :, :M2].contiguous(), b[:, :, :N2].contiguous()
+        C2 = torch.zeros(G, M2, N2, device="cuda")
+        L.check(lib.ieee_sgemm_grouped_ws(G, tab(list(a2)), tab(list(b2)), tab(list(C2)), None, M2, N2, K, 1, M2, 1, N2, N2,
+                                          1.0, 0, 0, L.ptr(work), work.numel(), L.stream()))
+        torch.testing.assert_close(C2.double(), (A.double() @ Bm.double().transpose(1, 2))[:, :M2, :N2], rtol=1e-4, atol=2e-3)
