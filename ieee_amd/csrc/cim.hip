@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void gpool_sum_others_kernel(const T* __restri
   float acc[3 * VEC];
 #pragma unroll
   for (int e = 0; e < 3 * VEC; ++e) acc[e] = 0.f;
+#pragma unroll 4
   for (int p = ty; p < g.P; p += g.ty) {
     const int64_t off = ((int64_t)b * g.P + p) * g.C + c0;
     float v[3][VEC];
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256) void ca_pool_kernel(const T* __restrict__ y2, 
   int mi[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { s[e] = 0.f; m[e] = -INFINITY; mi[e] = 0; }
+#pragma unroll 4
   for (int p = ty; p < g.P; p += g.ty) {
     float v[VEC];
     Vec16<T>::unpack(*(const uint4*)(y2 + z * gs + ((int64_t)b * g.P + p) * g.C + c0), v);
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(256) void cim_tail_kernel(const T* __restrict__ y1,
   float acc[MAXP * VEC];
 #pragma unroll
   for (int e = 0; e < MAXP * VEC; ++e) acc[e] = 0.f;
+#pragma unroll 4
   for (int p = ty; p < g.P; p += g.ty) {
     const int h = p / g.W;
     const int64_t off = z * gs + ((int64_t)b * g.P + p) * g.C + c0;
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(256) void cim_bwd_datt_kernel(const float* __restri
   float acc[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll 4
   for (int p = ty; p < g.P; p += g.ty) {
     float d[VEC], v[VEC];
     dout_at(dP, pbase, g.C, c0, p / g.W, H, g.W, parts, d, VEC);
@@ -361,9 +365,11 @@ __global__ __launch_bounds__(256) void cim_bwd_g_kernel(const float* __restrict_
                                                         const float* __restrict__ davg, const float* __restrict__ dmax,
                                                         const int* __restrict__ amax, T* __restrict__ g1,
                                                         T* __restrict__ g2, PosGeom g, int64_t gs, int H, int parts,
-                                                        int mode, int64_t pool_gs) {
+                                                        int mode, int64_t pool_gs, float* __restrict__ bnp1,
+                                                        float* __restrict__ bnp2) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int MAXP = 8;
+  __shared__ float red[256];
   const int z = blockIdx.y;
   const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
   const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
@@ -399,6 +405,12 @@ __global__ __launch_bounds__(256) void cim_bwd_g_kernel(const float* __restrict_
       am[e] = amax[bc];
     }
   }
+  // BN-backward sums of convOne / convAvgRest (sum g, sum g*y over this sample's positions, of the ROUNDED g
+  // that is stored), emitted per sample so that bn2d_bwd(stats_rblocks = B) needs no reduction pass
+  float bsum[4 * VEC];
+#pragma unroll
+  for (int e = 0; e < 4 * VEC; ++e) bsum[e] = 0.f;
+#pragma unroll 4
   for (int p = ty; p < g.P; p += g.ty) {
     const int h = p / g.W;
     float d[VEC];
@@ -427,8 +439,31 @@ __global__ __launch_bounds__(256) void cim_bwd_g_kernel(const float* __restrict_
       o1[e] = on1 ? d[e] : 0.f;
       o2[e] = on2 ? t2 : 0.f;
     }
-    *(uint4*)(g1 + off) = Vec16<T>::pack(o1);
-    *(uint4*)(g2 + off) = Vec16<T>::pack(o2);
+    const uint4 q1 = Vec16<T>::pack(o1), q2 = Vec16<T>::pack(o2);
+    *(uint4*)(g1 + off) = q1;
+    *(uint4*)(g2 + off) = q2;
+    if (bnp1 != nullptr) {
+      Vec16<T>::unpack(q1, o1);
+      Vec16<T>::unpack(q2, o2);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        bsum[e] += o1[e]; bsum[VEC + e] += o1[e] * v1[e];
+        bsum[2 * VEC + e] += o2[e]; bsum[3 * VEC + e] += o2[e] * v2[e];
+      }
+    }
+  }
+  if (bnp1 != nullptr && mode != 2) {   // partial layout [z][2][C][B] (sample index innermost, see StagedStoreEpi)
+    reduce_over_ty<4 * VEC>(bsum, tx, ty, g.tx, g.ty, red);
+    if (ty == 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int64_t o = ((int64_t)z * 2 * g.C + c0 + e) * g.B + b;
+        bnp1[o] = bsum[e];
+        bnp1[o + (int64_t)g.C * g.B] = bsum[VEC + e];
+        bnp2[o] = bsum[2 * VEC + e];
+        bnp2[o + (int64_t)g.C * g.B] = bsum[3 * VEC + e];
+      }
+    }
   }
 }
 
@@ -570,15 +605,17 @@ extern "C" int ieee_cim_tail_bwd_datt(const float* dparts, const void* y2, const
 extern "C" int ieee_cim_tail_bwd_g(const float* dparts, const void* y1, const void* y2, const float* stats1,
                                    const float* stats2, const float* att, const float* davg, const float* dmax,
                                    int64_t pool_gs, const int32_t* argmax, void* g1, void* g2, int dtype, int64_t B,
-                                   int64_t H, int64_t W, int64_t C, int64_t parts, int mode, void* stream) {
+                                   int64_t H, int64_t W, int64_t C, int64_t parts, int mode, float* bn_partial1,
+                                   float* bn_partial2, void* stream) {
   IEEE_REQUIRE(dparts && g1, "cim_tail_bwd_g: null pointer");
+  IEEE_REQUIRE((bn_partial1 == nullptr) == (bn_partial2 == nullptr), "cim_tail_bwd_g: give both BN partial buffers or none");
   IEEE_REQUIRE(mode == 2 || (y1 && y2 && stats1 && stats2 && g2), "cim_tail_bwd_g: missing CIM operands");
   IEEE_REQUIRE(mode != 0 || (att && davg && dmax && argmax), "cim_tail_bwd_g: missing attention operands");
   const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(B * g.cblocks), 3);
-  DISPATCH_T(dtype, (cim_bwd_g_kernel<float><<<grid, 256, 0, st>>>(dparts, (const float*)y1, (const float*)y2, stats1, stats2, att, davg, dmax, argmax, (float*)g1, (float*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs)),
-             (cim_bwd_g_kernel<bf16><<<grid, 256, 0, st>>>(dparts, (const bf16*)y1, (const bf16*)y2, stats1, stats2, att, davg, dmax, argmax, (bf16*)g1, (bf16*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs)));
+  DISPATCH_T(dtype, (cim_bwd_g_kernel<float><<<grid, 256, 0, st>>>(dparts, (const float*)y1, (const float*)y2, stats1, stats2, att, davg, dmax, argmax, (float*)g1, (float*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs, bn_partial1, bn_partial2)),
+             (cim_bwd_g_kernel<bf16><<<grid, 256, 0, st>>>(dparts, (const bf16*)y1, (const bf16*)y2, stats1, stats2, att, davg, dmax, argmax, (bf16*)g1, (bf16*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs, bn_partial1, bn_partial2)));
   return launch_status("cim_bwd_g_kernel");
 }
 

@@ -629,8 +629,8 @@ extern "C" int ieee_sgemm_grouped_ws(int64_t groups, const void* const* A, const
             : (sbn == 1 && sbk % 4 == 0 && aligned16(B, (int)groups)) ? 2 : 0;
   const int64_t tiles = cdiv(N, 64) * cdiv(M, 64) * groups;
   int64_t splitk = 1;
-  if (work && tiles < 192 && K >= 256) {
-    splitk = cdiv(384, tiles);
+  if (work && tiles < 1024 && K >= 256) {   // aim at ~4 workgroups per CU: the k-loop is latency bound
+    splitk = cdiv(1024, tiles);
     if (splitk > K / 128) splitk = K / 128;
     if (splitk > 32) splitk = 32;
     while (splitk > 1 && splitk * groups * M * N * 4 > work_bytes) --splitk;

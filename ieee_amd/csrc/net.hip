@@ -254,6 +254,7 @@ void Net::plan() {
   S = alloc("S", (int64_t)3 * B * P * fdim, dt);
   for (int i = 0; i < 5; ++i) gbuf[i] = alloc("g" + std::to_string(i), max_act, dt);
   slab = alloc("", max_slab / 4 + 64, IEEE_F32);
+  max_part = std::max(max_part, (int64_t)12 * B * fdim);   // two [3][2][C][B] sets from ieee_cim_tail_bwd_g
   bnpart = alloc("", max_part + 64, IEEE_F32);
   bncoef = alloc("", 3 * 3 * max_c, IEEE_F32);
   const int64_t Bq = B;
@@ -293,7 +294,7 @@ void Net::plan() {
   dH = alloc("dH", 3 * 2 * Bq * hid, IEEE_F32);
   davgmax = alloc("davgmax", 3 * 2 * Bq * fdim, IEEE_F32);
   remwork = alloc("", 3 * Bq + 64, IEEE_F32);
-  gemm_work = alloc("", (int64_t)4 << 20, IEEE_F32);   // split-K slabs of the head GEMMs (16 MiB)
+  gemm_work = alloc("", (int64_t)8 << 20, IEEE_F32);   // split-K slabs of the head GEMMs (32 MiB)
   packtab = alloc("", (int64_t)(5 * units.size() + 8) * sizeof(PackDescHost) / 4, IEEE_F32);
 }
 
@@ -363,13 +364,15 @@ struct Run {
   }
   // backward of out = [relu](bn(y) [+res]); dy may alias dout
   bool& fused_bwd = n.fused_bwd_state;   // the last dgrad already emitted the BN-backward sums of the next bn_bwd()
-  int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0) {
-    const int64_t rb = fused_bwd ? (u.M(B) + 127) / 128 : 0;
+  int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0,
+             float* partial = nullptr, int64_t partial_rb = 0) {
+    const int64_t rb = partial ? partial_rb : (fused_bwd ? (u.M(B) + 127) / 128 : 0);
+    if (!partial) partial = F(n.bnpart);
     fused_bwd = false;
     will_write(dy);
     if (gout) will_write(gout);
     return ieee_bn2d_bwd(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
-                         F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), F(n.bnpart), F(n.bncoef), 0, mask_from_y, rb, st);
+                         F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, F(n.bncoef), 0, mask_from_y, rb, st);
   }
   // --- second stream for the weight gradients (see Net::side)
   int gbuf_index(const void* p) const {
@@ -807,9 +810,9 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
     void *g1 = P(N.gbuf[1]), *g2 = P(N.gbuf[2]);
     IEEE_TRY(ieee_cim_tail_bwd_g(F(N.dPp), P(uo.y), P(ur.y), F(uo.stats), F(ur.stats), F(N.att), F(N.davgmax),
                                  F(N.davgmax) + BC, 2 * BC, (const int32_t*)P(N.amax), g1, g2, dt, B, Hh_, Ww, C, N.parts,
-                                 mode, st));
-    IEEE_TRY(bn_bwd(uo, g1, nullptr, g1, nullptr));
-    IEEE_TRY(bn_bwd(ur, g2, nullptr, g2, nullptr));
+                                 mode, F(N.bnpart), F(N.bnpart) + 6 * BC, st));
+    IEEE_TRY(bn_bwd(uo, g1, nullptr, g1, nullptr, 0, F(N.bnpart), B));
+    IEEE_TRY(bn_bwd(ur, g2, nullptr, g2, nullptr, 0, F(N.bnpart) + 6 * BC, B));
     IEEE_TRY(wgrad(uo, g1, Fm));
     IEEE_TRY(wgrad(ur, g2, P(N.S)));
     IEEE_TRY(dgrad(uo, g1, P(N.gbuf[3]), nullptr));
@@ -817,7 +820,7 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
     IEEE_TRY(ieee_cim_bwd_combine(P(N.gbuf[3]), P(N.gbuf[4]), F(N.dGp), dF, dt, B, Hh_, Ww, C, mode, st));
   } else {
     IEEE_TRY(ieee_cim_tail_bwd_g(F(N.dPp), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
-                                 P(N.gbuf[1]), nullptr, dt, B, Hh_, Ww, C, N.parts, 2, st));
+                                 P(N.gbuf[1]), nullptr, dt, B, Hh_, Ww, C, N.parts, 2, nullptr, nullptr, st));
     IEEE_TRY(ieee_cim_bwd_combine(P(N.gbuf[1]), nullptr, F(N.dGp), dF, dt, B, Hh_, Ww, C, 2, st));
   }
   return IEEE_OK;

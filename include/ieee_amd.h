@@ -188,7 +188,11 @@ int ieee_cim_tail_bwd_datt(const float* dparts, const void* y2, const float* sta
 int ieee_cim_tail_bwd_g(const float* dparts, const void* y1, const void* y2, const float* stats1,
                         const float* stats2, const float* att, const float* davg, const float* dmax,
                         int64_t pool_gs, const int32_t* argmax, void* g1, void* g2, int dtype, int64_t B,
-                        int64_t H, int64_t W, int64_t C, int64_t parts, int mode, void* stream);
+                        int64_t H, int64_t W, int64_t C, int64_t parts, int mode, float* bn_partial1,
+                        float* bn_partial2, void* stream);
+/* bn_partial1/2 (both or neither; modes 0/1): also emit the BatchNorm-backward sums of convOne / convAvgRest as
+ * [3][2][C][B] per-sample partials (sum g, sum g*y of the stored g1 / g2): ieee_bn2d_bwd(stats_rblocks = B) then
+ * skips its reduction pass */
 /* dF_m = D1_m + DS_a + DS_b + dGp_m / (H*W) */
 int ieee_cim_bwd_combine(const void* D1, const void* DS, const float* dG, void* dF, int dtype, int64_t B,
                          int64_t H, int64_t W, int64_t C, int mode, void* stream);

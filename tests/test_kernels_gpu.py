@@ -197,16 +197,21 @@ def test_cim_tail_chain_fwd_bwd_fp32(mode):
         L.check(lib.ieee_sgemm_grouped(3, tab(list(dH)), tab(list(w1d)), tab(list(davgmax)), None, 2 * B, C, hid, hid, 1, 1, C,
                                        C, 1.0, 0, 0, L.stream()))
     g1, g2 = torch.empty_like(y1), torch.empty_like(y2)
+    # the kernel also emits the BN-backward sums per sample ([3][2][C][B]) -> bn2d_bwd(stats_rblocks = B)
+    bp1, bp2 = torch.zeros(3, 2, C, B, device=dev), torch.zeros(3, 2, C, B, device=dev)
     L.check(lib.ieee_cim_tail_bwd_g(L.ptr(dP), L.ptr(y1), L.ptr(y2), L.ptr(st1), L.ptr(st2), L.ptr(att), L.ptr(davgmax),
                                     ctypes.c_void_p(davgmax.data_ptr() + B * C * 4), 2 * B * C, L.ptr(amax), L.ptr(g1),
-                                    L.ptr(g2), 0, B, H, W, C, 6, mode, L.stream()))
+                                    L.ptr(g2), 0, B, H, W, C, 6, mode, L.ptr(bp1), L.ptr(bp2), L.stream()))
+    for bp, gq, y in ((bp1, g1, y1), (bp2, g2, y2)):
+        torch.testing.assert_close(bp[:, 0].sum(-1), gq.view(3, -1, C).sum(1), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(bp[:, 1].sum(-1), (gq * y).view(3, -1, C).sum(1), rtol=1e-4, atol=1e-4)
     coef = torch.empty(3, 3, C, device=dev)
     res = {}
-    for name, gq, y, ga, st in (("1", g1, y1, w["g1"], st1), ("2", g2, y2, w["g2"], st2)):
+    for name, gq, y, ga, st, bp in (("1", g1, y1, w["g1"], st1, bp1), ("2", g2, y2, w["g2"], st2, bp2)):
         gd = ga.detach().to(dev)
         dg, db = torch.zeros(3, C, device=dev), torch.zeros(3, C, device=dev)
         L.check(lib.ieee_bn2d_bwd(L.ptr(gq), None, L.ptr(y), L.ptr(gq), None, 0, 3, B * P, C, B * P * C, L.ptr(gd), C,
-                                  L.ptr(st), L.ptr(dg), L.ptr(db), C, L.ptr(part), L.ptr(coef), 0, 0, 0, L.stream()))
+                                  L.ptr(st), L.ptr(dg), L.ptr(db), C, L.ptr(bp), L.ptr(coef), 0, 0, B, L.stream()))
         res["dy" + name], res["dg" + name], res["db" + name] = gq, dg, db
     back = lambda t: t.cpu().permute(0, 1, 4, 2, 3)
     torch.testing.assert_close(back(res["dy1"]), w["y1"].grad, rtol=2e-3, atol=2e-5)
