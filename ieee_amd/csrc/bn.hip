@@ -95,39 +95,55 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, 
   });
 }
 
-// sum the per-row-block partials of channel c: 32 lanes stride over the row blocks, then a shuffle tree.
-// block = 8 channels x 32 lanes; returns the totals in every lane of the channel's 32-lane group.
+// sum the per-row-block partials of one channel: `lpc` lanes (a power of two, 32..256) stride over the row blocks,
+// then an LDS tree.  block = (256/lpc) channels x lpc lanes; the totals are valid in lane 0 of each channel group.
 // transposed = 0: p[rblock][2][C] (the reduction kernels of this file); 1: p[2][C][rblocks] (conv epilogues)
-__device__ __forceinline__ void sum_partials(const float* p, int rblocks, int C, int c, int lane32, int transposed,
+__device__ __forceinline__ void sum_partials(const float* p, int rblocks, int C, int c, int lpc, int transposed,
                                              double& s1, double& s2) {
+  __shared__ double red[2][256];
+  const int t = threadIdx.x, lane = t & (lpc - 1);
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
     if (transposed) {
       const float* p1 = p + (int64_t)c * rblocks;
       const float* p2 = p1 + (int64_t)C * rblocks;
-      for (int r = lane32; r < rblocks; r += 32) { a1 += p1[r]; a2 += p2[r]; }
+#pragma unroll 4
+      for (int r = lane; r < rblocks; r += lpc) { a1 += p1[r]; a2 += p2[r]; }
     } else {
-      for (int r = lane32; r < rblocks; r += 32) { a1 += p[(int64_t)r * 2 * C + c]; a2 += p[(int64_t)r * 2 * C + C + c]; }
+#pragma unroll 4
+      for (int r = lane; r < rblocks; r += lpc) { a1 += p[(int64_t)r * 2 * C + c]; a2 += p[(int64_t)r * 2 * C + C + c]; }
     }
   }
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
-  s1 = a1; s2 = a2;
+  red[0][t] = a1;
+  red[1][t] = a2;
+  for (int o = lpc >> 1; o > 0; o >>= 1) {
+    __syncthreads();
+    if (lane < o) { red[0][t] += red[0][t + o]; red[1][t] += red[1][t + o]; }
+  }
+  s1 = red[0][t]; s2 = red[1][t];
+}
+
+// lanes per channel for `rblocks` partial rows: ~4 rows per lane, between one half-wave and the whole block
+static int finalize_lpc(int64_t rblocks) {
+  int lpc = 32;
+  while (lpc < 256 && lpc * 4 < rblocks) lpc *= 2;
+  return lpc;
 }
 
 // mean / invstd / scale / shift + running-stat update (train) or scale/shift from running stats (eval)
-// stats layout per group: [4][C] = mean, invstd, scale, shift.   launch: block 256 = 8 channels x 32 lanes
+// stats layout per group: [4][C] = mean, invstd, scale, shift.   launch: block 256 = (256/lpc) channels x lpc lanes
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, int64_t partial_gs, int rblocks, int M,
                                                           int C, const float* gamma, const float* beta,
                                                           int64_t param_gs, float* running_mean, float* running_var,
                                                           int64_t buf_gs, float* stats, int64_t stats_gs,
-                                                          float momentum, float eps, int training, int transposed) {
-  const int lane32 = threadIdx.x & 31;
-  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+                                                          float momentum, float eps, int training, int transposed,
+                                                          int lpc) {
+  const int lane = threadIdx.x & (lpc - 1);
+  const int c = blockIdx.x * (256 / lpc) + threadIdx.x / lpc;
   const int z = blockIdx.y;
   double s1 = 0.0, s2 = 0.0;
-  if (training) sum_partials(partial + z * partial_gs, rblocks, C, c, lane32, transposed, s1, s2);
-  if (c >= C || lane32 != 0) return;
+  if (training) sum_partials(partial + z * partial_gs, rblocks, C, c, lpc, transposed, s1, s2);
+  if (c >= C || lane != 0) return;
   const float ga = gamma[z * param_gs + c], be = beta[z * param_gs + c];
   float* st = stats + z * stats_gs;
   float mean, invstd;
@@ -215,18 +231,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // dgamma = sum(g*xhat), dbeta = sum(g);  coefficients of dy = k1*g + k2*y + k3
-// coef layout per group: [3][C].   launch: block 256 = 8 channels x 32 lanes
+// coef layout per group: [3][C].   launch: block 256 = (256/lpc) channels x lpc lanes
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int64_t partial_gs, int rblocks,
                                                               int M, int C, const float* gamma, int64_t param_gs,
                                                               const float* stats, int64_t stats_gs, float* dgamma,
                                                               float* dbeta, int64_t grad_gs, float* coef,
-                                                              int64_t coef_gs, int accumulate, int transposed) {
-  const int lane32 = threadIdx.x & 31;
-  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+                                                              int64_t coef_gs, int accumulate, int transposed,
+                                                              int lpc) {
+  const int lane = threadIdx.x & (lpc - 1);
+  const int c = blockIdx.x * (256 / lpc) + threadIdx.x / lpc;
   const int z = blockIdx.y;
   double s1, s2;
-  sum_partials(partial + z * partial_gs, rblocks, C, c, lane32, transposed, s1, s2);
-  if (c >= C || lane32 != 0) return;
+  sum_partials(partial + z * partial_gs, rblocks, C, c, lpc, transposed, s1, s2);
+  if (c >= C || lane != 0) return;
   const float* st = stats + z * stats_gs;
   const double mean = st[c], invstd = st[C + c];
   const double sgx = invstd * (s2 - mean * s1);   // sum g * xhat
@@ -322,9 +339,10 @@ extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int
     else bn_stats_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y, act_gs, g, partial, partial_gs);
     IEEE_TRY(launch_status("bn_stats_kernel"));
   }
-  bn_finalize_kernel<<<dim3(cdiv(C, 8), (unsigned)groups), 256, 0, st>>>(
+  const int lpc = training ? finalize_lpc(g.rblocks) : 32;
+  bn_finalize_kernel<<<dim3(cdiv(C, 256 / lpc), (unsigned)groups), 256, 0, st>>>(
       partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, beta, param_gs, running_mean, running_var, buf_gs, stats,
-      4 * C, momentum, eps, training, stats_rblocks > 0 ? 1 : 0);
+      4 * C, momentum, eps, training, stats_rblocks > 0 ? 1 : 0, lpc);
   IEEE_TRY(launch_status("bn_finalize_kernel"));
   if (out == nullptr) return IEEE_OK;   // statistics only: the consumer applies scale/shift itself
   const int64_t chunks = M * C / vec_of(dtype);
@@ -359,9 +377,10 @@ extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void*
     bn_bwd_reduce_kernel<bf16><<<rgrid, 256, 0, st>>>((const bf16*)dout, (const bf16*)out_mask, (const bf16*)y, act_gs,
                                                       g, partial, partial_gs, stats, 4 * C, mask_from_y);
   IEEE_TRY(launch_status("bn_bwd_reduce_kernel"));
-  bn_bwd_finalize_kernel<<<dim3(cdiv(C, 8), (unsigned)groups), 256, 0, st>>>(
+  const int lpc = finalize_lpc(g.rblocks);
+  bn_bwd_finalize_kernel<<<dim3(cdiv(C, 256 / lpc), (unsigned)groups), 256, 0, st>>>(
       partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, param_gs, stats, 4 * C, dgamma, dbeta, grad_gs, coef,
-      3 * C, accumulate, stats_rblocks > 0 ? 1 : 0);
+      3 * C, accumulate, stats_rblocks > 0 ? 1 : 0, lpc);
   IEEE_TRY(launch_status("bn_bwd_finalize_kernel"));
   const int64_t chunks = M * C / vec_of(dtype);
   dim3 grid(ew_blocks(chunks), (unsigned)groups);

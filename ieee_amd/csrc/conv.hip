@@ -202,7 +202,7 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
 // of PIPE stages with PIPE-1 k-tiles in flight (few-workgroup layers, where no co-resident workgroup hides the
 // load latency of a one-tile-deep pipeline); bf16 fast path only.
 template <typename T, int BN, bool SLOW, int MODE, int PIPE = 0>
-__global__ __launch_bounds__(256) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
+__global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : 1))) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
                                                           T* __restrict__ dst, const T* __restrict__ addend,
                                                           float* __restrict__ bn_partial, ConvArgs a, BwdStats bs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -251,9 +251,8 @@ struct WgradArgs {
 };
 
 // 3 waves per SIMD (148 VGPRs, no spill) instead of the 2 the default allocation settles on: +5-10 %
-#define WGRAD_BOUNDS __launch_bounds__(256, 3)
 template <typename T, bool SLOW, int PIPE = 0>
-__global__ WGRAD_BOUNDS void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256, (PIPE == 1 ? 4 : 3)) void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          float* __restrict__ slab, WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware order: every tile of one (k-split, modality) reads the same pixel range of dY and X, so all of
@@ -294,9 +293,15 @@ __global__ WGRAD_BOUNDS void conv_wgrad_kernel(const T* __restrict__ dy, const T
     const int ch = tn_dma_chunk(threadIdx.x);
     LoaderColsTN<T> lad;
     lad.init(dy, a.Co, m0, a.Co, kbeg, kend, ch);
-    LoaderIm2colTN<T> lbd;
-    lbd.init(x, a.g, n0, kbeg, kend, ch);
-    gemm_tn_dma<PIPE>(lad, lbd, epi, ktiles, m0, n0, smem);
+    if (a.plain_x) {   // 1x1 / stride 1 / no padding: im2col(X) is X itself
+      LoaderColsTN<T> lbd;
+      lbd.init(x, a.ncols, n0, a.ncols, kbeg, kend, ch);
+      gemm_tn_dma<PIPE>(lad, lbd, epi, ktiles, m0, n0, smem);
+    } else {
+      LoaderIm2colTN<T> lbd;
+      lbd.init(x, a.g, n0, kbeg, kend, ch);
+      gemm_tn_dma<PIPE>(lad, lbd, epi, ktiles, m0, n0, smem);
+    }
     return;
   }
   LoaderColsTN<T> la;
@@ -484,17 +489,25 @@ static void launch_gather_mode(int mode, dim3 grid, size_t smem, hipStream_t st,
 
 // Tile / pipeline choice of one gather launch (bf16 vector path).  wgs = workgroups of the 128x128 tiling.
 struct GatherPlan { int bn, pipe; };
+// Measured on the full training step (profiles/r01 notes, scripts/variant_scan.sh): the single-stage LDS-DMA
+// pipeline (PIPE 1: 118 VGPRs, 35 KB LDS -> 4 workgroups per CU) beats register staging (3 per CU) on almost every
+// layer (-7 % gather time); launches of <= 512 workgroups (Cout or Cin = 256 on the 16x8 maps) run faster still on
+// 128x64 tiles (twice the workgroups).  Deeper rings (PIPE 2-4) and the 128x256 tile lose: fewer workgroups per CU.
 static GatherPlan plan_gather(int M, int N, int ktiles, int groups) {
-  GatherPlan p{N <= 64 ? 64 : 128, 0};
+  GatherPlan p{N <= 64 ? 64 : 128, 1};
   static const int f_pipe = getenv("IEEE_GATHER_PIPE") ? atoi(getenv("IEEE_GATHER_PIPE")) : -1;
   static const int f_narrow = getenv("IEEE_GATHER_NARROW") ? atoi(getenv("IEEE_GATHER_NARROW")) : -1;
   static const int f_maxwg = getenv("IEEE_GATHER_MAXWG") ? atoi(getenv("IEEE_GATHER_MAXWG")) : 1 << 30;
+  static const int f_wide = getenv("IEEE_GATHER_WIDE") ? atoi(getenv("IEEE_GATHER_WIDE")) : 0;
   const int64_t wgs = (int64_t)cdiv(M, 128) * cdiv(N, 128) * groups;
+  if (N > 64 && wgs <= 512 && f_narrow != 0) p.bn = 64;
+  if (f_wide > 0 && N >= f_wide && N % 256 == 0) p.bn = 256;   // 128x256 tile: 25 % less L2 / LDS traffic per flop
   if (wgs <= f_maxwg) {   // tuning overrides apply to launches of at most IEEE_GATHER_MAXWG workgroups
     if (f_narrow == 1) p.bn = 64;
     if (f_pipe >= 0) p.pipe = f_pipe;
   }
-  if (ktiles < 2) p.pipe = 0;
+  if (p.bn == 256) p.pipe = 0;
+  if (ktiles < 2 && p.pipe > 1) p.pipe = 0;
   return p;
 }
 
@@ -544,8 +557,11 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   } else if constexpr (sizeof(T) == 2) {
 #define IEEE_GATHER_CASE(BN_, PIPE_) \
     launch_gather_mode<T, BN_, PIPE_>(mode, grid, smem, st, src, w, dst, addend, bn_partial, a, bs)
-    if (narrow) {
+    if (plan.bn == 256) {
+      IEEE_GATHER_CASE(256, 0);
+    } else if (narrow) {
       switch (plan.pipe) {
+        case 1: IEEE_GATHER_CASE(64, 1); break;
         case 2: IEEE_GATHER_CASE(64, 2); break;
         case 3: IEEE_GATHER_CASE(64, 3); break;
         case 4: IEEE_GATHER_CASE(64, 4); break;
@@ -553,6 +569,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
       }
     } else {
       switch (plan.pipe) {
+        case 1: IEEE_GATHER_CASE(128, 1); break;
         case 2: IEEE_GATHER_CASE(128, 2); break;
         case 3: IEEE_GATHER_CASE(128, 3); break;
         case 4: IEEE_GATHER_CASE(128, 4); break;
@@ -765,7 +782,8 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   static const int f_map = getenv("IEEE_WGRAD_MAP") ? atoi(getenv("IEEE_WGRAD_MAP")) : 2;
   a.xcd_group = (nkz >= 24 || nkz % 8 == 0) ? 1 : f_map;
   dim3 grid((unsigned)(a.tiles * (a.xcd_group == 1 ? cdiv(nkz, 8) * 8 : nkz)));
-  static const int f_pipe = getenv("IEEE_WGRAD_PIPE") ? atoi(getenv("IEEE_WGRAD_PIPE")) : 0;
+  // default: single-stage LDS-DMA (106 VGPRs -> 4 workgroups per CU): -6 % wgrad time over register staging at 3
+  static const int f_pipe = getenv("IEEE_WGRAD_PIPE") ? atoi(getenv("IEEE_WGRAD_PIPE")) : 1;
   const int pipe = (dtype == IEEE_BF16 && !slow) ? f_pipe : 0;
   const size_t smem = pipe ? (size_t)pipe * 32 * 1024 : (dtype == IEEE_BF16 ? 32 * 1024 : 64 * 1024);
   static bool attr_done = false;
@@ -781,6 +799,7 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
     else conv_wgrad_kernel<float, false><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
   } else if (dtype == IEEE_BF16) {
     if (slow) conv_wgrad_kernel<bf16, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
+    else if (pipe == 1) conv_wgrad_kernel<bf16, false, 1><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
     else if (pipe == 2) conv_wgrad_kernel<bf16, false, 2><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
     else if (pipe == 3) conv_wgrad_kernel<bf16, false, 3><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
     else if (pipe == 4) conv_wgrad_kernel<bf16, false, 4><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);

@@ -332,6 +332,38 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
 #pragma unroll
     for (int i = 0; i < BCH; ++i) glds16(lb.addr(i), stage + BM * 128 + (32 * i + 8 * wave_u) * 128);
   };
+  auto compute = [&](const char* cur) {
+    const char* At = cur + (wm * (BM / 2)) * 128;
+    const char* Bt = cur + BM * 128 + (wn * (BN / 2)) * 128;
+#pragma unroll
+    for (int kk = 0; kk < Img::KSTEPS; ++kk) {
+      Img::Frag fa[FM], fb[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa[i] = Img::frag(At, i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb[j] = Img::frag(Bt, j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+  };
+  if constexpr (DMA_STAGES == 1) {
+    // one LDS stage, nothing staged in registers: the fetch of the next tile is not overlapped inside the
+    // workgroup at all -- the (small) register and LDS footprint buys a 4th workgroup per CU instead
+    issue(0);
+    for (int kt = 0; kt < ktiles; ++kt) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // tile kt has landed for every wave
+      compute(smem);
+      if (kt + 1 < ktiles) {
+        __builtin_amdgcn_s_barrier();   // every wave is done reading the stage
+        la.next();
+        lb.next();
+        issue(0);
+      }
+    }
+  } else {
   // prologue: tiles 0 .. DMA_STAGES-2
   int issued = 0;
   for (; issued < DMA_STAGES - 1 && issued < ktiles; ++issued) {
@@ -347,21 +379,8 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
       issue(issued % DMA_STAGES);
       ++issued;
     }
-    const char* cur = smem + (kt % DMA_STAGES) * STAGE;
-    const char* At = cur + (wm * (BM / 2)) * 128;
-    const char* Bt = cur + BM * 128 + (wn * (BN / 2)) * 128;
-#pragma unroll
-    for (int kk = 0; kk < Img::KSTEPS; ++kk) {
-      Img::Frag fa[FM], fb[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) fa[i] = Img::frag(At, i * 16, kk, lane);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) fb[j] = Img::frag(Bt, j * 16, kk, lane);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
-    }
+    compute(smem + (kt % DMA_STAGES) * STAGE);
+  }
   }
 
   if constexpr (Epi::kStaged) {
@@ -398,6 +417,34 @@ __device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles
 #pragma unroll
     for (int i = 0; i < NCH; ++i) glds16(lb.addr(i), stage + TILE + (16 * i + 4 * wave_u) * 256);
   };
+  auto compute = [&](const char* cur) {
+#pragma unroll
+    for (int kk = 0; kk < Img::KSTEPS; ++kk) {
+      Img::Frag fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = Img::frag(cur, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = Img::frag(cur + TILE, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+  };
+  if constexpr (DMA_STAGES == 1) {   // see gemm_nt_dma
+    if (ktiles > 0) issue(0);
+    for (int kt = 0; kt < ktiles; ++kt) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      compute(smem);
+      if (kt + 1 < ktiles) {
+        __builtin_amdgcn_s_barrier();
+        la.next();
+        lb.next();
+        issue(0);
+      }
+    }
+  } else {
   int issued = 0;
   for (; issued < DMA_STAGES - 1 && issued < ktiles; ++issued) {
     if (issued > 0) { la.next(); lb.next(); }
@@ -412,19 +459,8 @@ __device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles
       issue(issued % DMA_STAGES);
       ++issued;
     }
-    const char* cur = smem + (kt % DMA_STAGES) * STAGE;
-#pragma unroll
-    for (int kk = 0; kk < Img::KSTEPS; ++kk) {
-      Img::Frag fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = Img::frag(cur, wm * 64 + i * 16, kk, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = Img::frag(cur + TILE, wn * 64 + j * 16, kk, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
-    }
+    compute(smem + (kt % DMA_STAGES) * STAGE);
+  }
   }
 
 #pragma unroll
