@@ -251,8 +251,11 @@ struct WgradArgs {
 };
 
 // 3 waves per SIMD (148 VGPRs, no spill) instead of the 2 the default allocation settles on: +5-10 %
+#ifndef IEEE_WGRAD_OCC
+#define IEEE_WGRAD_OCC 4
+#endif
 template <typename T, bool SLOW, int PIPE = 0>
-__global__ __launch_bounds__(256, (PIPE == 1 ? 4 : 3)) void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          float* __restrict__ slab, WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware order: every tile of one (k-split, modality) reads the same pixel range of dY and X, so all of
@@ -410,14 +413,15 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   }
   const PackDesc d = descs[lo];
   const int z = blockIdx.y;
+  __shared__ float lds[32 * 289];   // 36 KB, shared by the three tiled forms
+  const int t = threadIdx.x;
   if (d.pad_ == 1) {
     // 1x1 dgrad operand as a 64x64 LDS-tiled transpose: coalesced 256-B row reads of [co][ci], coalesced 16-byte
     // (bf16: 128-B row) writes of [ci][co]; the untiled version read with a stride of Ci floats
-    __shared__ float tile[64][65];
+    float (*tile)[65] = (float (*)[65])lds;
     const int tiles_ci = d.Ci / 64;
     const int tb = b - d.block_begin, tco = tb / tiles_ci, tci = tb - tco * tiles_ci;
     const float* src = params + d.src_off + z * d.src_gs + ((int64_t)tco * 64) * d.Ci + tci * 64;
-    const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (t >> 4) + 16 * i, c4 = (t & 15) * 4;
@@ -432,6 +436,45 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
       T* o = dst + (int64_t)c * d.ld + r8;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(tile[r8 + e][c]);
+    }
+    return;
+  }
+  if (d.pad_ == 2) {
+    // 3x3 forward operand dst[co][tap*Ci + ci] from OIHW [co][ci][tap]: a unit = (co, 64-channel chunk) = 576
+    // contiguous floats; 4 units per block go through LDS so that both the fp32 reads and the bf16 writes (128-B
+    // runs of 64 channels) are coalesced (the direct form reads with a 36-byte stride)
+    const int chunks = d.Ci / 64, units = d.Co * chunks;
+    const int u0 = (b - d.block_begin) * 4;
+    const float* src = params + d.src_off + z * d.src_gs;
+    for (int idx = t; idx < 4 * 576; idx += 256) {
+      const int u = u0 + idx / 576, j = idx % 576;
+      if (u < units) lds[idx] = src[(int64_t)u * 576 + j];   // unit u = (co = u / chunks, chunk = u % chunks): contiguous
+    }
+    __syncthreads();
+    T* dst = (T*)ws + d.dst_off + z * d.dst_gs;
+    for (int idx = t; idx < 4 * 576; idx += 256) {
+      const int ul = idx / 576, r = idx % 576, tap = r >> 6, c = r & 63;
+      const int u = u0 + ul;
+      if (u >= units) continue;
+      const int co = u / chunks, ch = u - co * chunks;
+      dst[(int64_t)co * d.ld + tap * d.Ci + ch * 64 + c] = from_f32<T>(lds[ul * 576 + c * 9 + tap]);
+    }
+    return;
+  }
+  if (d.pad_ == 3) {
+    // 3x3 dgrad operand dst[ci][tap*Co + co]: 32 co x 32 ci x 9 taps per block (288-float runs in, 64-B runs out)
+    const int tiles_ci = d.Ci / 32;
+    const int tb = b - d.block_begin, tco = tb / tiles_ci, tci = tb - tco * tiles_ci;
+    const float* src = params + d.src_off + z * d.src_gs + ((int64_t)tco * 32 * d.Ci + tci * 32) * 9;
+    for (int idx = t; idx < 32 * 288; idx += 256) {
+      const int co = idx / 288, j = idx % 288;
+      lds[co * 289 + j] = src[(int64_t)co * d.Ci * 9 + j];   // lds[co][ci*9 + tap], rows padded to 289 (bank spread)
+    }
+    __syncthreads();
+    T* dst = (T*)ws + d.dst_off + z * d.dst_gs;
+    for (int idx = t; idx < 32 * 288; idx += 256) {
+      const int co = idx & 31, r = idx >> 5, tap = r % 9, ci = r / 9;   // 32 consecutive threads = 32 co of one (ci, tap)
+      dst[(int64_t)(tci * 32 + ci) * d.ld + tap * d.Co + tco * 32 + co] = from_f32<T>(lds[co * 289 + ci * 9 + tap]);
     }
     return;
   }
@@ -733,7 +776,7 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
 static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups, int dtype) {
   const int64_t tiles = ((Co + 127) / 128) * ((ncols + 127) / 128) * groups;
   const int64_t bk = elem_bk(dtype);
-  static const int64_t target = getenv("IEEE_WGRAD_TARGET") ? atoll(getenv("IEEE_WGRAD_TARGET")) : 640;   // measured: 512-768 beat 1024 by 3.5 % (less slab traffic)
+  static const int64_t target = getenv("IEEE_WGRAD_TARGET") ? atoll(getenv("IEEE_WGRAD_TARGET")) : 448;   // measured at 4 workgroups/CU: 448 best (256: -2.5 %, 640: -0.6 %, 1024: -3.5 %; slab traffic)
   int64_t want = (target + tiles - 1) / tiles;               // aim at ~`target` workgroups per launch
   const int64_t maxsplit = (npix + 4 * bk - 1) / (4 * bk);   // at least 4 k-tiles per split
   if (want > maxsplit) want = maxsplit;

@@ -904,8 +904,12 @@ extern "C" int ieee_net_bind(void* handle, float* params, float* grads, float* b
         // 1x1 dgrad operands go through the 64x64 LDS-tiled transpose of pack_all_kernel (pad_ = 1)
         const bool tiled = mode == 1 && u.R == 1 && u.S == 1 && u.Co % 64 == 0 && u.Ci % 64 == 0 && ld == u.Co &&
                            u.Ci == u.Ci_src;
-        d.pad_ = tiled ? 1 : 0;
-        blocks += tiled ? (u.Co / 64) * (u.Ci / 64) : cdiv(rows * ld, 256);
+        // 3x3 operands: LDS-tiled forms 2 (forward) / 3 (dgrad) of pack_all_kernel
+        const bool k3 = u.R == 3 && u.S == 3 && u.Ci == u.Ci_src && u.S == u.S_src && u.Co % 32 == 0 && u.Ci % 64 == 0 &&
+                        ld == 9 * (mode == 0 ? u.Ci : u.Co);
+        d.pad_ = tiled ? 1 : (k3 ? (mode == 0 ? 2 : 3) : 0);
+        blocks += tiled ? (u.Co / 64) * (u.Ci / 64)
+                        : (k3 ? (mode == 0 ? cdiv(u.Co * (u.Ci / 64), 4) : (u.Co / 32) * (u.Ci / 32)) : cdiv(rows * ld, 256));
         tab.push_back(d);
       }
     }
