@@ -254,7 +254,7 @@ struct WgradArgs {
 #ifndef IEEE_WGRAD_OCC
 #define IEEE_WGRAD_OCC 4
 #endif
-template <typename T, bool SLOW, int PIPE = 0>
+template <typename T, bool SLOW, int PIPE = 0, bool HALF_M = false>
 __global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          float* __restrict__ slab, WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -299,11 +299,11 @@ __global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wg
     if (a.plain_x) {   // 1x1 / stride 1 / no padding: im2col(X) is X itself
       LoaderColsTN<T> lbd;
       lbd.init(x, a.ncols, n0, a.ncols, kbeg, kend, ch);
-      gemm_tn_dma<PIPE>(lad, lbd, epi, ktiles, m0, n0, smem);
+      gemm_tn_dma<PIPE, HALF_M>(lad, lbd, epi, ktiles, m0, n0, smem);
     } else {
       LoaderIm2colTN<T> lbd;
       lbd.init(x, a.g, n0, kbeg, kend, ch);
-      gemm_tn_dma<PIPE>(lad, lbd, epi, ktiles, m0, n0, smem);
+      gemm_tn_dma<PIPE, HALF_M>(lad, lbd, epi, ktiles, m0, n0, smem);
     }
     return;
   }
@@ -776,7 +776,13 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
 static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups, int dtype) {
   const int64_t tiles = ((Co + 127) / 128) * ((ncols + 127) / 128) * groups;
   const int64_t bk = elem_bk(dtype);
-  static const int64_t target = getenv("IEEE_WGRAD_TARGET") ? atoll(getenv("IEEE_WGRAD_TARGET")) : 448;   // measured at 4 workgroups/CU: 448 best (256: -2.5 %, 640: -0.6 %, 1024: -3.5 %; slab traffic)
+  // workgroups to aim at: 448 measured best at 4 workgroups/CU (256: -2.5 %, 640: -0.6 %, 1024: -3.5 %: slab
+  // traffic).  A larger target for the small-weight layers (stem, layer1; IEEE_WGRAD_TARGET_SMALL) was measured too:
+  // 1024 helps the 3x3 / stem launches by 5-8 % but costs the 1x1 ones 30 %, net -1 %
+  static const int64_t f_target = getenv("IEEE_WGRAD_TARGET") ? atoll(getenv("IEEE_WGRAD_TARGET")) : 0;
+  static const int64_t f_small = getenv("IEEE_WGRAD_TARGET_SMALL") ? atoll(getenv("IEEE_WGRAD_TARGET_SMALL")) : 448;
+  const int64_t per_split_bytes = groups * Co * ncols * 4;
+  const int64_t target = f_target ? f_target : (per_split_bytes <= (1 << 20) ? f_small : 448);
   int64_t want = (target + tiles - 1) / tiles;               // aim at ~`target` workgroups per launch
   const int64_t maxsplit = (npix + 4 * bk - 1) / (4 * bk);   // at least 4 k-tiles per split
   if (want > maxsplit) want = maxsplit;
@@ -842,6 +848,7 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
     else conv_wgrad_kernel<float, false><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
   } else if (dtype == IEEE_BF16) {
     if (slow) conv_wgrad_kernel<bf16, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
+    else if (pipe == 1 && d.Co <= 64) conv_wgrad_kernel<bf16, false, 1, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
     else if (pipe == 1) conv_wgrad_kernel<bf16, false, 1><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
     else if (pipe == 2) conv_wgrad_kernel<bf16, false, 2><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
     else if (pipe == 3) conv_wgrad_kernel<bf16, false, 3><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);

@@ -46,7 +46,7 @@ struct DistEpi {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void distmat_kernel(const T* q, const T* g, const float* qn, const float* gn,
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void distmat_kernel(const T* q, const T* g, const float* qn, const float* gn,
                                                       float* out, int m, int n, int d, int64_t ldo, int metric,
                                                       int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -55,11 +55,11 @@ __global__ __launch_bounds__(256) void distmat_kernel(const T* q, const T* g, co
   const int m0 = tm * 128, n0 = tn * 128;
   LoaderPlainNT<T, 4> la, lb;
   DistEpi epi{out, qn, gn, ldo, m, n, metric};
-  if constexpr (false && sizeof(T) == 2) {   // LDS-DMA variant (not faster in practice; kept for the next tuning round)
+  if constexpr (sizeof(T) == 2) {   // single-stage LDS-DMA pipeline, 4 workgroups per CU (see conv.hip plan_gather)
     const int ch = nt_dma_chunk(threadIdx.x);
     la.init(q, d, m0, m, d, ch);
     lb.init(g, d, n0, n, d, ch);
-    gemm_nt_dma<128, 128, DMA_STAGES>(la, lb, epi, (d + 63) / 64, m0, n0, smem);
+    gemm_nt_dma<128, 128, 1>(la, lb, epi, (d + 63) / 64, m0, n0, smem);
     return;
   }
   la.init(q, d, m0, m, d);

@@ -394,7 +394,10 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
   }
 }
 
-template <int STAGES, class LA, class LB, class Epi>
+// HALF_M: the GEMM has at most 64 rows (Cout = 64: stem, layer1 conv1/conv2).  The LDS image keeps its 128-column
+// rows (columns >= 64 come from the zero page) but the four waves share the 64 valid rows (32 x 64 per wave), so
+// half the MFMA work of the full tile disappears instead of multiplying zeros.
+template <int STAGES, bool HALF_M, class LA, class LB, class Epi>
 __device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem) {
   typedef ImgTN<bf16> Img;
   constexpr int DMA_STAGES = STAGES;
@@ -404,9 +407,10 @@ __device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
-  f32x4 acc[4][4];
+  constexpr int FM = HALF_M ? 2 : 4, WROWS = FM * 16;
+  f32x4 acc[FM][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -420,13 +424,13 @@ __device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles
   auto compute = [&](const char* cur) {
 #pragma unroll
     for (int kk = 0; kk < Img::KSTEPS; ++kk) {
-      Img::Frag fa[4], fb[4];
+      Img::Frag fa[FM], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = Img::frag(cur, wm * 64 + i * 16, kk, lane);
+      for (int i = 0; i < FM; ++i) fa[i] = Img::frag(cur, wm * WROWS + i * 16, kk, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[j] = Img::frag(cur + TILE, wn * 64 + j * 16, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
     }
@@ -464,10 +468,10 @@ __device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles
   }
 
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      epi(m0 + wm * 64 + i * 16 + (lane & 15), n0 + wn * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+      epi(m0 + wm * WROWS + i * 16 + (lane & 15), n0 + wn * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
 }
 
 // ------------------------------------------------------------------ loaders
