@@ -92,3 +92,46 @@ def reduce_summary_(vec):
     if world_size() > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     return vec
+
+
+def query_shard(num_q, world=None, rank_=None):
+    """[start, end) of this rank's contiguous slice of the query rows (as even as possible)"""
+    world = world_size() if world is None else world
+    rank_ = rank() if rank_ is None else rank_
+    base, extra = divmod(num_q, world)
+    start = rank_ * base + min(rank_, extra)
+    return start, start + base + (1 if rank_ < extra else 0)
+
+
+def sharded_evaluate_rank(qf, gf, q_pids, g_pids, q_camids, g_camids, max_rank=20, metric='euclidean',
+                          distmat_fn=None, counts_fn=None):
+    """Multi-GPU evaluator: per-query AP and CMC rows are independent, so every rank takes a slice
+    of the QUERIES against the whole gallery -- its own distmat block and its own ranking pass -- and the only
+    exchange is ONE all_reduce(sum) of [max_rank CMC counts, num_valid_q, AP sum] (22 numbers at max_rank 20).
+    Every rank returns the same (cmc, mAP) as the single-device evaluate_rank (reference metrics/rank.py:103-171).
+    distmat_fn / counts_fn: the per-shard distance and ranking functions (default: the device kernels)."""
+    import numpy as np
+    from .metrics.distance import compute_distance_matrix
+    from .metrics import rank as rank_mod
+    distmat_fn = distmat_fn or (lambda a, b: compute_distance_matrix(a, b, metric))
+    counts_fn = counts_fn or rank_mod.rank_counts
+    num_g = gf.shape[0]
+    if num_g < max_rank:
+        max_rank = num_g
+    a, b = query_shard(qf.shape[0])
+    q_pids, q_camids = np.asarray(q_pids), np.asarray(q_camids)
+    if b > a:
+        counts, valid, ap_sum = counts_fn(distmat_fn(qf[a:b], gf), q_pids[a:b], g_pids, q_camids[a:b], g_camids, max_rank)
+    else:
+        counts, valid, ap_sum = np.zeros(max_rank, dtype=np.int64), 0.0, 0.0
+    vec = torch.zeros(max_rank + 2, dtype=torch.float64)      # counts < 2^53: exact in float64
+    vec[:max_rank] = torch.from_numpy(np.asarray(counts, dtype=np.float64))
+    vec[max_rank] = valid
+    vec[max_rank + 1] = ap_sum
+    if world_size() > 1:
+        if dist.get_backend() == "nccl":
+            vec = vec.cuda()
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        vec = vec.cpu()
+    v = vec.numpy()
+    return rank_mod.finish_counts(np.rint(v[:max_rank]).astype(np.int64), float(v[max_rank]), float(v[max_rank + 1]))

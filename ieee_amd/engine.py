@@ -233,9 +233,14 @@ class Engine(object):
             qf = F.normalize(qf, p=2, dim=1)
             gf = F.normalize(gf, p=2, dim=1)
         print('Computing distance matrix with metric={} ...'.format(dist_metric))
-        distmat = compute_distance_matrix(qf, gf, dist_metric)
-        print('Computing CMC and mAP for {}'.format(dataset_name))
-        cmc, mAP = evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, use_metric_cuhk03=use_metric_cuhk03)
+        if ddp.world_size() > 1 and not use_metric_cuhk03:
+            # every rank holds the full feature sets; each ranks its slice of the queries (ieee_amd/dist.py)
+            print('Computing CMC and mAP for {} (queries sharded over {} ranks)'.format(dataset_name, ddp.world_size()))
+            cmc, mAP = ddp.sharded_evaluate_rank(qf, gf, q_pids, g_pids, q_camids, g_camids, metric=dist_metric)
+        else:
+            distmat = compute_distance_matrix(qf, gf, dist_metric)
+            print('Computing CMC and mAP for {}'.format(dataset_name))
+            cmc, mAP = evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, use_metric_cuhk03=use_metric_cuhk03)
         print('** Results **')
         print('mAP: {:.2%}'.format(mAP))
         print('CMC curve')

@@ -15,9 +15,9 @@ def _i32(x, name, device):
     return torch.from_numpy(np.ascontiguousarray(x.astype(np.int32))).to(device)
 
 
-def eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
-    """rank.py:103-171.  distmat: numpy array (as the reference's caller passes, engine.py:400) or a
-    CUDA tensor (on-device hand-off, SURVEY.md §8f N1)."""
+def rank_counts(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
+    """the device part of eval_market1501: returns (cmc_counts int64[max_rank], num_valid_q, AP sum) of the given
+    queries -- additive over disjoint query sets, which is what a query-sharded evaluation all-reduces"""
     lib = _lib.require_gpu()
     if isinstance(distmat, torch.Tensor):
         d = distmat if distmat.is_cuda else distmat.cuda()
@@ -27,13 +27,12 @@ def eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
     if d.stride(-1) != 1:
         d = d.contiguous()
     num_q, num_g = d.shape
-    if num_g < max_rank:
-        max_rank = num_g
-        print('Note: number of gallery samples is quite small, got {}'.format(num_g))
     dev = d.device
     qp, gp = _i32(q_pids, "q_pids", dev), _i32(g_pids, "g_pids", dev)
     qc, gc = _i32(q_camids, "q_camids", dev), _i32(g_camids, "g_camids", dev)
     assert qp.numel() == num_q and qc.numel() == num_q and gp.numel() == num_g and gc.numel() == num_g
+    if num_q == 0:
+        return np.zeros(max_rank, dtype=np.int64), 0.0, 0.0
     ap = torch.empty(num_q, dtype=torch.float64, device=dev)
     first = torch.empty(num_q, dtype=torch.int32, device=dev)
     summary = torch.empty(max_rank + 2, dtype=torch.int64, device=dev)
@@ -41,11 +40,24 @@ def eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
                                         _lib.ptr(qc), _lib.ptr(gc), max_rank, _lib.ptr(ap), _lib.ptr(first),
                                         _lib.ptr(summary), _lib.stream()))
     s = summary.cpu().numpy()          # the evaluator's single read-back (22 words)
-    num_valid_q = float(s[max_rank])
+    return s[:max_rank].copy(), float(s[max_rank]), float(s[max_rank + 1:max_rank + 2].view(np.float64)[0])
+
+
+def finish_counts(cmc_counts, num_valid_q, ap_sum):
+    """rank.py:166-169: CMC curve and mAP from the summed per-query results"""
     assert num_valid_q > 0, 'Error: all query identities do not appear in gallery'
-    all_cmc = s[:max_rank].astype(np.float32) / np.float32(num_valid_q)     # rank.py:167-168
-    mAP = float(s[max_rank + 1:max_rank + 2].view(np.float64)[0] / num_valid_q)   # rank.py:169
-    return all_cmc, mAP
+    all_cmc = np.asarray(cmc_counts).astype(np.float32) / np.float32(num_valid_q)
+    return all_cmc, float(ap_sum / num_valid_q)
+
+
+def eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
+    """rank.py:103-171.  distmat: numpy array (as the reference's caller passes, engine.py:400) or a
+    CUDA tensor (on-device hand-off, SURVEY.md §8f N1)."""
+    num_g = distmat.shape[1]
+    if num_g < max_rank:
+        max_rank = num_g
+        print('Note: number of gallery samples is quite small, got {}'.format(num_g))
+    return finish_counts(*rank_counts(distmat, q_pids, g_pids, q_camids, g_camids, max_rank))
 
 
 def evaluate_py(distmat, q_pids, g_pids, q_camids, g_camids, max_rank, use_metric_cuhk03):

@@ -85,3 +85,64 @@ def test_two_rank_gloo_allreduce_and_loss_scaling():
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
         assert dict(ret) == {0: 1, 1: 1}
+
+
+# ---- query-sharded evaluator: host logic + the single 22-number all-reduce
+def _counts_np(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
+    """per-shard checker built on the oracle: sums of the per-query CMC rows / AP over the valid queries"""
+    import numpy as np
+    from oracle import evaluator as oe
+    counts, valid, ap_sum = np.zeros(max_rank, dtype=np.int64), 0, 0.0
+    for i in range(distmat.shape[0]):
+        try:
+            cmc, ap = oe.rank_market1501_np(distmat[i:i + 1], q_pids[i:i + 1], g_pids, q_camids[i:i + 1], g_camids, max_rank)
+        except AssertionError:      # this query's identity does not appear in the gallery
+            continue
+        counts += np.rint(cmc).astype(np.int64)
+        valid += 1
+        ap_sum += ap
+    return counts, float(valid), ap_sum
+
+
+def _eval_inputs():
+    import numpy as np
+    rng = np.random.RandomState(3)
+    Q, G, D = 37, 211, 16
+    qf = rng.randint(-3, 4, size=(Q, D)).astype(np.float32) + rng.rand(Q, D).astype(np.float32) * 1e-3
+    gf = rng.randint(-3, 4, size=(G, D)).astype(np.float32) + rng.rand(G, D).astype(np.float32) * 1e-3
+    q_pids, g_pids = rng.randint(0, 12, Q), rng.randint(0, 10, G)     # pids 10, 11 never appear in the gallery
+    q_cam, g_cam = rng.randint(0, 4, Q), rng.randint(0, 4, G)
+    return qf, gf, q_pids, g_pids, q_cam, g_cam
+
+
+def _eval_worker(rank, world, port, ret):
+    import numpy as np
+    from oracle import evaluator as oe
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    ddp.init_from_env(backend="gloo")
+    qf, gf, qp, gp, qc, gc = _eval_inputs()
+    cmc, m_ap = ddp.sharded_evaluate_rank(qf, gf, qp, gp, qc, gc, max_rank=20, distmat_fn=oe.sqeuclid_np,
+                                          counts_fn=_counts_np)
+    ref_cmc, ref_map = oe.rank_market1501_np(oe.sqeuclid_np(qf, gf), qp, gp, qc, gc, 20)
+    np.testing.assert_allclose(cmc, ref_cmc, rtol=0, atol=1e-7)
+    assert abs(m_ap - ref_map) < 1e-12
+    dist.destroy_process_group()
+    ret[rank] = (cmc.tolist(), m_ap)
+
+
+def test_query_shards_cover_all_rows():
+    for Q, W in ((10000, 8), (37, 2), (3, 4), (0, 2)):
+        spans = [ddp.query_shard(Q, W, r) for r in range(W)]
+        assert spans[0][0] == 0 and spans[-1][1] == Q
+        assert all(b == c for (_, b), (c, _) in zip(spans, spans[1:]))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_query_sharded_evaluator_matches_single_process(world):
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_eval_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        out = dict(ret)
+        assert len(out) == world and all(out[r] == out[0] for r in out)      # every rank reports the same result

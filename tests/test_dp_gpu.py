@@ -87,3 +87,38 @@ def test_two_rank_step_equals_serial_sum(tmp_path):
     ref = total.cpu()
     err = (got["grads"] - ref).abs().max().item() / ref.abs().max().item()
     assert err < 1e-6, err
+
+
+# ---- query-sharded evaluator on the device: two ranks share the GPU over gloo
+def _eval_data():
+    g = torch.Generator().manual_seed(11)
+    Q, G, D = 301, 2500, 768
+    qf = torch.randint(0, 5, (Q, D), generator=g).float()
+    gf = torch.randint(0, 5, (G, D), generator=g).float()
+    q_pids, g_pids = torch.randint(0, 60, (Q,), generator=g).numpy(), torch.randint(0, 55, (G,), generator=g).numpy()
+    q_cam, g_cam = torch.randint(0, 4, (Q,), generator=g).numpy(), torch.randint(0, 4, (G,), generator=g).numpy()
+    return qf, gf, q_pids, g_pids, q_cam, g_cam
+
+
+def _eval_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), IEEE_DIST_BACKEND="gloo", IEEE_FORCE_DEVICE="0")
+    from ieee_amd import dist as ddp
+    ddp.init_from_env()
+    qf, gf, qp, gp, qc, gc = _eval_data()
+    cmc, m_ap = ddp.sharded_evaluate_rank(qf.cuda(), gf.cuda(), qp, gp, qc, gc, max_rank=20)
+    torch.save({"cmc": torch.from_numpy(cmc), "mAP": m_ap}, out_path + str(rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_sharded_evaluator_equals_single_device(tmp_path):
+    from ieee_amd.metrics.distance import compute_distance_matrix
+    from ieee_amd.metrics.rank import evaluate_rank
+    out = str(tmp_path / "ev.pt")
+    mp.spawn(_eval_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    qf, gf, qp, gp, qc, gc = _eval_data()
+    cmc, m_ap = evaluate_rank(compute_distance_matrix(qf.cuda(), gf.cuda()), qp, gp, qc, gc, max_rank=20)
+    for r in range(2):
+        got = torch.load(out + str(r))
+        assert torch.equal(got["cmc"], torch.from_numpy(cmc))          # integer-grid features: no ties in rounding
+        assert abs(got["mAP"] - m_ap) < 1e-12
