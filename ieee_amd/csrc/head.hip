@@ -798,6 +798,42 @@ extern "C" int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, fl
   return launch_status("margin3m_sum_kernel");
 }
 
+// torch.optim.Adam (L2 weight decay folded into the gradient, bias-corrected, optional AMSGrad), single-tensor
+// semantics of torch/optim/adam.py::_single_tensor_adam: step_size = lr / (1 - b1^t),
+// denom = sqrt(v or vmax) / sqrt(1 - b2^t) + eps
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float* __restrict__ vmax, int64_t n, float lr, float b1, float b2,
+                            float eps, float wd, float bc1, float bc2_sqrt) {
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    const float d = g[i] + wd * w;
+    const float mi = m[i] + (d - m[i]) * (1.f - b1);          // lerp form, as torch does (exp_avg.lerp_)
+    const float vi = b2 * v[i] + (1.f - b2) * d * d;
+    m[i] = mi;
+    v[i] = vi;
+    float vv = vi;
+    if (vmax != nullptr) {
+      vv = fmaxf(vmax[i], vi);
+      vmax[i] = vv;
+    }
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = w - step_size * (mi / denom);
+  }
+}
+
+extern "C" int ieee_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                              float* max_exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int64_t step, void* stream) {
+  IEEE_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step: null pointer");
+  IEEE_REQUIRE(step >= 1, "adam_step: step counts from 1");
+  if (n <= 0) return IEEE_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  adam_kernel<<<ewb(n), 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, n, lr, beta1,
+                                                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+  return launch_status("adam_kernel");
+}
+
 extern "C" int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
                                       float momentum, float weight_decay, int nesterov, void* stream) {
   IEEE_REQUIRE(params && grads && (momentum == 0.f || momentum_buf), "sgd_nesterov_step: null pointer");

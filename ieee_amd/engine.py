@@ -25,7 +25,7 @@ from torch.nn import functional as F
 from . import _lib, dist as ddp
 from .losses import CrossEntropyLoss, DeepSupervision, multiModalMarginLossNew
 from .metrics import accuracy, compute_distance_matrix, evaluate_rank
-from .optim import FusedSGD
+from .optim import FusedAdam, FusedSGD
 
 
 class AverageMeter(object):
@@ -289,7 +289,7 @@ class _FusedStepMixin(object):
     """the native train step shared by the 3M and the CE-only engines"""
 
     def _fused_ok(self):
-        return _is_native(self.model) and isinstance(self.optimizer, FusedSGD) and self.use_gpu
+        return _is_native(self.model) and isinstance(self.optimizer, (FusedSGD, FusedAdam)) and self.use_gpu
 
     def _fused_step(self, imgs, pids, weight_x, weight_m, margin, eps):
         lib = _lib.require_gpu()

@@ -26,6 +26,13 @@ class _Node(nn.Module):
     def forward(self, *a, **k):
         raise RuntimeError("this module only holds parameters; call IEEE3modalPart.forward")
 
+    # the reference's containers are ModuleList / Sequential: keep `model.backbone[0].layer4[2].conv3.weight` working
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+    def __len__(self):
+        return len(self._modules)
+
 
 class _NetFunction(torch.autograd.Function):
     """autograd bridge for the drop-in path (any torch.optim over model.parameters())"""
@@ -70,10 +77,17 @@ class IEEE3modalPart(nn.Module):
         self._build_storage(device)
         self._init_params()
         if pretrained:
-            raise RuntimeError(
-                "pretrained=True needs resnet50-19c8e357.pth from the network (reference resnet.py:25-26, 1075-1089); "
-                "there is no network here. Build with pretrained=False and load weights with load_state_dict / "
-                "torchreid.utils.load_pretrained_weights.")
+            # reference: each backbone downloads resnet50-19c8e357.pth (resnet.py:25-26, 1259-1261).  No network here:
+            # use the file if it is already on disk ($IEEE_RESNET50_PTH or the torch hub cache), else say so.
+            from . import checkpoint as _ckpt
+            path = _ckpt.find_resnet50_file()
+            if path is None:
+                raise RuntimeError(
+                    "pretrained=True needs %s (reference resnet.py:25-26, 1075-1089) and there is no network: put the "
+                    "file in the torch hub cache or set IEEE_RESNET50_PTH, or build with pretrained=False and call "
+                    "ieee_amd.checkpoint.init_pretrained_backbones / load_pretrained_weights." % _ckpt.RESNET50_FILE)
+            print("load pretrained weights...")
+            _ckpt.init_pretrained_backbones(self, path)
 
     # ---- storage: one flat fp32 buffer per kind, parameters are views in state_dict order
     def _build_storage(self, device):

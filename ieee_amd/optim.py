@@ -40,6 +40,69 @@ class FusedSGD(torch.optim.Optimizer):
         for p in self.model.parameters():
             p.grad = None
 
+    def state_dict(self):
+        d = super(FusedSGD, self).state_dict()
+        d['fused'] = {'momentum_buffer': self._buf}
+        return d
+
+    def load_state_dict(self, state_dict):
+        fused = state_dict.get('fused')
+        super(FusedSGD, self).load_state_dict({k: v for k, v in state_dict.items() if k != 'fused'})
+        if fused is not None and fused.get('momentum_buffer') is not None:
+            self.momentum_buffer().copy_(fused['momentum_buffer'])
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas, eps=1e-8, weight_decay[, amsgrad]) over the model's flat buffers in one launch per
+    contiguous trainable run (reference optim/optimizer.py:113-128 builds exactly these two variants)."""
+
+    def __init__(self, model, lr=0.0003, betas=(0.9, 0.99), eps=1e-8, weight_decay=5e-4, amsgrad=False):
+        self.model = model
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+        super(FusedAdam, self).__init__(list(model.parameters()), defaults)
+        self._m = self._v = self._vmax = None
+        self._step = 0
+
+    def _buffers(self):
+        ref = self.model._flat_params
+        if self._m is None or self._m.device != ref.device:
+            self._m, self._v = torch.zeros_like(ref), torch.zeros_like(ref)
+            self._vmax = torch.zeros_like(ref) if self.param_groups[0]['amsgrad'] else None
+        return self._m, self._v, self._vmax
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        lib = _lib.require_gpu()
+        g = self.param_groups[0]
+        mdl = self.model
+        m, v, vmax = self._buffers()
+        self._step += 1
+        for a, b in mdl.trainable_runs():
+            _lib.check(lib.ieee_adam_step(_lib.ptr(mdl._flat_params[a:b]), _lib.ptr(mdl._flat_grads[a:b]), _lib.ptr(m[a:b]),
+                                          _lib.ptr(v[a:b]), _lib.ptr(vmax[a:b]) if vmax is not None else None, b - a,
+                                          float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                          float(g['weight_decay']), self._step, _lib.stream()))
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def state_dict(self):
+        d = super(FusedAdam, self).state_dict()
+        d['fused'] = {'step': self._step, 'exp_avg': self._m, 'exp_avg_sq': self._v, 'max_exp_avg_sq': self._vmax}
+        return d
+
+    def load_state_dict(self, state_dict):
+        fused = state_dict.get('fused')
+        super(FusedAdam, self).load_state_dict({k: v for k, v in state_dict.items() if k != 'fused'})
+        if fused is not None:
+            m, v, vmax = self._buffers()
+            self._step = int(fused['step'])
+            if fused['exp_avg'] is not None:
+                m.copy_(fused['exp_avg']); v.copy_(fused['exp_avg_sq'])
+                if vmax is not None and fused['max_exp_avg_sq'] is not None:
+                    vmax.copy_(fused['max_exp_avg_sq'])
+
 
 def build_optimizer(model, optim='adam', lr=0.0003, weight_decay=5e-04, momentum=0.9, sgd_dampening=0,
                     sgd_nesterov=False, rmsprop_alpha=0.99, adam_beta1=0.9, adam_beta2=0.99, staged_lr=False,
@@ -60,6 +123,9 @@ def build_optimizer(model, optim='adam', lr=0.0003, weight_decay=5e-04, momentum
             return FusedSGD(model, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True)
         return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay,
                                dampening=sgd_dampening, nesterov=True)
+    if optim in ('adam', 'amsgrad') and fused and hasattr(model, "trainable_runs"):
+        return FusedAdam(model, lr=lr, betas=(adam_beta1, adam_beta2), weight_decay=weight_decay,
+                         amsgrad=(optim == 'amsgrad'))
     if optim == 'adam':
         return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, betas=(adam_beta1, adam_beta2))
     if optim == 'amsgrad':

@@ -257,6 +257,12 @@ int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, float* dfeats
  * (torchreid/optim/optimizer.py:130-138) over a flat fp32 range */
 int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
                            float momentum, float weight_decay, int nesterov, void* stream);
+/* torch.optim.Adam / Adam(amsgrad=True) as the reference builds them for optim = 'adam' / 'amsgrad'
+ * (torchreid/optim/optimizer.py:113-128): L2 weight decay, bias correction with `step` (1-based);
+ * max_exp_avg_sq == NULL = plain Adam */
+int ieee_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                   void* stream);
 
 /* ---- whole-network executor --------------------------------------------------- */
 /* One handle = IEEE3modalPart (ieee3modalPart.py:286-523) for a fixed batch / image size / dtype.

@@ -1,0 +1,107 @@
+"""CPU: checkpoint / pretrained-weight interop of the flat-buffer model against the behaviour of
+the reference's torchreid/utils/torchtools.py and resnet.py:1075-1089 — same file format, same key set, "module."
+prefix handling, unmatched layers ignored, three backbones initialised from one ImageNet ResNet-50 dict."""
+import os
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from ieee_amd import checkpoint as ckpt
+from ieee_amd.models import build_model
+
+C = 171
+
+
+def _model(num_classes=C, seed=0):
+    torch.manual_seed(seed)
+    return build_model("ieee3modalPart", num_classes=num_classes, loss="margin", pretrained=False, device="cpu")
+
+
+def _fake_resnet50(model):
+    """a torchvision-style ResNet-50 state_dict with distinctive values (names = the reference backbone's own names)"""
+    sd = OrderedDict()
+    for i, (k, v) in enumerate(model.state_dict().items()):
+        if k.startswith("backbone.0."):
+            sd[k[len("backbone.0."):]] = torch.full_like(v, (i % 97) + 1) if v.dtype.is_floating_point else v.clone() + 7
+    sd["fc.weight"] = torch.ones(1000, 2048)
+    sd["fc.bias"] = torch.ones(1000)
+    return sd
+
+
+def test_checkpoint_round_trip_and_module_prefix(tmp_path):
+    a = _model(seed=1)
+    with torch.no_grad():
+        a._flat_params.normal_()
+        a._flat_buffers.uniform_(0.5, 1.5)
+    ckpt.save_checkpoint({"state_dict": a.state_dict(), "epoch": 3, "rank1": 0.5}, str(tmp_path))
+    f = str(tmp_path / "model.pth.tar-3")
+    assert os.path.exists(f)
+    b = _model(seed=2)
+    assert ckpt.resume_from_checkpoint(f, b) == 3
+    for (k1, v1), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    # parameters are still views of the flat buffer (load_state_dict copied in place)
+    assert b.backbone[0].conv1.weight.data_ptr() == b._flat_params.data_ptr()
+    # DataParallel-style keys + a classifier of another size: matched layers load, the rest is reported
+    pref = OrderedDict(("module." + k, v) for k, v in a.state_dict().items())
+    torch.save({"state_dict": pref}, str(tmp_path / "dp.pth"))
+    c = _model(num_classes=C + 5, seed=3)
+    before = c.classifier_R[0].weight.clone()
+    matched, discarded = ckpt.load_pretrained_weights(c, str(tmp_path / "dp.pth"))
+    assert len(matched) + len(discarded) == len(pref)
+    assert sorted(discarded) == sorted(k for k in a.state_dict() if k.startswith("classifier_"))
+    assert torch.equal(c.classifier_R[0].weight, before)
+    assert torch.equal(c.backbone[2].layer4[2].conv3.weight, a.backbone[2].layer4[2].conv3.weight)
+    with pytest.raises(FileNotFoundError):
+        ckpt.load_checkpoint(str(tmp_path / "nope"))
+    with pytest.raises(ValueError):
+        ckpt.load_checkpoint(None)
+
+
+def test_imagenet_resnet50_initialises_the_three_backbones(tmp_path, monkeypatch):
+    m = _model(seed=4)
+    fake = _fake_resnet50(m)
+    head_before = m.reduce_layer[0].layers[0].weight.clone()
+    n = ckpt.init_pretrained_backbones(m, fake)
+    assert n == 3 * (len(fake) - 2)                     # fc.weight / fc.bias have no counterpart
+    sd = m.state_dict()
+    for k, v in fake.items():
+        if k.startswith("fc."):
+            continue
+        for mod in range(3):
+            assert torch.equal(sd["backbone.%d.%s" % (mod, k)], v)
+    assert torch.equal(m.reduce_layer[0].layers[0].weight, head_before)
+    # pretrained=True: uses the file when it is on disk, explains itself when it is not
+    path = str(tmp_path / ckpt.RESNET50_FILE)
+    torch.save(fake, path)
+    monkeypatch.setenv("IEEE_RESNET50_PTH", path)
+    p = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=True, device="cpu")
+    assert torch.equal(p.state_dict()["backbone.1.layer3.5.bn2.weight"], fake["layer3.5.bn2.weight"])
+    monkeypatch.delenv("IEEE_RESNET50_PTH")
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "empty"))
+    with pytest.raises(RuntimeError, match="no network"):
+        build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=True, device="cpu")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/torchreid"), reason="reference tree not present")
+def test_checkpoints_interoperate_with_the_reference_model(tmp_path):
+    """a checkpoint written here loads into the reference's IEEE3modalPart with its own loader (strict), and one
+    written by the reference loads here: same keys, same shapes, same order"""
+    from oracle.ref_import import import_reference
+    torchreid = import_reference()
+    ours = _model(seed=5)
+    with torch.no_grad():
+        ours._flat_params.normal_(0, 0.05)
+    ckpt.save_checkpoint({"state_dict": ours.state_dict(), "epoch": 1}, str(tmp_path))
+    rm = torchreid.models.build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, use_gpu=False)
+    state = torch.load(str(tmp_path / "model.pth.tar-1"), weights_only=False)["state_dict"]
+    rm.load_state_dict(state)                                           # strict: key sets identical
+    assert list(rm.state_dict().keys()) == list(ours.state_dict().keys())
+    with torch.no_grad():
+        for p in rm.parameters():
+            p.mul_(0.5)
+    torch.save({"state_dict": rm.state_dict(), "epoch": 9}, str(tmp_path / "ref.pth"))
+    back = _model(seed=6)
+    assert ckpt.resume_from_checkpoint(str(tmp_path / "ref.pth"), back) == 9
+    assert torch.equal(back.backbone[1].layer2[0].conv2.weight, ours.backbone[1].layer2[0].conv2.weight * 0.5)

@@ -121,3 +121,32 @@ def test_softmax_engine_and_eval_pipeline(capsys):
     rank1_map = eng.test()
     out = capsys.readouterr().out
     assert "mAP:" in out and "Rank-1" in out and 0.0 <= rank1_map <= 1.0
+
+
+def test_fused_adam_engine_step_matches_torch_adam_on_the_same_gradients():
+    """build_optimizer(optim='amsgrad') returns FusedAdam for the native model; one engine step must move the
+    parameters exactly like torch.optim.Adam(amsgrad=True) fed with the gradients that step left in the flat buffer"""
+    from ieee_amd.engine import Image3MEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import FusedAdam, build_optimizer
+    from tests.util_model import generated_state, images
+    m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, compute_dtype=torch.float32)
+    m.load_state_dict(generated_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 5))
+    opt = build_optimizer(m, optim="amsgrad", lr=3e-4, weight_decay=5e-4)
+    assert isinstance(opt, FusedAdam)
+    eng = Image3MEngine(FakeDM(), m, opt, margin=1, use_gpu=True)
+    m.train()
+    before = m._flat_params.clone()
+    B = 8
+    pids = torch.arange(B) // 4
+    eng.forward_backward({"img": images(B, 5), "pid": pids, "camid": pids * 0, "impath": "", "timeid": pids * 0})
+    grads = m._flat_grads.clone()
+    ref = torch.nn.Parameter(before.clone())
+    ref.grad = grads.clone()
+    torch.optim.Adam([ref], lr=3e-4, betas=(0.9, 0.99), weight_decay=5e-4, amsgrad=True).step()
+    # parameters that receive no gradient (REM.conv_value) are not part of any trainable run and must not move
+    moved = torch.zeros_like(before, dtype=torch.bool)
+    for a, b in m.trainable_runs():
+        moved[a:b] = True
+    torch.testing.assert_close(m._flat_params[moved], ref.detach()[moved], rtol=1e-5, atol=1e-7)
+    assert torch.equal(m._flat_params[~moved], before[~moved])

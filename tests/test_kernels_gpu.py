@@ -398,3 +398,30 @@ def test_sgemm_grouped_splitk_matches_matmul(layout):
         L.check(lib.ieee_sgemm_grouped_ws(G, tab(list(a2)), tab(list(b2)), tab(list(C2)), None, M2, N2, K, 1, M2, 1, N2, N2,
                                           1.0, 0, 0, L.ptr(work), work.numel(), L.stream()))
         torch.testing.assert_close(C2.double(), (A.double() @ Bm.double().transpose(1, 2))[:, :M2, :N2], rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amsgrad", [False, True])
+def test_adam_step_matches_torch_adam(amsgrad):
+    """ieee_adam_step against torch.optim.Adam (what the reference builds for optim='adam'/'amsgrad',
+    optim/optimizer.py:113-128) over three steps with changing gradients"""
+    from ieee_amd import _lib as L
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(9)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref_p], lr=3e-4, betas=(0.9, 0.99), weight_decay=5e-4, amsgrad=amsgrad)
+    p = p0.clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    vmax = torch.zeros(n, device="cuda") if amsgrad else None
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * (10.0 ** (step - 2))
+        ref_p.grad = grad.clone()
+        opt.step()
+        L.check(lib.ieee_adam_step(L.ptr(p), L.ptr(grad.cuda()), L.ptr(m), L.ptr(v), L.ptr(vmax) if amsgrad else None, n,
+                                   3e-4, 0.9, 0.99, 1e-8, 5e-4, step, L.stream()))
+        torch.testing.assert_close(p.cpu(), ref_p.detach(), rtol=1e-6, atol=1e-7)
+    st = opt.state[ref_p]
+    torch.testing.assert_close(m.cpu(), st["exp_avg"], rtol=1e-5, atol=1e-6)        # sums with cancellation near 0
+    torch.testing.assert_close(v.cpu(), st["exp_avg_sq"], rtol=1e-5, atol=1e-8)
