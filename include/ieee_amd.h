@@ -264,6 +264,21 @@ int ieee_adam_step(float* params, const float* grads, float* exp_avg, float* exp
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                    void* stream);
 
+/* ---- input pipeline ------------------------------------------ */
+/* The reference's per-image chain Resize((Ho,Wo)) -> RandomHorizontalFlip -> ToTensor -> Normalize
+ * (torchreid/data/transforms.py:233-326; dataset.py:335-351) for N decoded uint8 images of ONE source size:
+ * src [N][Hs][Ws][3] (device) -> dst [N][3][Ho][Wo] fp32 (device).  The resize is Pillow's two-pass 8-bit bilinear
+ * resampler, bit-exact: bounds_* [out][2] = (first source index, count), kk_* [out][ksize] = 22-bit fixed-point
+ * weights, both computed on the host as Pillow does (ieee_amd/data/transforms.py) and resident on the device; a
+ * table is NULL iff that axis keeps its size.  tmp: [N][tmp_rows][Wo][3] bytes for the horizontal pass, which only
+ * covers source rows ybox_first .. ybox_first+tmp_rows (what the vertical pass reads).  flip [N] bytes or NULL;
+ * mean3 / std3: HOST pointers to 3 floats. */
+int ieee_resize_flip_normalize(const uint8_t* src, float* dst, uint8_t* tmp, int64_t N, int64_t Hs, int64_t Ws,
+                               int64_t Ho, int64_t Wo, const int32_t* bounds_h, const int32_t* kk_h, int64_t ksize_h,
+                               const int32_t* bounds_v, const int32_t* kk_v, int64_t ksize_v, int64_t ybox_first,
+                               int64_t tmp_rows, const uint8_t* flip, const float* mean3, const float* std3,
+                               void* stream);
+
 /* ---- whole-network executor --------------------------------------------------- */
 /* One handle = IEEE3modalPart (ieee3modalPart.py:286-523) for a fixed batch / image size / dtype.
  * The caller owns three flat fp32 buffers laid out like the reference's state_dict: parameters,
