@@ -9,20 +9,26 @@
 
 namespace ieee {
 
-// fp32 NCHW images (three separate tensors, as the reference's batch dict carries them) -> NHWC T
+// fp32 NCHW images (three separate tensors, as the reference's batch dict carries them) -> NHWC T with the channel
+// axis padded to Cpad and a zero border of `pad` pixels on every side (pad = 3: the stem conv then needs no bounds tests)
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* x0, const float* x1, const float* x2, T* out, int B, int C, int HW,
-                                    int Cpad) {
+__global__ void nchw_to_nhwc_kernel(const float* x0, const float* x1, const float* x2, T* out, int B, int C, int H,
+                                    int W, int Cpad, int pad) {
   const int z = blockIdx.y;
   const float* x = z == 0 ? x0 : (z == 1 ? x1 : x2);
-  const int64_t total = (int64_t)B * HW * Cpad;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int64_t total = (int64_t)B * Hp * Wp * Cpad;
   T* o = out + z * total;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cpad);
-    const int64_t p = i / Cpad;
-    const int hw = (int)(p % HW);
-    const int b = (int)(p / HW);
-    o[i] = c < C ? from_f32<T>(x[((int64_t)b * C + c) * HW + hw]) : from_f32<T>(0.f);
+    int64_t p = i / Cpad;
+    const int wp = (int)(p % Wp); p /= Wp;
+    const int hp = (int)(p % Hp);
+    const int b = (int)(p / Hp);
+    const int h = hp - pad, w = wp - pad;
+    float v = 0.f;
+    if (c < C && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v = x[(((int64_t)b * C + c) * H + h) * W + w];
+    o[i] = from_f32<T>(v);
   }
 }
 
@@ -517,13 +523,13 @@ static int vecw(int dtype) { return dtype == IEEE_BF16 ? 8 : 4; }
   } while (0)
 
 extern "C" int ieee_nchw_to_nhwc3(const float* x_rgb, const float* x_ni, const float* x_ti, void* out, int dtype,
-                                  int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cpad, void* stream) {
+                                  int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cpad, int64_t pad, void* stream) {
   IEEE_REQUIRE(x_rgb && x_ni && x_ti && out, "nchw_to_nhwc3: null pointer");
-  IEEE_REQUIRE(Cpad >= C, "nchw_to_nhwc3: Cpad < C");
+  IEEE_REQUIRE(Cpad >= C && pad >= 0, "nchw_to_nhwc3: Cpad < C or negative padding");
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(ew_blocks2(B * Cpad * H * W), 3);
-  DISPATCH_T(dtype, (nchw_to_nhwc_kernel<float><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (float*)out, (int)B, (int)C, (int)(H * W), (int)Cpad)),
-             (nchw_to_nhwc_kernel<bf16><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (bf16*)out, (int)B, (int)C, (int)(H * W), (int)Cpad)));
+  dim3 grid(ew_blocks2(B * Cpad * (H + 2 * pad) * (W + 2 * pad)), 3);
+  DISPATCH_T(dtype, (nchw_to_nhwc_kernel<float><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (float*)out, (int)B, (int)C, (int)H, (int)W, (int)Cpad, (int)pad)),
+             (nchw_to_nhwc_kernel<bf16><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (bf16*)out, (int)B, (int)C, (int)H, (int)W, (int)Cpad, (int)pad)));
   return launch_status("nchw_to_nhwc_kernel");
 }
 

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // (zero fill beyond: the channel / column padded stem)
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int Co, int Ci, int R, int S,
-                                   int ld, int mode, int64_t w_gs, int64_t dst_gs, int Ci_src, int S_src) {
+                                   int ld, int mode, int64_t w_gs, int64_t dst_gs, int Ci_src, int S_src, int R_src) {
   const int z = blockIdx.y;
   const int rows = mode == 0 ? Co : Ci;
   const int64_t total = (int64_t)rows * ld;
@@ -371,21 +371,22 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     const int tap = col / inner, c = col % inner;
     const int co = mode == 0 ? row : c, ci = mode == 0 ? c : row;
     const int rr = tap / S, ss = tap % S;
-    if (ci < Ci_src && ss < S_src) v = w[z * w_gs + (((int64_t)co * Ci_src + ci) * R + rr) * S_src + ss];
+    if (ci < Ci_src && ss < S_src && rr < R_src) v = w[z * w_gs + (((int64_t)co * Ci_src + ci) * R_src + rr) * S_src + ss];
   }
   dst[z * dst_gs + i] = from_f32<T>(v);
 }
 
 // dw_real[co][ci][r][s] (Ci_src x S_src) = dw_padded[co][ci][r][s] (Ci x S): drop the padded entries
 __global__ void unpad_weight_grad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int R,
-                                         int S, int Ci_src, int S_src, int64_t dwp_gs, int64_t dw_gs, int accumulate) {
+                                         int S, int Ci_src, int S_src, int R_src, int64_t dwp_gs, int64_t dw_gs,
+                                         int accumulate) {
   const int z = blockIdx.y;
-  const int64_t total = (int64_t)Co * Ci_src * R * S_src;
+  const int64_t total = (int64_t)Co * Ci_src * R_src * S_src;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int ss = (int)(i % S_src);
   int64_t t = i / S_src;
-  const int rr = (int)(t % R); t /= R;
+  const int rr = (int)(t % R_src); t /= R_src;
   const int ci = (int)(t % Ci_src);
   const int co = (int)(t / Ci_src);
   const float v = dwp[z * dwp_gs + (((int64_t)co * Ci + ci) * R + rr) * S + ss];
@@ -400,7 +401,8 @@ struct PackDesc {
   int64_t dst_off, dst_gs;   // elements of T, relative to the workspace base given to the kernel
   int Co, Ci, R, S, ld, mode, Ci_src, S_src;
   int block_begin;           // first blockIdx.x of this descriptor
-  int pad_;
+  int pad_;                  // 0 = direct form, 1..3 = the LDS-tiled forms below
+  int R_src, reserved_;      // rows of the fp32 source (R_src <= R: zero rows beyond)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__ params, char* __restrict__ ws,
@@ -501,8 +503,8 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     const unsigned tap = col / inner, c = col - tap * inner;
     const unsigned co = d.mode == 0 ? row : c, ci = d.mode == 0 ? c : row;
     const unsigned rr = tap / (unsigned)d.S, ss = tap - rr * (unsigned)d.S;
-    if (ci < (unsigned)d.Ci_src && ss < (unsigned)d.S_src)
-      v = src[((co * (unsigned)d.Ci_src + ci) * (unsigned)d.R + rr) * (unsigned)d.S_src + ss];
+    if (ci < (unsigned)d.Ci_src && ss < (unsigned)d.S_src && rr < (unsigned)d.R_src)
+      v = src[((co * (unsigned)d.Ci_src + ci) * (unsigned)d.R_src + rr) * (unsigned)d.S_src + ss];
   }
   dst[i] = from_f32<T>(v);
 }
@@ -659,21 +661,21 @@ extern "C" int64_t ieee_conv_packed_ld(int dtype, int64_t inner_channels, int64_
 }
 
 extern "C" int ieee_pack_conv_weight_padded(const float* w_oihw, void* dst, int dtype, int mode, int64_t groups,
-                                            int64_t Co, int64_t Ci_src, int64_t R, int64_t S_src, int64_t Ci,
-                                            int64_t S, int64_t w_gs, int64_t dst_gs, void* stream) {
+                                            int64_t Co, int64_t Ci_src, int64_t R_src, int64_t S_src, int64_t Ci,
+                                            int64_t R, int64_t S, int64_t w_gs, int64_t dst_gs, void* stream) {
   IEEE_REQUIRE(w_oihw && dst, "pack_conv_weight_padded: null pointer");
   IEEE_REQUIRE(mode == 0, "pack_conv_weight_padded: forward packing only (the padded stem has no dgrad)");
   IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "pack_conv_weight_padded: bad dtype");
-  IEEE_REQUIRE(Ci_src <= Ci && S_src <= S, "pack_conv_weight_padded: source larger than destination");
+  IEEE_REQUIRE(Ci_src <= Ci && S_src <= S && R_src <= R, "pack_conv_weight_padded: source larger than destination");
   const int64_t ld = ieee_conv_packed_ld(dtype, Ci, R, S);
   dim3 grid(cdiv(Co * ld, 256), (unsigned)groups);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IEEE_F32)
     pack_weight_kernel<float><<<grid, 256, 0, st>>>(w_oihw, (float*)dst, (int)Co, (int)Ci, (int)R, (int)S, (int)ld, 0,
-                                                    w_gs, dst_gs, (int)Ci_src, (int)S_src);
+                                                    w_gs, dst_gs, (int)Ci_src, (int)S_src, (int)R_src);
   else
     pack_weight_kernel<bf16><<<grid, 256, 0, st>>>(w_oihw, (bf16*)dst, (int)Co, (int)Ci, (int)R, (int)S, (int)ld, 0,
-                                                   w_gs, dst_gs, (int)Ci_src, (int)S_src);
+                                                   w_gs, dst_gs, (int)Ci_src, (int)S_src, (int)R_src);
   return launch_status("pack_weight_kernel");
 }
 
@@ -696,12 +698,14 @@ extern "C" int ieee_pack_all_weights(const float* params, void* ws_base, const v
 }
 
 extern "C" int ieee_unpad_weight_grad(const float* dw_padded, float* dw, int64_t groups, int64_t Co, int64_t Ci,
-                                      int64_t R, int64_t S, int64_t Ci_src, int64_t S_src, int64_t dwp_gs,
-                                      int64_t dw_gs, int accumulate, void* stream) {
+                                      int64_t R, int64_t S, int64_t Ci_src, int64_t R_src, int64_t S_src,
+                                      int64_t dwp_gs, int64_t dw_gs, int accumulate, void* stream) {
   IEEE_REQUIRE(dw_padded && dw, "unpad_weight_grad: null pointer");
-  dim3 grid(cdiv(Co * Ci_src * R * S_src, 256), (unsigned)groups);
+  IEEE_REQUIRE(Ci_src <= Ci && S_src <= S && R_src <= R, "unpad_weight_grad: source larger than the padded tensor");
+  dim3 grid(cdiv(Co * Ci_src * R_src * S_src, 256), (unsigned)groups);
   unpad_weight_grad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(dw_padded, dw, (int)Co, (int)Ci, (int)R, (int)S,
-                                                                  (int)Ci_src, (int)S_src, dwp_gs, dw_gs, accumulate);
+                                                                  (int)Ci_src, (int)S_src, (int)R_src, dwp_gs, dw_gs,
+                                                                  accumulate);
   return launch_status("unpad_weight_grad_kernel");
 }
 
@@ -716,10 +720,10 @@ extern "C" int ieee_pack_conv_weight(const float* w_oihw, void* dst, int dtype, 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == IEEE_F32)
     pack_weight_kernel<float><<<grid, 256, 0, st>>>(w_oihw, (float*)dst, (int)Co, (int)Ci, (int)R, (int)S, (int)ld,
-                                                    mode, w_gs, dst_gs, (int)Ci, (int)S);
+                                                    mode, w_gs, dst_gs, (int)Ci, (int)S, (int)R);
   else
     pack_weight_kernel<bf16><<<grid, 256, 0, st>>>(w_oihw, (bf16*)dst, (int)Co, (int)Ci, (int)R, (int)S, (int)ld, mode,
-                                                   w_gs, dst_gs, (int)Ci, (int)S);
+                                                   w_gs, dst_gs, (int)Ci, (int)S, (int)R);
   return launch_status("pack_weight_kernel");
 }
 
@@ -732,7 +736,13 @@ extern "C" int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int
   IEEE_REQUIRE(Co % 4 == 0, "conv2d_fwd: Cout %ld must be a multiple of 4", (long)Co);
   GatherGeom g{d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.R, d.S, d.stride, -d.pad, +1, 1, d.N * d.Ho * d.Wo};
   const int bk = elem_bk(dtype);
-  const bool fast = (Ci % bk == 0) || (Ci < bk && Ci % elem_vec(dtype) == 0 && bk % Ci == 0 && S % (bk / Ci) == 0);
+  const int vec = elem_vec(dtype);
+  // vector path: whole k-tiles per tap; or several whole taps per k-tile inside one filter row; or (Ci < one 16-byte
+  // chunk, no padding) chunks of vec/Ci horizontally adjacent pixels and k-tiles of whole filter rows -- see
+  // LoaderIm2colNT
+  const bool fast = (Ci % bk == 0) || (Ci < bk && Ci % vec == 0 && bk % Ci == 0 && S % (bk / Ci) == 0) ||
+                    (Ci < vec && vec % Ci == 0 && pad == 0 && (bk / Ci) % S == 0 && R % ((bk / Ci) / S) == 0 &&
+                     S % (vec / Ci) == 0 && Wi % (vec / Ci) == 0 && stride % (vec / Ci) == 0);
   const bool slow = !fast;
   const int ldw = (int)ieee_conv_packed_ld(dtype, Ci, R, S);
   hipStream_t st = (hipStream_t)stream;
@@ -825,7 +835,11 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   a.dy_gs = dy_gs;
   a.x_gs = x_gs;
   a.slab_gs = (int64_t)nsplit * d.Co * a.ncols;
-  const bool slow = (Ci % elem_vec(dtype)) != 0;
+  const int vec = elem_vec(dtype);
+  // a 16-byte chunk of im2col(X) is vec consecutive channels of one tap, or (Ci < vec, no padding) vec/Ci adjacent pixels
+  const bool chunk_ok = Ci % vec == 0 || (vec % Ci == 0 && pad == 0 && S % (vec / Ci) == 0 && Wi % (vec / Ci) == 0 &&
+                                          stride % (vec / Ci) == 0);
+  const bool slow = !chunk_ok;
   a.plain_x = (d.R == 1 && d.S == 1 && d.stride == 1 && d.pad == 0) ? 1 : 0;
   const int nkz = nsplit * (int)groups;
   static const int f_map = getenv("IEEE_WGRAD_MAP") ? atoi(getenv("IEEE_WGRAD_MAP")) : 2;

@@ -513,8 +513,10 @@ struct GatherGeom {
   int npix;            // N*Ho*Wo
 };
 
-// Fast path: either Cs % BK == 0 (a k-tile stays inside one tap) or BK % Cs == 0 with S % (BK/Cs) == 0
-// (a k-tile covers BK/Cs consecutive horizontal taps of one row: the channel-padded stem, Cs = 8).
+// Fast path: either Cs % BK == 0 (a k-tile stays inside one tap) or BK % Cs == 0 and the BK/Cs taps of a k-tile are
+// consecutive horizontal taps: part of one filter row (S % (BK/Cs) == 0: the 8-channel padded stem) or whole rows
+// ((BK/Cs) % S == 0, R % ((BK/Cs)/S) == 0: the 4-channel stem, whose 16-byte chunk is TWO horizontally adjacent
+// pixels -- that form is only used without padding, so both taps of a chunk are always in range).
 // All per-pixel work is done once: each slot keeps a 32-bit element offset of its (un-tapped) source pixel
 // and a bit mask of the taps that fall inside the image; per k-tile the tap contributes one wave-uniform
 // offset, so a load costs a shift/test and one add (the 64-bit multiplies of a per-tile decode used to
@@ -542,7 +544,13 @@ template <typename T, int NCH> struct LoaderIm2colNT {
     int coff = ch * VEC;
     ds = 0;
     tpt = 1;
-    if (g.Cs < BK) { tpt = BK / g.Cs; ds = coff / g.Cs; coff -= ds * g.Cs; }
+    int dr = 0;      // this chunk's tap offset inside the k-tile: dr filter rows down, ds taps right
+    if (g.Cs < BK) {
+      tpt = BK / g.Cs;
+      ds = coff / g.Cs;
+      coff -= ds * g.Cs;
+      if (tpt > g.S) { dr = ds / g.S; ds -= dr * g.S; }
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int m = m0 + (t >> 3) + 32 * i;
@@ -551,7 +559,7 @@ template <typename T, int NCH> struct LoaderIm2colNT {
       if (m < g.npix) {
         const int n = m / hw, rem = m - n * hw;
         const int pp = rem / g.Wo, qq = rem - pp * g.Wo;
-        const int hb = pp * g.mul + g.off, wb = qq * g.mul + g.off + g.sgn * ds;
+        const int hb = pp * g.mul + g.off + g.sgn * dr, wb = qq * g.mul + g.off + g.sgn * ds;
         const int he = g.div == 2 ? (hb >> 1) : hb, we = g.div == 2 ? (wb >> 1) : wb;
         off[i] = ((n * g.Hs + he) * g.Ws + we) * g.Cs + coff;
         for (int rr = 0; rr < g.R; ++rr)
@@ -577,7 +585,7 @@ template <typename T, int NCH> struct LoaderIm2colNT {
   __device__ __forceinline__ void next() {
     if (g.Cs < BK) {
       s += tpt;
-      if (s >= g.S) { s = 0; ++r; }
+      while (s >= g.S) { s -= g.S; ++r; }
     } else {
       ci0 += BK;
       if (ci0 < g.Cs) return;

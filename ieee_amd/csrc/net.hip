@@ -27,7 +27,7 @@ struct ConvUnit {
   std::string name;
   int Ci, Co, R, stride, pad, Hi, Wi, Ho, Wo;
   int S = 0;                       // kernel width (== R except for the column-padded stem)
-  int Ci_src = 0, S_src = 0;       // dims of the reference parameter when the unit runs zero-padded
+  int Ci_src = 0, S_src = 0, R_src = 0;   // dims of the reference parameter when the unit runs zero-padded
   int s_w, s_g, s_b, s_rm, s_rv;   // slot ids of modality 0 (modality m = id + m)
   Tensor y, a, stats, wf, wd, dwpad;
   bool need_dgrad = true;
@@ -39,6 +39,7 @@ struct PackDescHost {
   int64_t src_off, src_gs, dst_off, dst_gs;
   int Co, Ci, R, S, ld, mode, Ci_src, S_src;
   int block_begin, pad_;
+  int R_src, reserved_;
 };
 extern "C" int ieee_pack_all_weights(const float* params, void* ws_base, const void* descs, int64_t ndesc,
                                      int64_t total_blocks, int dtype, void* stream);
@@ -141,7 +142,7 @@ struct Net {
                int Wi) {
     ConvUnit u;
     u.name = conv;
-    u.Ci = Ci; u.Co = Co; u.R = R; u.S = R; u.Ci_src = Ci; u.S_src = R;
+    u.Ci = Ci; u.Co = Co; u.R = R; u.S = R; u.Ci_src = Ci; u.S_src = R; u.R_src = R;
     u.stride = stride; u.pad = pad; u.Hi = Hi; u.Wi = Wi;
     u.Ho = (Hi + 2 * pad - R) / stride + 1;
     u.Wo = (Wi + 2 * pad - R) / stride + 1;
@@ -159,12 +160,17 @@ struct Net {
 
 void Net::build() {
   const std::string bb = "backbone.{m}.";
+  // The stem (conv 7x7/2 pad 3 over 3 channels, resnet.py:622) runs as an 8x8/2 convolution WITHOUT padding over a
+  // 4-channel image that ieee_nchw_to_nhwc3 writes with a 3-pixel zero border: the 8th filter row / column and the 4th
+  // channel are zero.  A 16-byte chunk is then two horizontally adjacent pixels, a k-tile of 64 two whole filter rows
+  // (K = 256, 4 k-tiles instead of the 7 of an 8-channel 7x8 form), and no load needs a bounds test.
   u_stem = add_unit(bb + "conv1", bb + "bn1", 3, 64, 7, 2, 3, H, W);
   units[u_stem].need_dgrad = false;
-  // the stem runs as a 7x8 conv over 8 (zero-padded) channels: one k-tile = 8 contiguous NHWC pixels of one
-  // input row, so it takes the vectorised / LDS-DMA path instead of a 3-channel element-wise gather
-  units[u_stem].Ci = 8;
-  units[u_stem].S = 8;
+  {
+    ConvUnit& s = units[u_stem];
+    s.Ci = 4; s.R = 8; s.S = 8;            // (Ci_src, R_src, S_src) stay (3, 7, 7)
+    s.Hi = H + 6; s.Wi = W + 6; s.pad = 0;  // same output size: (H + 6 - 8) / 2 + 1 = (H + 6 - 7) / 2 + 1 for even H
+  }
   int h = units[u_stem].Ho, w = units[u_stem].Wo;
   h = (h + 2 - 3) / 2 + 1;   // maxpool 3x3 s2 p1
   w = (w + 2 - 3) / 2 + 1;
@@ -227,7 +233,7 @@ extern "C" int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t 
 void Net::plan() {
   ws_bytes = 0;
   const int dt = dtype;
-  x0 = alloc("x0", (int64_t)3 * B * H * W * 8, dt);
+  x0 = alloc("x0", (int64_t)3 * B * (H + 6) * (W + 6) * 4, dt);
   int64_t max_act = 0, max_slab = 0, max_part = 0, max_c = 0;
   for (size_t i = 0; i < units.size(); ++i) {
     ConvUnit& u = units[i];
@@ -237,7 +243,7 @@ void Net::plan() {
     u.stats = alloc(u.name + ".stats", (int64_t)3 * 4 * u.Co, IEEE_F32);
     u.wf = alloc("", 3 * u.Co * ieee_conv_packed_ld(dt, u.Ci, u.R, u.S), dt);
     if (u.need_dgrad) u.wd = alloc("", 3 * u.Ci * ieee_conv_packed_ld(dt, u.Co, u.R, u.S), dt);
-    if (u.Ci != u.Ci_src || u.S != u.S_src) u.dwpad = alloc("", (int64_t)3 * u.Co * u.Ci * u.R * u.S, IEEE_F32);
+    if (u.Ci != u.Ci_src || u.S != u.S_src || u.R != u.R_src) u.dwpad = alloc("", (int64_t)3 * u.Co * u.Ci * u.R * u.S, IEEE_F32);
     max_act = std::max(max_act, n);
     if (u.need_dgrad) max_act = std::max(max_act, (int64_t)3 * B * u.Hi * u.Wi * u.Ci);
     max_slab = std::max(max_slab, ieee_conv2d_wgrad_workspace_bytes(dt, 3, B, u.Ho, u.Wo, u.Ci, u.Co, u.R, u.S));
@@ -314,8 +320,8 @@ struct Run {
 
   int pack(const ConvUnit& u, bool with_dgrad) {
     const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
-    if (u.Ci != u.Ci_src || u.S != u.S_src) {
-      IEEE_TRY(ieee_pack_conv_weight_padded(par(u.s_w), P(u.wf), n.dtype, 0, 3, u.Co, u.Ci_src, u.R, u.S_src, u.Ci, u.S,
+    if (u.Ci != u.Ci_src || u.S != u.S_src || u.R != u.R_src) {
+      IEEE_TRY(ieee_pack_conv_weight_padded(par(u.s_w), P(u.wf), n.dtype, 0, 3, u.Co, u.Ci_src, u.R_src, u.S_src, u.Ci, u.R, u.S,
                                             gs(u.s_w), u.Co * ldf, st));
       return IEEE_OK;
     }
@@ -334,10 +340,10 @@ struct Run {
     }
     (void)hipEventRecord(n.ev_pool[n.ev_used], (hipStream_t)st);
     n.ev_cat.push_back(cat);
-    n.ev_name.push_back(u.name + " " + std::to_string(u.Ci_src) + "->" + std::to_string(u.Co) + " k" + std::to_string(u.R) +
+    n.ev_name.push_back(u.name + " " + std::to_string(u.Ci_src) + "->" + std::to_string(u.Co) + " k" + std::to_string(u.R_src) +
                         " s" + std::to_string(u.stride) + " " + std::to_string(u.Ho) + "x" + std::to_string(u.Wo));
-    n.ev_flops.push_back(3.0 * 2.0 * (double)u.M(B) * u.Co * u.R * u.S_src * u.Ci_src);
-    n.prof_flops[cat] += 3.0 * 2.0 * (double)u.M(B) * u.Co * u.R * u.S_src * u.Ci_src;   // algorithmic, 3 modalities
+    n.ev_flops.push_back(3.0 * 2.0 * (double)u.M(B) * u.Co * u.R_src * u.S_src * u.Ci_src);
+    n.prof_flops[cat] += 3.0 * 2.0 * (double)u.M(B) * u.Co * u.R_src * u.S_src * u.Ci_src;   // algorithmic, 3 modalities
     n.prof_launches[cat] += 1;
   }
   void prof_end() {
@@ -436,11 +442,11 @@ struct Run {
   int wgrad_on(const ConvUnit& u, const void* dy, const void* x) {
     prof_begin(1, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
-    if (u.Ci != u.Ci_src || u.S != u.S_src) {   // padded stem: gradient of the padded operand, then drop the padding
+    if (u.Ci != u.Ci_src || u.S != u.S_src || u.R != u.R_src) {   // padded stem: gradient of the padded operand, then drop the padding
       const int64_t npad = (int64_t)u.Co * u.Ci * u.R * u.S;
       IEEE_TRY(ieee_conv2d_wgrad(dy, x, F(u.dwpad), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride,
                                  u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, npad, 0, st));
-      return ieee_unpad_weight_grad(F(u.dwpad), grd(u.s_w), 3, u.Co, u.Ci, u.R, u.S, u.Ci_src, u.S_src, npad, gs(u.s_w), 0,
+      return ieee_unpad_weight_grad(F(u.dwpad), grd(u.s_w), 3, u.Co, u.Ci, u.R, u.S, u.Ci_src, u.R_src, u.S_src, npad, gs(u.s_w), 0,
                                     st);
     }
     return ieee_conv2d_wgrad(dy, x, grd(u.s_w), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride,
@@ -517,7 +523,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
     else
       IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev, (int64_t)N.pack_eval.size(), N.pack_blocks_eval, dt, st));
   }
-  IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, 8, st));
+  IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, 4, 3, st));
   // stem: conv7x7/2 -> BN -> ReLU -> maxpool3x3/2   (resnet.py:622-626)
   const ConvUnit& s = N.units[N.u_stem];
   IEEE_TRY(conv(s, P(N.x0), training != 0));
@@ -899,7 +905,7 @@ extern "C" int ieee_net_bind(void* handle, float* params, float* grads, float* b
         d.dst_off = (int64_t)((mode == 0 ? u.wf.off : u.wd.off) / es);
         d.dst_gs = rows * ld;
         d.Co = u.Co; d.Ci = u.Ci; d.R = u.R; d.S = u.S; d.ld = (int)ld; d.mode = mode;
-        d.Ci_src = u.Ci_src; d.S_src = u.S_src;
+        d.Ci_src = u.Ci_src; d.S_src = u.S_src; d.R_src = u.R_src; d.reserved_ = 0;
         d.block_begin = blocks;
         // 1x1 dgrad operands go through the 64x64 LDS-tiled transpose of pack_all_kernel (pad_ = 1)
         const bool tiled = mode == 1 && u.R == 1 && u.S == 1 && u.Co % 64 == 0 && u.Ci % 64 == 0 && ld == u.Co &&

@@ -88,14 +88,14 @@ int64_t ieee_conv_packed_ld(int dtype, int64_t inner_channels, int64_t R, int64_
 int ieee_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int mode, int64_t groups, int64_t Co,
                           int64_t Ci, int64_t R, int64_t S, int64_t w_gs, int64_t dst_gs, void* stream);
 
-/* same, zero-padding the input-channel and kernel-width axes to (Ci, S) >= (Ci_src, S_src); and its inverse
- * for the weight gradient (dw_padded [Co][Ci][R][S] -> dw [Co][Ci_src][R][S_src]) */
+/* same, zero-padding the input-channel, kernel-height and kernel-width axes to (Ci, R, S) >= (Ci_src, R_src, S_src);
+ * and its inverse for the weight gradient (dw_padded [Co][Ci][R][S] -> dw [Co][Ci_src][R_src][S_src]) */
 int ieee_pack_conv_weight_padded(const float* w_oihw, void* dst, int dtype, int mode, int64_t groups, int64_t Co,
-                                 int64_t Ci_src, int64_t R, int64_t S_src, int64_t Ci, int64_t S, int64_t w_gs,
-                                 int64_t dst_gs, void* stream);
+                                 int64_t Ci_src, int64_t R_src, int64_t S_src, int64_t Ci, int64_t R, int64_t S,
+                                 int64_t w_gs, int64_t dst_gs, void* stream);
 int ieee_unpad_weight_grad(const float* dw_padded, float* dw, int64_t groups, int64_t Co, int64_t Ci, int64_t R,
-                           int64_t S, int64_t Ci_src, int64_t S_src, int64_t dwp_gs, int64_t dw_gs, int accumulate,
-                           void* stream);
+                           int64_t S, int64_t Ci_src, int64_t R_src, int64_t S_src, int64_t dwp_gs, int64_t dw_gs,
+                           int accumulate, void* stream);
 
 /* every conv weight of the network in ONE launch: `descs` is a device array of packing descriptors built by
  * the executor (ieee_pack_desc_bytes() each); offsets are elements relative to `params` / `ws_base` */
@@ -158,11 +158,13 @@ int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void* y, void* d
                   float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks, void* stream);
 
 /* ---- stem plumbing ----------------------------------------------------------- */
-/* three fp32 NCHW image tensors (batch dict 'img' = [RGB, NI, TI], dataset.py:338-351) -> [3][B][H][W][Cpad]
- * (channels C..Cpad-1 zero: the stem runs as a 7x8 conv over 8 channels so that one k-tile is 8 contiguous
- * pixels of one input row) */
+/* three fp32 NCHW image tensors (batch dict 'img' = [RGB, NI, TI], dataset.py:338-351) ->
+ * [3][B][H+2*pad][W+2*pad][Cpad], channels C..Cpad-1 and the `pad`-pixel border zero.  The executor's stem uses
+ * Cpad = 4, pad = 3: conv1 (7x7/2, pad 3; resnet.py:622) then is an 8x8/2 convolution WITHOUT padding over 4
+ * channels (8th filter row / column and 4th channel zero), whose k-tile of 64 is two filter rows of 8 contiguous
+ * pixels and needs no bounds tests */
 int ieee_nchw_to_nhwc3(const float* x_rgb, const float* x_ni, const float* x_ti, void* out, int dtype,
-                       int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cpad, void* stream);
+                       int64_t B, int64_t C, int64_t H, int64_t W, int64_t Cpad, int64_t pad, void* stream);
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:501); argmax holds the window-local index of the first maximum */
 int ieee_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int dtype, int64_t groups, int64_t B,
                           int64_t Hi, int64_t Wi, int64_t C, void* stream);

@@ -84,10 +84,12 @@ def test_conv_exact_integer_data_fp32():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_padded_stem_equals_7x7_conv(dtype):
-    """the stem runs as a 7x8 conv over 8 zero-padded channels (one k-tile = 8 contiguous pixels of a row)"""
-    import ctypes
-    from ieee_amd import _lib as L, _ops
+@pytest.mark.parametrize("form", ["c8_7x8_pad3", "c4_8x8_prepadded"])
+def test_padded_stem_equals_7x7_conv(dtype, form):
+    """the stem as a zero-padded vector-path conv: (a) 7x8 over 8 channels with padding 3 (one k-tile = 8 contiguous
+    pixels of a row); (b) what the executor uses: 8x8 over 4 channels WITHOUT padding on an image that
+    ieee_nchw_to_nhwc3 wrote with a 3-pixel zero border (a 16-byte chunk = 2 adjacent pixels, a k-tile = 2 filter rows)"""
+    from ieee_amd import _lib as L
     lib = L.require_gpu()
     g = torch.Generator().manual_seed(7)
     rt = (lambda t: t.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else (lambda t: t)
@@ -98,27 +100,37 @@ def test_padded_stem_equals_7x7_conv(dtype):
     refs = [_ref(x[i], w[i], dy[i], 2, 3) for i in range(G)]
     dt = L.IEEE_BF16 if dtype == torch.bfloat16 else L.IEEE_F32
     xs = [x[i].contiguous().cuda() for i in range(G)]
-    x8 = torch.empty(G, N, H, W, 8, device="cuda", dtype=dtype)
-    L.check(lib.ieee_nchw_to_nhwc3(L.ptr(xs[0]), L.ptr(xs[1]), L.ptr(xs[2]), L.ptr(x8), dt, N, 3, H, W, 8, L.stream()))
-    assert float(x8[..., 3:].abs().max()) == 0.0
-    ld = lib.ieee_conv_packed_ld(dt, 8, 7, 8)
+    if form == "c8_7x8_pad3":
+        Cp, Rp, Sp, ipad, cpad = 8, 7, 8, 0, 3
+    else:
+        Cp, Rp, Sp, ipad, cpad = 4, 8, 8, 3, 0
+    Hp, Wp = H + 2 * ipad, W + 2 * ipad
+    xp = torch.full((G, N, Hp, Wp, Cp), 7.0, device="cuda", dtype=dtype)
+    L.check(lib.ieee_nchw_to_nhwc3(L.ptr(xs[0]), L.ptr(xs[1]), L.ptr(xs[2]), L.ptr(xp), dt, N, 3, H, W, Cp, ipad, L.stream()))
+    assert float(xp[..., 3:].abs().max()) == 0.0
+    if ipad:
+        assert float(xp[:, :, :ipad].abs().max()) == 0.0 and float(xp[:, :, :, -ipad:].abs().max()) == 0.0
+        torch.testing.assert_close(xp[:, :, ipad:-ipad, ipad:-ipad, :3].float().cpu(), x.permute(0, 1, 3, 4, 2))
+    ld = lib.ieee_conv_packed_ld(dt, Cp, Rp, Sp)
     wp = torch.empty(G, Co, ld, device="cuda", dtype=dtype)
     wd = w.cuda().contiguous()
-    L.check(lib.ieee_pack_conv_weight_padded(L.ptr(wd), L.ptr(wp), dt, 0, G, Co, 3, 7, 7, 8, 8, Co * 3 * 49, Co * ld, L.stream()))
+    L.check(lib.ieee_pack_conv_weight_padded(L.ptr(wd), L.ptr(wp), dt, 0, G, Co, 3, 7, 7, Cp, Rp, Sp, Co * 3 * 49, Co * ld,
+                                             L.stream()))
     y = torch.empty(G, N, H // 2, W // 2, Co, device="cuda", dtype=dtype)
-    L.check(lib.ieee_conv2d_fwd(L.ptr(x8), L.ptr(wp), L.ptr(y), dt, G, N, H, W, 8, Co, 7, 8, 2, 3, N * H * W * 8, Co * ld,
-                                y[0].numel(), None, L.stream()))
+    L.check(lib.ieee_conv2d_fwd(L.ptr(xp), L.ptr(wp), L.ptr(y), dt, G, N, Hp, Wp, Cp, Co, Rp, Sp, 2, cpad, xp[0].numel(),
+                                Co * ld, y[0].numel(), None, L.stream()))
     tol = dict(rtol=2e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
     for i in range(G):
         torch.testing.assert_close(y[i].float().cpu().permute(0, 3, 1, 2), refs[i][0], **tol)
     dyd = dy.permute(0, 1, 3, 4, 2).contiguous().cuda().to(dtype)
-    nbytes = lib.ieee_conv2d_wgrad_workspace_bytes(dt, G, N, H // 2, W // 2, 8, Co, 7, 8)
+    nbytes = lib.ieee_conv2d_wgrad_workspace_bytes(dt, G, N, H // 2, W // 2, Cp, Co, Rp, Sp)
     work = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    dwp = torch.zeros(G, Co, 8, 7, 8, device="cuda")
-    L.check(lib.ieee_conv2d_wgrad(L.ptr(dyd), L.ptr(x8), L.ptr(dwp), L.ptr(work), dt, G, N, H, W, 8, Co, 7, 8, 2, 3,
-                                  dyd[0].numel(), x8[0].numel(), dwp[0].numel(), 0, L.stream()))
+    dwp = torch.zeros(G, Co, Cp, Rp, Sp, device="cuda")
+    L.check(lib.ieee_conv2d_wgrad(L.ptr(dyd), L.ptr(xp), L.ptr(dwp), L.ptr(work), dt, G, N, Hp, Wp, Cp, Co, Rp, Sp, 2, cpad,
+                                  dyd[0].numel(), xp[0].numel(), dwp[0].numel(), 0, L.stream()))
     dw = torch.zeros(G, Co, 3, 7, 7, device="cuda")
-    L.check(lib.ieee_unpad_weight_grad(L.ptr(dwp), L.ptr(dw), G, Co, 8, 7, 8, 3, 7, dwp[0].numel(), dw[0].numel(), 0, L.stream()))
+    L.check(lib.ieee_unpad_weight_grad(L.ptr(dwp), L.ptr(dw), G, Co, Cp, Rp, Sp, 3, 7, 7, dwp[0].numel(), dw[0].numel(), 0,
+                                       L.stream()))
     wtol = dict(rtol=2e-2, atol=0.5) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-3)
     for i in range(G):
         torch.testing.assert_close(dw[i].cpu(), refs[i][2], **wtol)
