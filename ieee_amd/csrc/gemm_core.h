@@ -562,14 +562,21 @@ template <typename T, int NCH> struct LoaderIm2colNT {
         const int hb = pp * g.mul + g.off + g.sgn * dr, wb = qq * g.mul + g.off + g.sgn * ds;
         const int he = g.div == 2 ? (hb >> 1) : hb, we = g.div == 2 ? (wb >> 1) : wb;
         off[i] = ((n * g.Hs + he) * g.Ws + we) * g.Cs + coff;
-        for (int rr = 0; rr < g.R; ++rr)
-          for (int ss = 0; ss < g.S; ++ss) {
-            int h = hb + g.sgn * rr, w = wb + g.sgn * ss;
-            bool ok = true;
-            if (g.div == 2) { ok = !((h | w) & 1); h >>= 1; w >>= 1; }
-            ok = ok && (unsigned)h < (unsigned)g.Hs && (unsigned)w < (unsigned)g.Ws;
-            if (ok) vm[i] |= 1ull << (rr * g.S + ss);
-          }
+        // the valid taps are (row condition) x (column condition): R + S tests instead of R*S (the 8x8 stem would
+        // otherwise spend more time here than in its four k-tiles)
+        unsigned long long rowpat = 0ull;
+        for (int ss = 0; ss < g.S; ++ss) {
+          int w = wb + g.sgn * ss;
+          bool ok = true;
+          if (g.div == 2) { ok = !(w & 1); w >>= 1; }
+          if (ok && (unsigned)w < (unsigned)g.Ws) rowpat |= 1ull << ss;
+        }
+        for (int rr = 0; rr < g.R; ++rr) {
+          int h = hb + g.sgn * rr;
+          bool ok = true;
+          if (g.div == 2) { ok = !(h & 1); h >>= 1; }
+          if (ok && (unsigned)h < (unsigned)g.Hs) vm[i] |= rowpat << (rr * g.S);
+        }
       }
     }
     r = 0; s = 0; ci0 = 0; tap = 0; toff = 0;
