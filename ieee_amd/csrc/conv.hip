@@ -223,9 +223,17 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : 1))) void co
     const int ch = nt_dma_chunk(threadIdx.x);
     LoaderPlainNT<T, BN / 32> lbd;
     lbd.init(w, a.ldw, n0, a.N, a.ldw, ch);
-    LoaderIm2colNT<T, 4> la;
-    la.init(src, a.g, m0, ch);
-    gemm_nt_dma<128, BN, PIPE>(la, lbd, epi, a.ktiles, m0, n0, smem);
+    if (a.g.R == 1 && a.g.S == 1 && a.g.mul == 1 && a.g.off == 0 && a.g.div == 1) {
+      // 1x1 / stride 1 / no padding (two thirds of the launches): im2col(X) is X itself, a plain [pixels][C] matrix --
+      // no pixel decode, no tap masks (their set-up rivals the whole k-loop of the K = 64..256 layers)
+      LoaderPlainNT<T, 4> la;
+      la.init(src, a.g.Cs, m0, a.g.npix, a.g.Cs, ch);
+      gemm_nt_dma<128, BN, PIPE>(la, lbd, epi, a.ktiles, m0, n0, smem);
+    } else {
+      LoaderIm2colNT<T, 4> la;
+      la.init(src, a.g, m0, ch);
+      gemm_nt_dma<128, BN, PIPE>(la, lbd, epi, a.ktiles, m0, n0, smem);
+    }
     return;
   } else {
   LoaderPlainNT<T, BN / 32> lb;
