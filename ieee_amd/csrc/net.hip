@@ -68,7 +68,7 @@ struct Net {
   // workspace
   size_t ws_bytes = 0;
   std::map<std::string, Tensor> tensors;
-  Tensor x0, pool, pool_arg, S, gbuf[5], slab, bnpart, bncoef, packtab, gemm_work;
+  Tensor x0, pool, pool_arg, S, gbuf[10], slab, bnpart, bncoef, packtab, gemm_work;
   std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
   int pack_blocks_train = 0, pack_blocks_eval = 0;
   // training: the layer3 / layer4 / CIM operands (90 % of the bytes) are packed on the side stream while the
@@ -84,9 +84,9 @@ struct Net {
   // that reads gradient buffer b (the caller's stream waits on it before it overwrites b).
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> side_ready;
-  hipEvent_t gbuf_read[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t gbuf_read[10] = {};
   hipEvent_t side_done = nullptr;
-  bool gbuf_pending[5] = {false, false, false, false, false};
+  bool gbuf_pending[10] = {};
   bool side_dirty = false;
   size_t side_used = 0;
   ~Net() {
@@ -258,7 +258,9 @@ void Net::plan() {
   const ConvUnit& uo = units[u_one];
   const int64_t P = (int64_t)uo.Hi * uo.Wi;
   S = alloc("S", (int64_t)3 * B * P * fdim, dt);
-  for (int i = 0; i < 5; ++i) gbuf[i] = alloc("g" + std::to_string(i), max_act, dt);
+  // two sets of five activation-sized gradient buffers: consecutive bottleneck blocks alternate between them, so a
+  // buffer is rewritten two blocks after the side-stream wgrad that reads it was issued (one set stalled the chain)
+  for (int i = 0; i < 10; ++i) gbuf[i] = alloc("g" + std::to_string(i), max_act, dt);
   slab = alloc("", max_slab / 4 + 64, IEEE_F32);
   max_part = std::max(max_part, (int64_t)12 * B * fdim);   // two [3][2][C][B] sets from ieee_cim_tail_bwd_g
   bnpart = alloc("", max_part + 64, IEEE_F32);
@@ -382,7 +384,7 @@ struct Run {
   }
   // --- second stream for the weight gradients (see Net::side)
   int gbuf_index(const void* p) const {
-    for (int i = 0; i < 5; ++i) if (p == (const void*)(ws + n.gbuf[i].off)) return i;
+    for (int i = 0; i < 10; ++i) if (p == (const void*)(ws + n.gbuf[i].off)) return i;
     return -1;
   }
   bool side_enabled() {
@@ -393,7 +395,7 @@ struct Run {
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
       const int prio = getenv("IEEE_SIDE_PRIO") ? atoi(getenv("IEEE_SIDE_PRIO")) : least;
       if (hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, prio) != hipSuccess) { n.side = nullptr; return false; }
-      for (int i = 0; i < 5; ++i) (void)hipEventCreateWithFlags(&n.gbuf_read[i], hipEventDisableTiming);
+      for (int i = 0; i < 10; ++i) (void)hipEventCreateWithFlags(&n.gbuf_read[i], hipEventDisableTiming);
       (void)hipEventCreateWithFlags(&n.side_done, hipEventDisableTiming);
       for (int i = 0; i < 2; ++i) (void)hipEventCreateWithFlags(&n.pack_ev[i], hipEventDisableTiming);
     }
@@ -413,7 +415,7 @@ struct Run {
     (void)hipStreamWaitEvent((hipStream_t)st, n.side_done, 0);
     n.side_dirty = false;
     n.side_used = 0;
-    for (int b = 0; b < 5; ++b) n.gbuf_pending[b] = false;
+    for (int b = 0; b < 10; ++b) n.gbuf_pending[b] = false;
   }
   int wgrad(const ConvUnit& u, const void* dy, const void* x) {
     if (side_enabled()) {
@@ -509,7 +511,8 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
                               hipMemcpyHostToDevice, (hipStream_t)st));
       N.pack_uploaded_ws = ws;
     }
-    if (training && side_enabled() && !N.pack_late.empty()) {
+    static const bool pack_async = !(getenv("IEEE_PACK_ASYNC") && atoi(getenv("IEEE_PACK_ASYNC")) == 0);
+    if (training && pack_async && side_enabled() && !N.pack_late.empty()) {
       IEEE_HIP(hipEventRecord(N.pack_ev[0], (hipStream_t)st));   // parameters (and the tables) are final here
       IEEE_HIP(hipStreamWaitEvent(N.side, N.pack_ev[0], 0));
       IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev + bytes_eval + bytes_train, (int64_t)N.pack_late.size(),
@@ -660,10 +663,14 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
   int hi = (int)N.blocks.size() - 1, lo = 0;
   if (part > 0) { hi = first_block[5 - part] - 1; lo = first_block[4 - part]; }
   // trunk backward (Bottleneck blocks in reverse); X holds d(out) of the current block
-  void* X = P(N.gbuf[0]);
-  void *Q = P(N.gbuf[1]), *Rb = P(N.gbuf[2]), *U = P(N.gbuf[3]), *V = P(N.gbuf[4]);
+  // block bi reads d(out) from xbuf(bi) and leaves d(in) in xbuf(bi - 1); its scratch buffers come from set(bi)
+  auto set_of = [](int bi) { return (bi & 1) ? 0 : 5; };
+  void *X = nullptr, *Q = nullptr, *Rb = nullptr, *U = nullptr, *V = nullptr, *Xout = nullptr;
   for (int bi = hi; bi >= lo; --bi) {
     const Block& b = N.blocks[bi];
+    const int sb = set_of(bi);
+    X = P(N.gbuf[sb]); Q = P(N.gbuf[sb + 1]); Rb = P(N.gbuf[sb + 2]); U = P(N.gbuf[sb + 3]); V = P(N.gbuf[sb + 4]);
+    Xout = P(N.gbuf[set_of(bi - 1)]);
     const ConvUnit &c1 = N.units[b.c1], &c2 = N.units[b.c2], &c3 = N.units[b.c3];
     const void* xin = bi == 0 ? P(N.pool) : P(N.units[N.blocks[bi - 1].c3].a);
     // out = relu(bn3(y3) + identity): g = dout*[out>0] -> Q ; dy3 -> X (in place)
@@ -686,9 +693,11 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     // d(block input) = dgrad(conv1) + identity-branch gradient; it is d(out) of the previous block, whose bn3
     // backward sums (mask = that block's stored output) are emitted here too
     const ConvUnit* pc3 = bi > 0 ? &N.units[N.blocks[bi - 1].c3] : nullptr;
-    IEEE_TRY(dgrad(c1, U, X, addend, pc3, true));
+    IEEE_TRY(dgrad(c1, U, Xout, addend, pc3, true));
   }
   if (lo > 0) return IEEE_OK;
+  X = P(N.gbuf[set_of(-1)]);      // d(out) of the stem's max-pool, left by block 0
+  Q = P(N.gbuf[set_of(-1) + 1]);
   // stem: maxpool -> ReLU/BN -> conv wgrad (no dgrad: the input is the image)
   const ConvUnit& s = N.units[N.u_stem];
   will_write(Q);
