@@ -336,9 +336,14 @@ class _FusedStepMixin(object):
         self.optimizer.step()
         return small, out3
 
-    @staticmethod
-    def _summary_from(small):
-        v = small.cpu().numpy()                      # the step's single device->host read-back
+    def _summary_from(self, small):
+        # the step's single device->host read-back, into a pinned buffer (a pageable .cpu() adds ~50 us of staging)
+        host = getattr(self, "_small_host", None)
+        if host is None or host.numel() != small.numel():
+            host = self._small_host = torch.empty(small.numel(), dtype=small.dtype, pin_memory=True)
+        host.copy_(small, non_blocking=True)
+        torch.cuda.current_stream(small.device).synchronize()
+        v = host.numpy().copy()
         hl, ha = v[:18], v[18:36]
         lR, lN, lT = float(hl[0:6].sum()), float(hl[6:12].sum()), float(hl[12:18].sum())
         aR, aN, aT = float(ha[0:6].mean()), float(ha[6:12].mean()), float(ha[12:18].mean())
