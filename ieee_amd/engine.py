@@ -198,7 +198,7 @@ class Engine(object):
             rank1, mAP = self._evaluate(dataset_name=name, query_loader=self.test_loader[name]['query'],
                                         gallery_loader=self.test_loader[name]['gallery'], dist_metric=dist_metric,
                                         normalize_feature=normalize_feature, use_metric_cuhk03=use_metric_cuhk03,
-                                        ranks=ranks)
+                                        ranks=ranks, rerank=rerank)
         return mAP
 
     @torch.no_grad()
@@ -233,7 +233,17 @@ class Engine(object):
             qf = F.normalize(qf, p=2, dim=1)
             gf = F.normalize(gf, p=2, dim=1)
         print('Computing distance matrix with metric={} ...'.format(dist_metric))
-        if ddp.world_size() > 1 and not use_metric_cuhk03:
+        if rerank:
+            # reference engine.py:402-406: re-rank with the query-query and gallery-gallery matrices, then evaluate
+            print('Applying person re-ranking ...')
+            from .rerank import re_ranking
+            distmat = compute_distance_matrix(qf, gf, dist_metric)
+            distmat_qq = compute_distance_matrix(qf, qf, dist_metric)
+            distmat_gg = compute_distance_matrix(gf, gf, dist_metric)
+            distmat = re_ranking(distmat, distmat_qq, distmat_gg)
+            print('Computing CMC and mAP for {}'.format(dataset_name))
+            cmc, mAP = evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, use_metric_cuhk03=use_metric_cuhk03)
+        elif ddp.world_size() > 1 and not use_metric_cuhk03:
             # every rank holds the full feature sets; each ranks its slice of the queries (ieee_amd/dist.py)
             print('Computing CMC and mAP for {} (queries sharded over {} ranks)'.format(dataset_name, ddp.world_size()))
             cmc, mAP = ddp.sharded_evaluate_rank(qf, gf, q_pids, g_pids, q_camids, g_camids, metric=dist_metric)

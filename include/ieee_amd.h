@@ -266,6 +266,15 @@ int ieee_adam_step(float* params, const float* grads, float* exp_avg, float* exp
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                    void* stream);
 
+/* ---- re-ranking ----------------------------------------------- */
+/* k-reciprocal re-ranking, torchreid/utils/rerank.py:31-113 (engine/engine.py:402-406): device matrices
+ * q_g_dist [Q][G], q_q_dist [Q][Q], g_g_dist [G][G] fp32 -> out [Q][G] fp32.  Dense like the reference (three
+ * (Q+G)^2 fp32 work matrices: Q+G < 46000); rank ties are broken by index.  k1+1 <= 64. */
+int64_t ieee_rerank_workspace_bytes(int64_t Q, int64_t G, int64_t k1);
+int ieee_rerank(const float* q_g_dist, const float* q_q_dist, const float* g_g_dist, int64_t Q, int64_t G,
+                int64_t k1, int64_t k2, double lambda_value, float* out, void* work, int64_t work_bytes,
+                void* stream);
+
 /* ---- input pipeline ------------------------------------------ */
 /* The reference's per-image chain Resize((Ho,Wo)) -> RandomHorizontalFlip -> ToTensor -> Normalize
  * (torchreid/data/transforms.py:233-326; dataset.py:335-351) for N decoded uint8 images of ONE source size:
