@@ -66,6 +66,21 @@ class NativeNet:
         _lib.check(self.lib.ieee_net_backward_part(self.handle, _lib.ptr(self.workspace), _lib.ptr(dlogits),
                                                    _lib.ptr(dfeats), part, _lib.stream()))
 
+    def backward_part_async(self, dlogits, dfeats, part):
+        """like backward_part, but the launch stream is not made to wait for the part's weight gradients (they run on
+        the executor's side stream); pair with side_wait()"""
+        _lib.check(self.lib.ieee_net_backward_part_async(self.handle, _lib.ptr(self.workspace), _lib.ptr(dlogits),
+                                                         _lib.ptr(dfeats), part, _lib.stream()))
+
+    def side_wait(self, stream=None):
+        """stream=None: final join on the current (launch) stream; else make that torch stream wait for every weight
+        gradient issued so far without blocking the launch stream"""
+        if stream is None:
+            _lib.check(self.lib.ieee_net_side_wait(self.handle, _lib.ptr(self.workspace), _lib.stream(), 1))
+        else:
+            _lib.check(self.lib.ieee_net_side_wait(self.handle, _lib.ptr(self.workspace),
+                                                   ctypes.c_void_p(stream.cuda_stream), 0))
+
     def tensor(self, name):
         """a named intermediate as a torch view of the workspace (parity tests / debugging)"""
         off, numel, dt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()

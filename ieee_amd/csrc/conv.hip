@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : 1))) void co
       // no pixel decode, no tap masks (their set-up rivals the whole k-loop of the K = 64..256 layers)
       LoaderPlainNT<T, 4> la;
       la.init(src, a.g.Cs, m0, a.g.npix, a.g.Cs, ch);
-      gemm_nt_dma<128, BN, PIPE>(la, lbd, epi, a.ktiles, m0, n0, smem);
+      gemm_nt_dma<128, BN, PIPE>(la, lbd, epi, a.ktiles, m0, n0, smem, a.dbg);
     } else {
       LoaderIm2colNT<T, 4> la;
       la.init(src, a.g, m0, ch);

@@ -488,10 +488,16 @@ struct Run {
     return rc;
   }
   int forward_impl(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out);
-  int backward(const float* dlogits, const float* dfeats, int part = -1) {
+  int backward(const float* dlogits, const float* dfeats, int part = -1, bool join = true) {
     const int rc = backward_impl(dlogits, dfeats, part);
-    side_join();   // also after an error: no side-stream work may outlive the call
+    if (join || rc != IEEE_OK) side_join();   // also after an error: no side-stream work may outlive the call
     return rc;
+  }
+  // make `other` wait for every weight-gradient kernel issued so far (the caller's stream is NOT blocked)
+  void side_wait_on(void* other) {
+    if (!n.side_dirty || n.side == nullptr) return;
+    (void)hipEventRecord(n.side_done, n.side);
+    (void)hipStreamWaitEvent((hipStream_t)other, n.side_done, 0);
   }
   int backward_impl(const float* dlogits, const float* dfeats, int part);
   int backward_head(const float* dlogits, const float* dfeats);
@@ -982,6 +988,25 @@ extern "C" int ieee_net_backward_part(void* handle, void* workspace, const float
   IEEE_REQUIRE(part > 0 || (dlogits && dfeats), "net_backward_part: part 0 needs the loss gradients");
   Run r(*n, workspace, stream);
   return r.backward(dlogits, dfeats, part);
+}
+
+extern "C" int ieee_net_backward_part_async(void* handle, void* workspace, const float* dlogits, const float* dfeats,
+                                            int part, void* stream) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && n->bound && n->grads, "net_backward_part_async: network not bound (or no gradient buffer)");
+  IEEE_REQUIRE(workspace && part >= 0 && part <= 4, "net_backward_part_async: bad arguments");
+  IEEE_REQUIRE(part > 0 || (dlogits && dfeats), "net_backward_part_async: part 0 needs the loss gradients");
+  Run r(*n, workspace, stream);
+  return r.backward(dlogits, dfeats, part, false);
+}
+
+extern "C" int ieee_net_side_wait(void* handle, void* workspace, void* waiting_stream, int is_launch_stream) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && workspace && (waiting_stream || is_launch_stream), "net_side_wait: bad arguments");
+  Run r(*n, workspace, waiting_stream);
+  if (is_launch_stream) r.side_join();
+  else r.side_wait_on(waiting_stream);
+  return IEEE_OK;
 }
 
 extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {

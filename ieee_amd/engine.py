@@ -328,21 +328,34 @@ class _FusedStepMixin(object):
         else:
             df.zero_()
             out3.zero_()
-        if ddp.world_size() == 1:
+        staged = ddp.world_size() > 1 or (os.environ.get("IEEE_FORCE_DP_PATH") == "1" and torch.distributed.is_initialized())
+        if not staged:
             net.backward(dl, df)
         else:
             # data parallel: the backward runs in 5 parts; as soon as a part is done its (final) slice of the flat
             # gradient is all-reduced (sum) asynchronously over RCCL/xGMI while the next part computes.  Together
             # the slices are exactly one pass over the 438 MB buffer; torch orders each collective after the
             # kernels already enqueued on the compute stream, and wait() orders the SGD step after them.
+            # The compute stream is never blocked between parts: a helper stream waits for the part's kernels on the
+            # compute stream AND for its weight gradients on the executor's side stream, and the collective is issued
+            # from there.
             handles = []
+            main = torch.cuda.current_stream()
+            if not hasattr(self, "_comm_stream"):
+                self._comm_stream = torch.cuda.Stream()
+            comm = self._comm_stream
             for part, ranges in enumerate(m.grad_part_ranges()):
-                net.backward_part(dl, df, part)
-                for a, b in ranges:
-                    handles.append(torch.distributed.all_reduce(m._flat_grads[a:b], op=torch.distributed.ReduceOp.SUM,
-                                                                async_op=True))
+                net.backward_part_async(dl, df, part)
+                comm.wait_stream(main)
+                net.side_wait(comm)
+                with torch.cuda.stream(comm):
+                    for a, b in ranges:
+                        handles.append(torch.distributed.all_reduce(m._flat_grads[a:b], op=torch.distributed.ReduceOp.SUM,
+                                                                    async_op=True))
+            net.side_wait()                      # final join of the weight-gradient stream into the compute stream
             for h in handles:
                 h.wait()
+            main.wait_stream(comm)
         self.optimizer.step()
         return small, out3
 

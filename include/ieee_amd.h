@@ -318,6 +318,14 @@ int ieee_net_backward(void* handle, void* workspace, const float* dlogits, const
  * their all-reduce with the remaining parts (ieee_amd/engine.py) */
 int ieee_net_backward_part(void* handle, void* workspace, const float* dlogits, const float* dfeats, int part,
                            void* stream);
+/* Same, without blocking the launch stream at the end of the part: the part's weight gradients may still be running
+ * on the executor's side stream when the call returns.  ieee_net_side_wait(waiting_stream, 0) makes ANOTHER stream
+ * (e.g. the one a collective is issued from) wait for every weight gradient issued so far;
+ * ieee_net_side_wait(launch_stream, 1) is the final join that must precede the optimizer step (it also retires
+ * the executor's buffer-reuse bookkeeping, so pass the stream the parts were launched on). */
+int ieee_net_backward_part_async(void* handle, void* workspace, const float* dlogits, const float* dfeats, int part,
+                                 void* stream);
+int ieee_net_side_wait(void* handle, void* workspace, void* waiting_stream, int is_launch_stream);
 /* measurement: enable=1 starts recording a HIP event pair (on the launch stream) around every conv
  * launch of subsequent forward/backward calls; enable=0 stops, synchronises the device and returns
  * out6 = {ms, algorithmic FLOPs, launches} for [0] forward+dgrad (conv_gather_kernel) and
