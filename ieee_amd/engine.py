@@ -329,6 +329,26 @@ class _FusedStepMixin(object):
             df.zero_()
             out3.zero_()
         staged = ddp.world_size() > 1 or (os.environ.get("IEEE_FORCE_DP_PATH") == "1" and torch.distributed.is_initialized())
+        if not staged and isinstance(self.optimizer, FusedSGD) and os.environ.get("IEEE_OPT_OVERLAP", "1") != "0":
+            # single GPU: parts 0-3 (head, layer4, layer3, layer2 = 90 % of the parameters) are updated on a helper
+            # stream while the compute stream still runs the backward of layer1 + stem and the side stream drains the
+            # last weight gradients; only layer1 + stem wait for the final join.  Same arithmetic as optimizer.step().
+            main = torch.cuda.current_stream()
+            if not hasattr(self, "_opt_stream"):
+                self._opt_stream = torch.cuda.Stream()
+            helper = self._opt_stream
+            for part in range(4):
+                net.backward_part_async(dl, df, part)
+            helper.wait_stream(main)
+            net.side_wait(helper)
+            net.backward_part_async(dl, df, 4)
+            with torch.cuda.stream(helper):
+                for part in range(4):
+                    self.optimizer.step_part(part)
+            net.side_wait()
+            self.optimizer.step_part(4)
+            main.wait_stream(helper)
+            return small, out3
         if not staged:
             net.backward(dl, df)
         else:

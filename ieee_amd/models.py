@@ -208,6 +208,24 @@ class IEEE3modalPart(nn.Module):
             runs.append((start, pos))
         return runs
 
+    def part_runs(self):
+        """trainable_runs() cut at the boundaries of the 5 staged-backward parts: part_runs()[p] = the element runs an
+        optimizer may update as soon as part p of the backward (and its weight gradients) is done"""
+        key = (self.interaction, self.attention, self.using_REM)
+        if getattr(self, "_part_runs_key", None) != key:
+            runs = self.trainable_runs()
+            out = []
+            for ranges in self.grad_part_ranges():
+                mine = []
+                for a, b in ranges:
+                    for c, d in runs:
+                        lo, hi = max(a, c), min(b, d)
+                        if lo < hi:
+                            mine.append((lo, hi))
+                out.append(mine)
+            self._part_runs, self._part_runs_key = out, key
+        return self._part_runs
+
     def grad_part_ranges(self):
         """[start, end) element ranges of the flat gradient buffer that are final after each of the 5 staged
         backward parts (0: head + CIM, 1: layer4, 2: layer3, 3: layer2, 4: layer1 + stem; three ranges per

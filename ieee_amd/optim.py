@@ -23,18 +23,27 @@ class FusedSGD(torch.optim.Optimizer):
             self._buf = torch.zeros_like(self.model._flat_params)
         return self._buf
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        """uses the gradients the native backward left in the model's flat gradient buffer"""
+    def _update(self, runs):
         lib = _lib.require_gpu()
         g = self.param_groups[0]
         m = self.model
         buf = self.momentum_buffer()
-        for a, b in m.trainable_runs():
+        for a, b in runs:
             _lib.check(lib.ieee_sgd_nesterov_step(_lib.ptr(m._flat_params[a:b]), _lib.ptr(m._flat_grads[a:b]),
                                                   _lib.ptr(buf[a:b]), b - a, float(g['lr']), float(g['momentum']),
                                                   float(g['weight_decay']), 1 if g['nesterov'] else 0,
                                                   _lib.stream()))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """uses the gradients the native backward left in the model's flat gradient buffer"""
+        self._update(self.model.trainable_runs())
+
+    @torch.no_grad()
+    def step_part(self, part):
+        """the same update restricted to the parameters whose gradients are final after staged-backward part `part`
+        (model.part_runs()); the five parts together are exactly step().  Runs on the current stream."""
+        self._update(self.model.part_runs()[part])
 
     def zero_grad(self, set_to_none=True):
         for p in self.model.parameters():
