@@ -68,7 +68,7 @@ struct Net {
   // workspace
   size_t ws_bytes = 0;
   std::map<std::string, Tensor> tensors;
-  Tensor x0, pool, pool_arg, S, gbuf[10], slab, bnpart, bncoef, packtab, gemm_work;
+  Tensor x0, pool, pool_arg, S, gbuf[10], slab, bnpart, bncoef, bnpart2, bncoef2, packtab, gemm_work;
   std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
   int pack_blocks_train = 0, pack_blocks_eval = 0;
   // training: the layer3 / layer4 / CIM operands (90 % of the bytes) are packed on the side stream while the
@@ -83,6 +83,10 @@ struct Net {
   // the caller's stream when wgrad i's dY operand is final; gbuf_read[b] on the side stream after the last wgrad
   // that reads gradient buffer b (the caller's stream waits on it before it overwrites b).
   hipStream_t side = nullptr;
+  // third stream: the downsample branch of the first block of every stage (conv + BN forward; BN backward + dgrad)
+  // is independent of that block's conv1 -> conv2 (-> conv3) chain and runs beside it with its own BN scratch
+  hipStream_t side2 = nullptr;
+  hipEvent_t branch_ev[16] = {};
   std::vector<hipEvent_t> side_ready;
   hipEvent_t gbuf_read[10] = {};
   hipEvent_t side_done = nullptr;
@@ -96,6 +100,8 @@ struct Net {
     if (side_done) (void)hipEventDestroy(side_done);
     for (hipEvent_t e : pack_ev) if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
+    for (hipEvent_t e : branch_ev) if (e) (void)hipEventDestroy(e);
+    if (side2) (void)hipStreamDestroy(side2);
   }
   Tensor Gp, avgmax, amax, Hh, Hs, att, Pp, Zg, Zp, glob, part, sv_g, sv_p, rr, part2, fcraw, sv_fc, featcat, fcall,
       logits, featn, norms;
@@ -265,6 +271,8 @@ void Net::plan() {
   max_part = std::max(max_part, (int64_t)12 * B * fdim);   // two [3][2][C][B] sets from ieee_cim_tail_bwd_g
   bnpart = alloc("", max_part + 64, IEEE_F32);
   bncoef = alloc("", 3 * 3 * max_c, IEEE_F32);
+  bnpart2 = alloc("", max_part + 64, IEEE_F32);      // BN scratch of the downsample-branch stream
+  bncoef2 = alloc("", 3 * 3 * max_c, IEEE_F32);
   const int64_t Bq = B;
   Gp = alloc("Gp", 3 * Bq * fdim, IEEE_F32);
   avgmax = alloc("avgmax", 3 * 2 * Bq * fdim, IEEE_F32);
@@ -312,7 +320,11 @@ struct Run {
   char* ws;
   void* st;
   int B;
-  Run(Net& net, void* workspace, void* stream) : n(net), ws((char*)workspace), st(stream), B(net.B) {}
+  float *bnpart_cur, *bncoef_cur;      // BN scratch of the stream `st` currently denotes (see BranchScope)
+  Run(Net& net, void* workspace, void* stream) : n(net), ws((char*)workspace), st(stream), B(net.B) {
+    bnpart_cur = (float*)(ws + net.bnpart.off);
+    bncoef_cur = (float*)(ws + net.bncoef.off);
+  }
   void* P(const Tensor& t) const { return ws + t.off; }
   float* F(const Tensor& t) const { return (float*)(ws + t.off); }
   float* par(int slot) const { return n.params + n.slot_off[slot]; }
@@ -361,13 +373,13 @@ struct Run {
     prof_begin(0, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_fwd(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
-                           (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, fused_stats ? F(n.bnpart) : nullptr, st);
+                           (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, fused_stats ? bnpart_cur : nullptr, st);
   }
   int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training) {
     const int64_t rb = (training && fused_stats) ? ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) : 0;
     fused_stats = false;
     return ieee_bn2d_fwd(P(u.y), residual, out, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b),
-                         gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), F(n.bnpart), n.bn_mom, n.bn_eps,
+                         gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), bnpart_cur, n.bn_mom, n.bn_eps,
                          training, relu, rb, st);
   }
   // backward of out = [relu](bn(y) [+res]); dy may alias dout
@@ -375,12 +387,12 @@ struct Run {
   int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0,
              float* partial = nullptr, int64_t partial_rb = 0) {
     const int64_t rb = partial ? partial_rb : (fused_bwd ? (u.M(B) + 127) / 128 : 0);
-    if (!partial) partial = F(n.bnpart);
+    if (!partial) partial = bnpart_cur;
     fused_bwd = false;
     will_write(dy);
     if (gout) will_write(gout);
     return ieee_bn2d_bwd(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
-                         F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, F(n.bncoef), 0, mask_from_y, rb, st);
+                         F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, bncoef_cur, 0, mask_from_y, rb, st);
   }
   // --- second stream for the weight gradients (see Net::side)
   int gbuf_index(const void* p) const {
@@ -417,6 +429,46 @@ struct Run {
     n.side_used = 0;
     for (int b = 0; b < 10; ++b) n.gbuf_pending[b] = false;
   }
+  // --- third stream for the downsample branches (see Net::side2)
+  bool branch_enabled(int phase = 3) {   // phase bit 1: forward, bit 2: backward
+    // measured: forward +0.2 %; backward -2 % (the weight-gradient stream already fills the machine there) -> forward only
+    static const int on = getenv("IEEE_BRANCH_ASYNC") ? atoi(getenv("IEEE_BRANCH_ASYNC")) : 1;
+    if (!(on & phase) || !side_enabled()) return false;
+    if (n.side2 == nullptr) {
+      if (hipStreamCreateWithFlags(&n.side2, hipStreamNonBlocking) != hipSuccess) { n.side2 = nullptr; return false; }
+      for (int i = 0; i < 16; ++i) (void)hipEventCreateWithFlags(&n.branch_ev[i], hipEventDisableTiming);
+    }
+    return true;
+  }
+  // While alive, every wrapper call of this Run launches on the branch stream with the branch's BN scratch; the
+  // fused-statistics flags of the main chain are put back on exit.  fork: the branch starts after everything the
+  // caller's stream has been given so far; join(): the caller's stream waits for the branch.
+  struct BranchScope {
+    Run& r;
+    void* main_st;
+    float *part0, *coef0;
+    bool fs, fb;
+    hipEvent_t done;
+    BranchScope(Run& run, int slot) : r(run), main_st(run.st), part0(run.bnpart_cur), coef0(run.bncoef_cur),
+                                      fs(run.fused_stats), fb(run.fused_bwd), done(run.n.branch_ev[2 * slot + 1]) {
+      (void)hipEventRecord(r.n.branch_ev[2 * slot], (hipStream_t)main_st);
+      (void)hipStreamWaitEvent(r.n.side2, r.n.branch_ev[2 * slot], 0);
+      r.st = (void*)r.n.side2;
+      r.bnpart_cur = (float*)(r.ws + r.n.bnpart2.off);
+      r.bncoef_cur = (float*)(r.ws + r.n.bncoef2.off);
+      r.fused_stats = false;
+      r.fused_bwd = false;
+    }
+    ~BranchScope() {
+      (void)hipEventRecord(done, r.n.side2);
+      r.st = main_st;
+      r.bnpart_cur = part0;
+      r.bncoef_cur = coef0;
+      r.fused_stats = fs;
+      r.fused_bwd = fb;
+    }
+  };
+  void branch_join(int slot) { (void)hipStreamWaitEvent((hipStream_t)st, n.branch_ev[2 * slot + 1], 0); }
   int wgrad(const ConvUnit& u, const void* dy, const void* x) {
     if (side_enabled()) {
       if (n.side_used == n.side_ready.size()) {
@@ -465,7 +517,7 @@ struct Run {
     prof_begin(0, u, "dgrad");
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_dgrad(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
-                             u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, fuse ? F(n.bnpart) : nullptr,
+                             u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, fuse ? bnpart_cur : nullptr,
                              fuse ? P(prev->y) : nullptr, (fuse && prev_mask_tensor) ? P(prev->a) : nullptr,
                              (fuse && !prev_mask_tensor) ? F(prev->stats) : nullptr, st);
   }
@@ -539,6 +591,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
   IEEE_TRY(bn(s, nullptr, P(s.a), 1, training));
   IEEE_TRY(ieee_maxpool3x3s2_fwd(P(s.a), P(N.pool), (uint8_t*)P(N.pool_arg), dt, 3, B, s.Ho, s.Wo, s.Co, st));
   const void* x = P(N.pool);
+  int ds_slot = 0;                    // branch event slots 0..3: forward, 4..7: backward
   for (const Block& b : N.blocks) {   // Bottleneck.forward, resnet.py:164-184
     const ConvUnit &c1 = N.units[b.c1], &c2 = N.units[b.c2], &c3 = N.units[b.c3];
     if (late_pack_pending && b.c1 >= N.pack_late_unit) {   // first layer3 block: its operands come from the side stream
@@ -546,6 +599,13 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
       late_pack_pending = false;
     }
     const bool ws_ = training != 0;
+    const bool par_ds = b.ds >= 0 && training && branch_enabled(1);
+    if (par_ds) {   // downsample branch beside conv1 -> conv2 on its own stream
+      const ConvUnit& d = N.units[b.ds];
+      BranchScope scope(*this, ds_slot);
+      IEEE_TRY(conv(d, x, ws_));
+      IEEE_TRY(bn(d, nullptr, P(d.a), 0, training));
+    }
     IEEE_TRY(conv(c1, x, ws_));
     IEEE_TRY(bn(c1, nullptr, P(c1.a), 1, training));
     IEEE_TRY(conv(c2, P(c1.a), ws_));
@@ -553,9 +613,14 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
     const void* identity = x;
     if (b.ds >= 0) {   // downsample branch first: its conv+BN pair must not sit between conv3 and bn3 (shared scratch)
       const ConvUnit& d = N.units[b.ds];
-      IEEE_TRY(conv(d, x, ws_));
-      IEEE_TRY(bn(d, nullptr, P(d.a), 0, training));
+      if (par_ds) {
+        branch_join(ds_slot);
+      } else {
+        IEEE_TRY(conv(d, x, ws_));
+        IEEE_TRY(bn(d, nullptr, P(d.a), 0, training));
+      }
       identity = P(d.a);
+      ++ds_slot;
     }
     IEEE_TRY(conv(c3, P(c2.a), ws_));
     IEEE_TRY(bn(c3, identity, P(c3.a), 1, training));
@@ -681,6 +746,15 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     const void* xin = bi == 0 ? P(N.pool) : P(N.units[N.blocks[bi - 1].c3].a);
     // out = relu(bn3(y3) + identity): g = dout*[out>0] -> Q ; dy3 -> X (in place)
     IEEE_TRY(bn_bwd(c3, X, P(c3.a), X, Q));
+    const int bslot = 4 + (bi == 0 ? 0 : (bi == 3 ? 1 : (bi == 7 ? 2 : 3)));
+    const bool par_ds = b.ds >= 0 && branch_enabled(2);
+    if (par_ds) {   // the downsample branch's backward beside the conv3 -> conv2 -> conv1 chain
+      const ConvUnit& d = N.units[b.ds];
+      BranchScope scope(*this, bslot);
+      IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
+      IEEE_TRY(wgrad(d, Q, xin));
+      IEEE_TRY(dgrad(d, Q, V, nullptr));
+    }
     IEEE_TRY(wgrad(c3, X, P(c2.a)));
     IEEE_TRY(dgrad(c3, X, Rb, nullptr, &c2));
     IEEE_TRY(bn_bwd(c2, Rb, nullptr, Rb, nullptr, 1));   // relu mask recomputed from y2 (no residual)
@@ -691,9 +765,13 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     const void* addend = Q;
     if (b.ds >= 0) {
       const ConvUnit& d = N.units[b.ds];
-      IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
-      IEEE_TRY(wgrad(d, Q, xin));
-      IEEE_TRY(dgrad(d, Q, V, nullptr));
+      if (par_ds) {
+        branch_join(bslot);
+      } else {
+        IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
+        IEEE_TRY(wgrad(d, Q, xin));
+        IEEE_TRY(dgrad(d, Q, V, nullptr));
+      }
       addend = V;
     }
     // d(block input) = dgrad(conv1) + identity-branch gradient; it is d(out) of the previous block, whose bn3
