@@ -71,8 +71,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     }
     const int64_t o = (((int64_t)b * Ho + pp) * Wo + q) * C + ch * VEC;
     *(uint4*)(out + o) = Vec16<T>::pack(best);
+    if constexpr (VEC == 8) {           // the 8 argmax bytes as one 8-byte store
+      uint2 pk = make_uint2(0u, 0u);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) arg[o + e] = (uint8_t)bi[e];
+      for (int e = 0; e < 4; ++e) { pk.x |= (unsigned)bi[e] << (8 * e); pk.y |= (unsigned)bi[4 + e] << (8 * e); }
+      *(uint2*)(arg + o) = pk;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) arg[o + e] = (uint8_t)bi[e];
+    }
   }
 }
 
@@ -108,9 +115,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         float d[VEC];
         Vec16<T>::unpack(*(const uint4*)(dout + o), d);
         const int local = r * 3 + s;
+        if constexpr (VEC == 8) {       // the 8 argmax bytes as one 8-byte load
+          const uint2 a = *(const uint2*)(arg + o);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          if (arg[o + e] == local) acc[e] += d[e];
+          for (int e = 0; e < 4; ++e) {
+            if ((int)((a.x >> (8 * e)) & 0xff) == local) acc[e] += d[e];
+            if ((int)((a.y >> (8 * e)) & 0xff) == local) acc[4 + e] += d[4 + e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (arg[o + e] == local) acc[e] += d[e];
+        }
       }
     }
     *(uint4*)(dx + i * VEC) = Vec16<T>::pack(acc);
@@ -139,17 +155,26 @@ static PosGeom pos_geom(int B, int H, int W, int C, int vec) {
 __device__ __forceinline__ int bin_start(int i, int H, int parts) { return (i * H) / parts; }
 __device__ __forceinline__ int bin_end(int i, int H, int parts) { return ((i + 1) * H + parts - 1) / parts; }
 
-// reduce NQ*VEC per-thread accumulators over the ty row lanes; result valid for ty == 0
+// reduce NQ*VEC per-thread accumulators over the ty row lanes; result valid for ty == 0.  Eight quantities share
+// one LDS round (two barriers), so the 32-64 accumulators of the CIM kernels cost 8-16 barriers, not 64-128.
+constexpr int RED_Q = 8;
 template <int NQV>
 __device__ __forceinline__ void reduce_over_ty(float* acc, int tx, int ty, int txn, int tyn, float* red) {
-  for (int q = 0; q < NQV; ++q) {
+#pragma unroll
+  for (int q0 = 0; q0 < NQV; q0 += RED_Q) {
     __syncthreads();
-    red[ty * txn + tx] = acc[q];
+#pragma unroll
+    for (int q = 0; q < RED_Q; ++q)
+      if (q0 + q < NQV) red[q * 256 + ty * txn + tx] = acc[q0 + q];
     __syncthreads();
     if (ty == 0) {
-      float s = 0.f;
-      for (int y = 0; y < tyn; ++y) s += red[y * txn + tx];
-      acc[q] = s;
+#pragma unroll
+      for (int q = 0; q < RED_Q; ++q) {
+        if (q0 + q >= NQV) break;
+        float s = 0.f;
+        for (int y = 0; y < tyn; ++y) s += red[q * 256 + y * txn + tx];
+        acc[q0 + q] = s;
+      }
     }
   }
 }
@@ -160,7 +185,7 @@ __global__ __launch_bounds__(256) void gpool_sum_others_kernel(const T* __restri
                                                                float* __restrict__ Gp, PosGeom g, int64_t gs,
                                                                int write_s) {
   constexpr int VEC = 16 / sizeof(T);
-  __shared__ float red[256];
+  __shared__ float red[RED_Q * 256];
   const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
   const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
   const int c0 = (cb * g.tx + tx) * VEC;
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(256) void ca_pool_kernel(const T* __restrict__ y2, 
                                                       int* __restrict__ amax, PosGeom g, int64_t gs,
                                                       int64_t pool_gs) {
   constexpr int VEC = 16 / sizeof(T);
-  __shared__ float red[256];
+  __shared__ float red[RED_Q * 256];
   __shared__ int redi[256];
   const int z = blockIdx.y;
   const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
@@ -261,7 +286,7 @@ __global__ __launch_bounds__(256) void cim_tail_kernel(const T* __restrict__ y1,
                                                        PosGeom g, int64_t gs, int H, int parts, int mode) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int MAXP = 8;
-  __shared__ float red[256];
+  __shared__ float red[RED_Q * 256];
   const int z = blockIdx.y;
   const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
   const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
@@ -334,7 +359,7 @@ __global__ __launch_bounds__(256) void cim_bwd_datt_kernel(const float* __restri
                                                            const float* __restrict__ st2, float* __restrict__ datt,
                                                            PosGeom g, int64_t gs, int H, int parts) {
   constexpr int VEC = 16 / sizeof(T);
-  __shared__ float red[256];
+  __shared__ float red[RED_Q * 256];
   const int z = blockIdx.y;
   const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
   const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
@@ -375,7 +400,7 @@ __global__ __launch_bounds__(256) void cim_bwd_g_kernel(const float* __restrict_
                                                         float* __restrict__ bnp2) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int MAXP = 8;
-  __shared__ float red[256];
+  __shared__ float red[RED_Q * 256];
   const int z = blockIdx.y;
   const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
   const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
