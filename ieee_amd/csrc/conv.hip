@@ -559,7 +559,7 @@ static GatherPlan plan_gather(int M, int N, int ktiles, int groups) {
     if (f_narrow == 1) p.bn = 64;
     if (f_pipe >= 0) p.pipe = f_pipe;
   }
-  if (p.bn == 256) p.pipe = 0;
+  if (p.bn == 256 && p.pipe != 1) p.pipe = 0;
   if (ktiles < 2 && p.pipe > 1) p.pipe = 0;
   return p;
 }
@@ -611,7 +611,8 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
 #define IEEE_GATHER_CASE(BN_, PIPE_) \
     launch_gather_mode<T, BN_, PIPE_>(mode, grid, smem, st, src, w, dst, addend, bn_partial, a, bs)
     if (plan.bn == 256) {
-      IEEE_GATHER_CASE(256, 0);
+      if (plan.pipe == 1) IEEE_GATHER_CASE(256, 1);
+      else IEEE_GATHER_CASE(256, 0);
     } else if (narrow) {
       switch (plan.pipe) {
         case 1: IEEE_GATHER_CASE(64, 1); break;
