@@ -202,7 +202,7 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
 // of PIPE stages with PIPE-1 k-tiles in flight (few-workgroup layers, where no co-resident workgroup hides the
 // load latency of a one-tile-deep pipeline); bf16 fast path only.
 template <typename T, int BN, bool SLOW, int MODE, int PIPE = 0>
-__global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : 1))) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
+__global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ? 3 : 1)))) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
                                                           T* __restrict__ dst, const T* __restrict__ addend,
                                                           float* __restrict__ bn_partial, ConvArgs a, BwdStats bs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -586,7 +586,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   const bool narrow = plan.bn == 64;
   a.tiles_n = cdiv(N, plan.bn);
   dim3 grid(a.tiles_m * a.tiles_n, groups);
-  const int stages = plan.pipe ? plan.pipe : (sizeof(T) == 2 ? 1 : 2);   // bf16: single LDS stage (see gemm_nt)
+  const int stages = plan.pipe == 5 ? 1 : (plan.pipe ? plan.pipe : (sizeof(T) == 2 ? 1 : 2));   // PIPE 5 = one stage too
   size_t smem = (size_t)stages * (128 + plan.bn) * 128;
   {   // the LDS-staged epilogue needs the C tile: bf16 rows padded by 16 B, fp32 rows unpadded
     const size_t bn = plan.bn;
@@ -624,6 +624,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
     } else {
       switch (plan.pipe) {
         case 1: IEEE_GATHER_CASE(128, 1); break;
+        case 5: IEEE_GATHER_CASE(128, 5); break;
         case 2: IEEE_GATHER_CASE(128, 2); break;
         case 3: IEEE_GATHER_CASE(128, 3); break;
         case 4: IEEE_GATHER_CASE(128, 4); break;

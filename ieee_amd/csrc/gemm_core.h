@@ -356,7 +356,38 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
         for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
     }
   };
-  if constexpr (DMA_STAGES == 1) {
+  if constexpr (DMA_STAGES == 5) {
+    // one LDS stage, but ALL fragments of the k-tile are pulled into registers first (64 VGPRs), so the stage is free
+    // again before the MFMAs start and the next tile's DMA runs under this tile's 32 MFMAs.  Costs a workgroup per CU
+    // (150-160 VGPRs -> 3) against PIPE 1.
+    issue(0);
+    for (int kt = 0; kt < ktiles; ++kt) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // tile kt has landed for every wave
+      const char* At = smem + (wm * (BM / 2)) * 128;
+      const char* Bt = smem + BM * 128 + (wn * (BN / 2)) * 128;
+      Img::Frag fa[Img::KSTEPS][FM], fb[Img::KSTEPS][FN];
+#pragma unroll
+      for (int kk = 0; kk < Img::KSTEPS; ++kk) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[kk][i] = Img::frag(At, i * 16, kk, lane);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[kk][j] = Img::frag(Bt, j * 16, kk, lane);
+      }
+      if (kt + 1 < ktiles) {
+        __syncthreads();              // every wave holds its fragments (lgkmcnt(0)) -> the stage may be overwritten
+        la.next();
+        lb.next();
+        issue(0);
+      }
+#pragma unroll
+      for (int kk = 0; kk < Img::KSTEPS; ++kk)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[kk][j], fa[kk][i], acc[i][j]);
+    }
+  } else if constexpr (DMA_STAGES == 1) {
     // one LDS stage, nothing staged in registers: the fetch of the next tile is not overlapped inside the
     // workgroup at all -- the (small) register and LDS footprint buys a 4th workgroup per CU instead
     issue(0);
