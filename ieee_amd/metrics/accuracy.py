@@ -1,17 +1,10 @@
-"""top-k accuracy, reference torchreid/metrics/accuracy.py:4-38 (logging-only output of the train
-step).  Plain torch indexing on whatever device the logits live on."""
+"""top-k accuracy in percent, the logging-only output of the train step (reference torchreid/metrics/accuracy.py:4-38;
+SURVEY.md §8a A21): one [1]-shaped tensor per requested k, on whatever device the logits live on."""
 
 
 def accuracy(output, target, topk=(1, )):
-    maxk = max(topk)
-    batch_size = target.size(0)
-    if isinstance(output, (tuple, list)):
-        output = output[0]
-    _, pred = output.topk(maxk, 1, True, True)
-    pred = pred.t()
-    correct = pred.eq(target.view(1, -1).expand_as(pred))
-    res = []
-    for k in topk:
-        correct_k = correct[:k].reshape(-1).float().sum(0, keepdim=True)
-        res.append(correct_k.mul_(100.0 / batch_size))
-    return res
+    logits = output[0] if isinstance(output, (tuple, list)) else output
+    n = target.size(0)
+    ranked = logits.topk(max(topk), dim=1, largest=True, sorted=True).indices          # [n, max k] class ids, best first
+    hit = ranked.eq(target.reshape(-1, 1))                                             # a label matches at most one column
+    return [hit[:, :k].any(dim=1).float().sum().reshape(1) * (100.0 / n) for k in topk]
