@@ -66,7 +66,11 @@ template <typename T> struct StoreEpi {
 // one contiguous run instead of a stride-2N walk, which took 15-70 us on the 1024-4096 row tiles of layer1/stem).
 template <typename T, int MODE> struct StagedStoreEpi {
   static constexpr bool kStaged = true;
-  static constexpr bool STATS = MODE != 0;
+  static constexpr bool STATS = MODE == 1 || MODE == 2;
+  // MODE 3 (inference): the consumer BatchNorm runs on running statistics, so its scale / shift are known before
+  // the conv and the whole bn(+residual)(+relu) is applied here: out = [relu](v*scale + shift [+ addend]);
+  // bstats = that BN's [4][N] stats (scale at 2N, shift at 3N), relu flag in `relu`.
+  int relu = 0;
   T* out;
   const T* addend;
   float* bn_partial;   // this group's [2][N][tiles_m] block (MODE 1: sum v, sum v^2; MODE 2: sum g, sum g*y)
@@ -112,7 +116,23 @@ template <typename T, int MODE> struct StagedStoreEpi {
         if (m >= M) continue;
         uint4 v = *(const uint4*)(smem + r * ROWB + ch * 16);
         T* o = out + (int64_t)m * ld + n;
-        if (addend != nullptr || STATS) {
+        if constexpr (MODE == 3) {
+          float f[VEC];
+          Vec16<T>::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) f[e] = f[e] * bstats[2 * N + n + e] + bstats[3 * N + n + e];
+          if (addend != nullptr) {
+            float a[VEC];
+            Vec16<T>::unpack(*(const uint4*)(addend + (int64_t)m * ld + n), a);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] += a[e];
+          }
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] = fmaxf(f[e], 0.f);
+          }
+          v = Vec16<T>::pack(f);
+        } else if (addend != nullptr || STATS) {
           float f[VEC];
           Vec16<T>::unpack(v, f);
           if (addend != nullptr) {
@@ -195,6 +215,7 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
   const void* mask;
   const float* stats;
   int64_t act_gs, stats_gs;
+  int relu;                  // MODE 3 only
 };
 
 // (forcing 4 waves per SIMD here spills 80 VGPRs and is 2.5x slower; the default allocation gives 3)
@@ -214,10 +235,11 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
   w += z * a.w_gs;
   dst += z * a.dst_gs;
   if (addend != nullptr) addend += z * a.dst_gs;
-  StagedStoreEpi<T, MODE> epi{dst, addend, MODE ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
+  StagedStoreEpi<T, MODE> epi{0, dst, addend, (MODE == 1 || MODE == 2) ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
                               MODE == 2 ? (const T*)bs.y + z * bs.act_gs : nullptr,
                               (MODE == 2 && bs.mask) ? (const T*)bs.mask + z * bs.act_gs : nullptr,
-                              (MODE == 2 && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
+                              ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
+  if constexpr (MODE == 3) epi.relu = bs.relu;
   if constexpr (PIPE > 0) {   // both operands through LDS-DMA
     static_assert(!SLOW && sizeof(T) == 2, "the LDS-DMA ring is the bf16 vector path");
     const int ch = nt_dma_chunk(threadIdx.x);
@@ -535,7 +557,8 @@ static void launch_gather_inst(dim3 grid, size_t smem, hipStream_t st, const T* 
 template <typename T, int BN, int PIPE>
 static void launch_gather_mode(int mode, dim3 grid, size_t smem, hipStream_t st, const T* src, const T* w, T* dst,
                                const T* addend, float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
-  if (mode == 2) launch_gather_inst<T, BN, false, 2, PIPE>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
+  if (mode == 3) launch_gather_inst<T, BN, false, 3, PIPE>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
+  else if (mode == 2) launch_gather_inst<T, BN, false, 2, PIPE>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
   else if (mode == 1) launch_gather_inst<T, BN, false, 1, PIPE>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
   else launch_gather_inst<T, BN, false, 0, PIPE>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
 }
@@ -567,7 +590,7 @@ static GatherPlan plan_gather(int M, int N, int ktiles, int groups) {
 template <typename T>
 static int launch_gather(const T* src, const T* w, T* dst, const T* addend, const GatherGeom& g, int M, int N,
                          int Ktrue, int ldw, int groups, int64_t src_gs, int64_t w_gs, int64_t dst_gs, bool slow,
-                         hipStream_t st, float* bn_partial = nullptr, const BwdStats* bwd = nullptr) {
+                         hipStream_t st, float* bn_partial = nullptr, const BwdStats* bwd = nullptr, bool affine = false) {
   const int BK = ImgNT<T>::BK;
   ConvArgs a;
   a.g = g;
@@ -601,9 +624,13 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
     set_error(IEEE_ERR_UNSUPPORTED, "conv: fused BN statistics need the bf16 vector path");
     return IEEE_ERR_UNSUPPORTED;
   }
-  BwdStats bs{nullptr, nullptr, nullptr, 0, 0};
+  BwdStats bs{nullptr, nullptr, nullptr, 0, 0, 0};
   if (bwd) bs = *bwd;
-  const int mode = (stats && bwd) ? 2 : (stats ? 1 : 0);
+  if (affine && slow) {
+    set_error(IEEE_ERR_UNSUPPORTED, "conv: the fused inference BatchNorm needs the vector path");
+    return IEEE_ERR_UNSUPPORTED;
+  }
+  const int mode = affine ? 3 : ((stats && bwd) ? 2 : (stats ? 1 : 0));
   if (slow) {
     if (narrow) launch_gather_inst<T, 64, true, 0, 0>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
     else launch_gather_inst<T, 128, true, 0, 0>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
@@ -765,6 +792,31 @@ extern "C" int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int
   IEEE_REQUIRE(false, "conv2d_fwd: bad dtype %d", dtype);
 }
 
+extern "C" int ieee_conv2d_fwd_bn_eval(const void* x, const void* w_packed, void* out, const void* residual,
+                                       const float* bn_stats, int relu, int dtype, int64_t groups, int64_t N, int64_t Hi,
+                                       int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride,
+                                       int64_t pad, int64_t x_gs, int64_t w_gs, int64_t out_gs, void* stream) {
+  IEEE_REQUIRE(x && w_packed && out && bn_stats, "conv2d_fwd_bn_eval: null pointer");
+  Dims d;
+  IEEE_TRY(check_dims("conv2d_fwd_bn_eval", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
+  IEEE_REQUIRE(Co % elem_vec(dtype) == 0, "conv2d_fwd_bn_eval: Cout %ld must be a multiple of %d", (long)Co, elem_vec(dtype));
+  GatherGeom g{d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.R, d.S, d.stride, -d.pad, +1, 1, d.N * d.Ho * d.Wo};
+  const int bk = elem_bk(dtype), vec = elem_vec(dtype);
+  const bool fast = (Ci % bk == 0) || (Ci < bk && Ci % vec == 0 && bk % Ci == 0 && S % (bk / Ci) == 0) ||
+                    (Ci < vec && vec % Ci == 0 && pad == 0 && (bk / Ci) % S == 0 && R % ((bk / Ci) / S) == 0 &&
+                     S % (vec / Ci) == 0 && Wi % (vec / Ci) == 0 && stride % (vec / Ci) == 0);
+  const int ldw = (int)ieee_conv_packed_ld(dtype, Ci, R, S);
+  hipStream_t st = (hipStream_t)stream;
+  BwdStats bs{nullptr, nullptr, bn_stats, out_gs, 4 * Co, relu};
+  if (dtype == IEEE_F32)
+    return launch_gather<float>((const float*)x, (const float*)w_packed, (float*)out, (const float*)residual, g, g.npix,
+                                d.Co, d.R * d.S * d.Ci, ldw, (int)groups, x_gs, w_gs, out_gs, !fast, st, nullptr, &bs, true);
+  if (dtype == IEEE_BF16)
+    return launch_gather<bf16>((const bf16*)x, (const bf16*)w_packed, (bf16*)out, (const bf16*)residual, g, g.npix, d.Co,
+                               d.R * d.S * d.Ci, ldw, (int)groups, x_gs, w_gs, out_gs, !fast, st, nullptr, &bs, true);
+  IEEE_REQUIRE(false, "conv2d_fwd_bn_eval: bad dtype %d", dtype);
+}
+
 extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
                                  int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
                                  int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
@@ -784,7 +836,7 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
     return launch_gather<float>((const float*)dy, (const float*)w_packed_d, (float*)dx, (const float*)addend, g,
                                 g.npix, d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st);
   if (dtype == IEEE_BF16) {
-    BwdStats bs{bn_y, bn_mask, bn_stats, dx_gs, 4 * Ci};
+    BwdStats bs{bn_y, bn_mask, bn_stats, dx_gs, 4 * Ci, 0};
     return launch_gather<bf16>((const bf16*)dy, (const bf16*)w_packed_d, (bf16*)dx, (const bf16*)addend, g, g.npix,
                                d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st, bn_partial,
                                bn_partial ? &bs : nullptr);

@@ -382,6 +382,18 @@ struct Run {
                          gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), bnpart_cur, n.bn_mom, n.bn_eps,
                          training, relu, rb, st);
   }
+  // inference: conv + BatchNorm(running statistics) (+ residual) (+ ReLU) in ONE launch; the raw conv output is never
+  // written.  The tiny finalize launch turns the running statistics into this unit's scale / shift first.
+  int conv_bn_eval(const ConvUnit& u, const void* in, const void* residual, void* out, int relu) {
+    const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
+    IEEE_TRY(ieee_bn2d_fwd(P(u.y), nullptr, nullptr, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b),
+                           gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), bnpart_cur, n.bn_mom, n.bn_eps,
+                           0, relu, 0, st));
+    prof_begin(0, u);
+    struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
+    return ieee_conv2d_fwd_bn_eval(in, P(u.wf), out, residual, F(u.stats), relu, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co,
+                                   u.R, u.S, u.stride, u.pad, (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, st);
+  }
   // backward of out = [relu](bn(y) [+res]); dy may alias dout
   bool& fused_bwd = n.fused_bwd_state;   // the last dgrad already emitted the BN-backward sums of the next bn_bwd()
   int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0,
@@ -587,8 +599,14 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
   IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, 4, 3, st));
   // stem: conv7x7/2 -> BN -> ReLU -> maxpool3x3/2   (resnet.py:622-626)
   const ConvUnit& s = N.units[N.u_stem];
-  IEEE_TRY(conv(s, P(N.x0), training != 0));
-  IEEE_TRY(bn(s, nullptr, P(s.a), 1, training));
+  static const bool fuse_eval = !(getenv("IEEE_EVAL_FUSE") && atoi(getenv("IEEE_EVAL_FUSE")) == 0);
+  const bool fe = !training && fuse_eval;        // inference: BatchNorm folded into the conv epilogues
+  if (fe) {
+    IEEE_TRY(conv_bn_eval(s, P(N.x0), nullptr, P(s.a), 1));
+  } else {
+    IEEE_TRY(conv(s, P(N.x0), training != 0));
+    IEEE_TRY(bn(s, nullptr, P(s.a), 1, training));
+  }
   IEEE_TRY(ieee_maxpool3x3s2_fwd(P(s.a), P(N.pool), (uint8_t*)P(N.pool_arg), dt, 3, B, s.Ho, s.Wo, s.Co, st));
   const void* x = P(N.pool);
   int ds_slot = 0;                    // branch event slots 0..3: forward, 4..7: backward
@@ -605,6 +623,19 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
       BranchScope scope(*this, ds_slot);
       IEEE_TRY(conv(d, x, ws_));
       IEEE_TRY(bn(d, nullptr, P(d.a), 0, training));
+    }
+    if (fe) {   // inference: three fused launches (+ one for the downsample branch) per block
+      IEEE_TRY(conv_bn_eval(c1, x, nullptr, P(c1.a), 1));
+      IEEE_TRY(conv_bn_eval(c2, P(c1.a), nullptr, P(c2.a), 1));
+      const void* idn = x;
+      if (b.ds >= 0) {
+        const ConvUnit& d = N.units[b.ds];
+        IEEE_TRY(conv_bn_eval(d, x, nullptr, P(d.a), 0));
+        idn = P(d.a);
+      }
+      IEEE_TRY(conv_bn_eval(c3, P(c2.a), idn, P(c3.a), 1));
+      x = P(c3.a);
+      continue;
     }
     IEEE_TRY(conv(c1, x, ws_));
     IEEE_TRY(bn(c1, nullptr, P(c1.a), 1, training));

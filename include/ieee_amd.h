@@ -111,6 +111,13 @@ int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int dtype, int
  * sum / sum-of-squares of the stored outputs, rblocks = ieee_conv2d_fwd_stats_rblocks(); hand the same buffer
  * and rblocks to ieee_bn2d_fwd(stats_rblocks) and the separate statistics pass disappears */
 int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t Wo);
+/* inference: conv + eval-mode BatchNorm (+ residual) (+ ReLU) in one launch -- Bottleneck.forward / the stem in eval
+ * mode (resnet.py:164-184, 622-626).  bn_stats: that BN's [groups][4][Co] statistics as ieee_bn2d_fwd(training = 0,
+ * out = NULL) leaves them (scale at 2*Co, shift at 3*Co); out = [relu](conv(x)*scale + shift [+ residual]). */
+int ieee_conv2d_fwd_bn_eval(const void* x, const void* w_packed, void* out, const void* residual,
+                            const float* bn_stats, int relu, int dtype, int64_t groups, int64_t N, int64_t Hi,
+                            int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                            int64_t x_gs, int64_t w_gs, int64_t out_gs, void* stream);
 
 /* dx[N,Hi,Wi,Ci] = conv_transpose(dy) (+ addend, same layout as dx, may be NULL): the
  * residual-branch gradient of Bottleneck (resnet.py:181 `out += identity`) is folded in here */

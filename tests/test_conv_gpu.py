@@ -181,3 +181,42 @@ def test_fused_bn_partials_in_conv_epilogues():
             gq = d
         torch.testing.assert_close(p2[:, 0].sum(-1), gq.sum(1), rtol=1e-3, atol=5e-2)
         torch.testing.assert_close(p2[:, 1].sum(-1), (gq * yv).sum(1), rtol=1e-3, atol=5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("res,relu", [(False, 1), (True, 1), (False, 0)])
+def test_conv_with_fused_eval_batchnorm(dtype, res, relu):
+    """inference: conv + BatchNorm(running statistics) (+ residual) (+ ReLU) in one launch (ieee_conv2d_fwd_bn_eval)
+    against torch's conv2d -> batch_norm(eval) -> add -> relu"""
+    from ieee_amd import _lib as L, _ops
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(13)
+    G, N, H, W, Ci, Co = 3, 3, 10, 6, 64, 192
+    rt = (lambda t: t.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = rt(torch.randn(G, N, Ci, H, W, generator=g))
+    w = rt(torch.randn(G, Co, Ci, 3, 3, generator=g) * 0.05)
+    idn = rt(torch.randn(G, N, Co, H, W, generator=g))
+    gamma, beta = torch.rand(G, Co, generator=g) + 0.5, torch.randn(G, Co, generator=g) * 0.1
+    rm, rv = torch.randn(G, Co, generator=g) * 0.1, torch.rand(G, Co, generator=g) + 0.5
+    want = []
+    for i in range(G):
+        y = F.batch_norm(F.conv2d(x[i], w[i], padding=1), rm[i], rv[i], gamma[i], beta[i], training=False, eps=1e-5)
+        if res:
+            y = y + idn[i]
+        want.append(torch.relu(y) if relu else y)
+    dt = L.IEEE_BF16 if dtype == torch.bfloat16 else L.IEEE_F32
+    xd = x.permute(0, 1, 3, 4, 2).contiguous().cuda().to(dtype)
+    rd = idn.permute(0, 1, 3, 4, 2).contiguous().cuda().to(dtype)
+    wp = _ops.pack_conv_weight(w.cuda(), dtype, 0)
+    stats = torch.empty(G, 4, Co, device="cuda")
+    dummy = torch.empty(G, N, H, W, Co, device="cuda", dtype=dtype)
+    part = torch.empty(64, device="cuda")
+    gd, bd, rmd, rvd = gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda()
+    L.check(lib.ieee_bn2d_fwd(L.ptr(dummy), None, None, dt, G, N * H * W, Co, N * H * W * Co, L.ptr(gd), L.ptr(bd), Co, L.ptr(rmd),
+                              L.ptr(rvd), Co, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 0, relu, 0, L.stream()))
+    out = torch.empty_like(dummy)
+    L.check(lib.ieee_conv2d_fwd_bn_eval(L.ptr(xd), L.ptr(wp), L.ptr(out), L.ptr(rd) if res else None, L.ptr(stats), relu, dt, G, N,
+                                        H, W, Ci, Co, 3, 3, 1, 1, xd[0].numel(), wp.stride(0), out[0].numel(), L.stream()))
+    tol = dict(rtol=2e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    for i in range(G):
+        torch.testing.assert_close(out[i].float().cpu().permute(0, 3, 1, 2), want[i], **tol)
