@@ -31,6 +31,8 @@ class NativeNet:
                                      _lib.ptr(model._flat_buffers), offs, n))
         nbytes = lib.ieee_net_workspace_bytes(self.handle)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=model._flat_params.device)
+        self.model = model
+        self._eval_key = None
 
     def __del__(self):
         try:
@@ -50,9 +52,18 @@ class NativeNet:
         else:
             logits = None
             feats = torch.empty((B, 2304), dtype=torch.float32, device=dev)
+        m = self.model
+        # inference cache (ieee_net_eval_cache): valid while nothing has written the parameters / running statistics --
+        # torch's version counters see every in-place op on the views, `_native_epoch` counts the native writers
+        key = (m._flat_params._version, m._flat_buffers._version, m._native_epoch)
+        if training:
+            m._native_epoch += 1                      # running statistics are updated by the native forward
+        elif key != self._eval_key:
+            _lib.check(self.lib.ieee_net_eval_cache(self.handle, 0))
         _lib.check(self.lib.ieee_net_forward(self.handle, _lib.ptr(self.workspace), _lib.ptr(xs[0]), _lib.ptr(xs[1]),
                                              _lib.ptr(xs[2]), 1 if training else 0, _lib.ptr(logits),
                                              _lib.ptr(feats), _lib.stream()))
+        self._eval_key = None if training else key
         return logits, feats
 
     def backward(self, dlogits, dfeats):

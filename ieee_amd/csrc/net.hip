@@ -78,6 +78,11 @@ struct Net {
   hipEvent_t pack_ev[2] = {nullptr, nullptr};
   const void* pack_uploaded_ws = nullptr;
   bool fused_bwd_state = false;   // survives between the staged ieee_net_backward_part calls
+  // inference: the packed weights and every BatchNorm's scale / shift only depend on the parameters and running
+  // statistics; while the caller vouches that those have not changed (ieee_net_eval_cache) consecutive eval forwards
+  // skip the packing launch and the 55 finalize launches
+  bool eval_cache_valid = false;
+  const void* eval_cache_ws = nullptr;
   // Weight-gradient kernels run on a second (low-priority) HIP stream: nothing on the dgrad / BN-backward chain
   // depends on them, so they fill the tails and the HBM-bound phases of that chain.  side_ready[i] is recorded on
   // the caller's stream when wgrad i's dY operand is final; gbuf_read[b] on the side stream after the last wgrad
@@ -384,9 +389,11 @@ struct Run {
   }
   // inference: conv + BatchNorm(running statistics) (+ residual) (+ ReLU) in ONE launch; the raw conv output is never
   // written.  The tiny finalize launch turns the running statistics into this unit's scale / shift first.
+  bool eval_cached = false;      // this forward may reuse the packed weights / BN scale-shift of the previous eval forward
   int conv_bn_eval(const ConvUnit& u, const void* in, const void* residual, void* out, int relu) {
     const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
-    IEEE_TRY(ieee_bn2d_fwd(P(u.y), nullptr, nullptr, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b),
+    if (!eval_cached)
+      IEEE_TRY(ieee_bn2d_fwd(P(u.y), nullptr, nullptr, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b),
                            gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), bnpart_cur, n.bn_mom, n.bn_eps,
                            0, relu, 0, st));
     prof_begin(0, u);
@@ -593,8 +600,9 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
     } else if (training)
       IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev + bytes_eval, (int64_t)N.pack_train.size(), N.pack_blocks_train,
                                      dt, st));
-    else
+    else if (!(eval_cached = (N.eval_cache_valid && N.eval_cache_ws == (const void*)ws && !N.profiling)))
       IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev, (int64_t)N.pack_eval.size(), N.pack_blocks_eval, dt, st));
+    if (training) N.eval_cache_valid = false;     // the step that follows changes parameters and running statistics
   }
   IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, 4, 3, st));
   // stem: conv7x7/2 -> BN -> ReLU -> maxpool3x3/2   (resnet.py:622-626)
@@ -666,9 +674,9 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
   const int mode = !N.interaction ? 2 : (N.attention ? 0 : 1);
   if (N.interaction) {
     IEEE_TRY(conv(uo, Fm, training != 0));
-    IEEE_TRY(bn(uo, nullptr, nullptr, 1, training));    // statistics only: the CIM tail applies scale/shift itself
+    if (!eval_cached) IEEE_TRY(bn(uo, nullptr, nullptr, 1, training));    // statistics only: the CIM tail applies scale/shift itself
     IEEE_TRY(conv(ur, P(N.S), training != 0));
-    IEEE_TRY(bn(ur, nullptr, nullptr, 1, training));
+    if (!eval_cached) IEEE_TRY(bn(ur, nullptr, nullptr, 1, training));
     if (N.attention) {   // ChannelAttention.forward :277-282
       IEEE_TRY(ieee_ca_pool(P(ur.y), F(ur.stats), F(N.avgmax), F(N.avgmax) + BC, 2 * BC, (int32_t*)P(N.amax), dt, B, Hh_,
                             Ww, C, st));
@@ -731,6 +739,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
   }
   if (!training) {
     IEEE_HIP(hipMemcpyAsync(feats_out, F(N.fcall), sizeof(float) * (size_t)B * 3 * R, hipMemcpyDeviceToDevice, (hipStream_t)st));
+    if (fe) { N.eval_cache_valid = true; N.eval_cache_ws = ws; }
     return IEEE_OK;
   }
   {   // classifiers   :507-511
@@ -1115,6 +1124,13 @@ extern "C" int ieee_net_side_wait(void* handle, void* workspace, void* waiting_s
   Run r(*n, workspace, waiting_stream);
   if (is_launch_stream) r.side_join();
   else r.side_wait_on(waiting_stream);
+  return IEEE_OK;
+}
+
+extern "C" int ieee_net_eval_cache(void* handle, int keep) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n, "net_eval_cache: null handle");
+  if (!keep) n->eval_cache_valid = false;
   return IEEE_OK;
 }
 

@@ -73,6 +73,7 @@ class IEEE3modalPart(nn.Module):
         self.using_REM = using_REM
         self.compute_dtype = compute_dtype
         self._nets = {}
+        self._native_epoch = 0                   # bumped by every native writer of parameters / running statistics
         self._spec = state_spec(num_classes)     # all children exist (keys identical to the default reference)
         self._build_storage(device)
         self._init_params()
@@ -225,6 +226,11 @@ class IEEE3modalPart(nn.Module):
                 out.append(mine)
             self._part_runs, self._part_runs_key = out, key
         return self._part_runs
+
+    def invalidate_eval_cache(self):
+        """call after writing parameters or running statistics in a way torch's version counters do not see
+        (e.g. through `.data`): the next eval forward re-packs the weights and re-derives the BatchNorm scale / shift"""
+        self._native_epoch += 1
 
     def grad_part_ranges(self):
         """[start, end) element ranges of the flat gradient buffer that are final after each of the 5 staged

@@ -28,6 +28,7 @@ class FusedSGD(torch.optim.Optimizer):
         g = self.param_groups[0]
         m = self.model
         buf = self.momentum_buffer()
+        m._native_epoch += 1                      # parameters change behind torch's version counters
         for a, b in runs:
             _lib.check(lib.ieee_sgd_nesterov_step(_lib.ptr(m._flat_params[a:b]), _lib.ptr(m._flat_grads[a:b]),
                                                   _lib.ptr(buf[a:b]), b - a, float(g['lr']), float(g['momentum']),
@@ -86,6 +87,7 @@ class FusedAdam(torch.optim.Optimizer):
         mdl = self.model
         m, v, vmax = self._buffers()
         self._step += 1
+        mdl._native_epoch += 1                    # parameters change behind torch's version counters
         for a, b in mdl.trainable_runs():
             _lib.check(lib.ieee_adam_step(_lib.ptr(mdl._flat_params[a:b]), _lib.ptr(mdl._flat_grads[a:b]), _lib.ptr(m[a:b]),
                                           _lib.ptr(v[a:b]), _lib.ptr(vmax[a:b]) if vmax is not None else None, b - a,

@@ -333,6 +333,11 @@ int ieee_net_backward_part(void* handle, void* workspace, const float* dlogits, 
 int ieee_net_backward_part_async(void* handle, void* workspace, const float* dlogits, const float* dfeats, int part,
                                  void* stream);
 int ieee_net_side_wait(void* handle, void* workspace, void* waiting_stream, int is_launch_stream);
+/* Inference cache: after an eval-mode ieee_net_forward the workspace holds the packed weights and every BatchNorm's
+ * scale / shift; the next eval forward on the same workspace reuses them (no packing launch, no finalize launches)
+ * unless ieee_net_eval_cache(handle, 0) was called in between.  The CALLER must call it whenever parameters or
+ * running statistics may have changed outside ieee_net_forward(training = 1) (optimizer steps, state loading, ...). */
+int ieee_net_eval_cache(void* handle, int keep);
 /* measurement: enable=1 starts recording a HIP event pair (on the launch stream) around every conv
  * launch of subsequent forward/backward calls; enable=0 stops, synchronises the device and returns
  * out6 = {ms, algorithmic FLOPs, launches} for [0] forward+dgrad (conv_gather_kernel) and

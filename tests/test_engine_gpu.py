@@ -179,3 +179,54 @@ def test_multi_stream_step_is_bitwise_reproducible():
     for a, b in zip(finals[0][:3], finals[1][:3]):
         assert torch.equal(a, b)
     assert all(l == l for l in finals[0][3])          # no NaN
+
+
+def test_eval_cache_follows_parameter_changes():
+    """consecutive eval forwards reuse the packed weights / BN scale-shift; any change of parameters or running
+    statistics (torch in-place ops, load_state_dict, a train step, invalidate_eval_cache after a .data write) must
+    be picked up by the next eval forward"""
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    from ieee_amd.engine import Image3MEngine
+    from tests.util_model import generated_state, images
+    B = 8
+    m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, compute_dtype=torch.float32)
+    state = generated_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 3)
+    m.load_state_dict(state)
+    m.eval()
+    x = [t.cuda() for t in images(B, 3)]
+
+    def fresh_reference():
+        r = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, compute_dtype=torch.float32)
+        r.load_state_dict(m.state_dict())
+        r.eval()
+        with torch.no_grad():
+            return r(x).clone()
+
+    with torch.no_grad():
+        f0 = m(x).clone()
+        f1 = m(x).clone()                                   # cached path
+    assert torch.equal(f0, f1) and torch.equal(f0, fresh_reference())
+    with torch.no_grad():
+        m.backbone[0].layer1[0].conv1.weight.mul_(1.5)      # in-place op on a view: version counter
+        f2 = m(x).clone()
+    assert not torch.equal(f2, f0) and torch.equal(f2, fresh_reference())
+    with torch.no_grad():
+        m.backbone[1].bn1.running_var.add_(0.25)            # a buffer
+        f3 = m(x).clone()
+    assert not torch.equal(f3, f2) and torch.equal(f3, fresh_reference())
+    m.backbone[2].layer4[2].conv3.weight.data.mul_(0.5)     # .data write: invisible to the version counters
+    m.invalidate_eval_cache()
+    with torch.no_grad():
+        f4 = m(x).clone()
+    assert not torch.equal(f4, f3) and torch.equal(f4, fresh_reference())
+    # a train step in between (native writers) and back to eval
+    opt = build_optimizer(m, optim="sgd", lr=1e-2, weight_decay=0.0, momentum=0.0)
+    eng = Image3MEngine(FakeDM(), m, opt, margin=1, use_gpu=True)
+    m.train()
+    pids = torch.arange(B) // 4
+    eng.forward_backward({"img": images(B, 4), "pid": pids, "camid": pids * 0, "impath": "", "timeid": pids * 0})
+    m.eval()
+    with torch.no_grad():
+        f5 = m(x).clone()
+    assert not torch.equal(f5, f4) and torch.equal(f5, fresh_reference())
