@@ -110,9 +110,11 @@ __device__ int g_dbg_nok_dummy;
 // TN slots: k-row = t/CPR + (256/CPR)*slot, chunk = t%CPR.
 // Epilogue contract: epi(m, n, f32x4 v): v[r] is C[m][n+r] (global indices).
 
+// Register-staged cores (fp32 everywhere; bf16 for the element-gather "slow" loaders).  The bf16 vector paths of the
+// convs and the distmat use the LDS-DMA cores further down.
 // STAGES = 2: double-buffered LDS, one barrier per k-tile.  STAGES = 1: one LDS stage and two barriers per
-// k-tile — half the LDS, so twice the workgroups per CU; measured faster for every bf16 conv shape of the net
-// (occupancy hides the load latency better than the second buffer does).
+// k-tile -- half the LDS, so twice the workgroups per CU; measured faster wherever it was tried (occupancy hides
+// the load latency better than the second buffer does).
 template <typename T, int BM, int BN, int STAGES, class LA, class LB, class Epi>
 __device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem, int g_dbg_nok = 0) {
   typedef ImgNT<T> Img;
