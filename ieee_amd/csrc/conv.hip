@@ -361,9 +361,23 @@ __global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wg
 // order so the (dominant) slab reads are coalesced; for 3x3 / 7x7 the 4-byte writes scatter.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                            int splitk, int Co, int Ci, int RS, int64_t slab_gs,
-                                                           int64_t dw_gs, int accumulate) {
+                                                           int64_t dw_gs, int accumulate, int vec4) {
   const int z = blockIdx.y;
   const int64_t total = (int64_t)Co * Ci * RS;
+  if (vec4) {   // 1x1 with 16-byte aligned operands: slab order == OIHW order -> 16-byte lanes (most of the slab bytes)
+    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= total) return;
+    const float* s = slab + z * slab_gs + i4;
+    float4 acc = *(const float4*)s;
+    for (int k = 1; k < splitk; ++k) {
+      const float4 v = *(const float4*)(s + k * total);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4* d = (float4*)(dw + z * dw_gs + i4);
+    if (accumulate) { const float4 o = *d; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    *d = acc;
+    return;
+  }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index in slab order [co][rs][ci]
   if (i >= total) return;
   const float* s = slab + z * slab_gs + i;
@@ -935,8 +949,10 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   }
   IEEE_TRY(launch_status("conv_wgrad_kernel"));
   const int64_t total = (int64_t)d.Co * d.Ci * d.R * d.S;
-  dim3 rgrid(cdiv(total, 256), (unsigned)groups);
+  const bool vec4 = d.R * d.S == 1 && (total & 3) == 0 && (dw_gs & 3) == 0 && (a.slab_gs & 3) == 0 &&
+                    ((uintptr_t)dw_oihw & 15) == 0 && ((uintptr_t)slab & 15) == 0;
+  dim3 rgrid(cdiv(vec4 ? total / 4 : total, 256), (unsigned)groups);
   wgrad_reduce_kernel<<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs,
-                                             accumulate);
+                                             accumulate, vec4 ? 1 : 0);
   return launch_status("wgrad_reduce_kernel");
 }
