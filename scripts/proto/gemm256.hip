@@ -105,6 +105,350 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const bf16* __restrict_
     }
 }
 
+// variant 2: phase schedule.  Per k-tile four quadrant phases of 16 MFMAs; the next tile's operand groups (64 rows =
+// 8 KB each, 2-3 DMAs per thread per phase) are issued between them: A groups 1,3 + B groups at phases 0/1 into the
+// other buffer, and the tile-after-next's A groups 0,2 at phase 2 into THIS buffer (every wave has finished with them
+// after phase 1).  One counted vmcnt and two barriers per k-tile.
+__global__ __launch_bounds__(512, 1) void gemm256_phase_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                               bf16* __restrict__ C, int M, int N, int K, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef ImgNT<bf16> Img;
+  constexpr int STAGE = 512 * 128;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 2, wc = wave & 3;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int ch = nt_dma_chunk(t & 255);
+  const bf16* pa[4];
+  const bf16* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (t >> 3) + 64 * i;
+    pa[i] = A + (int64_t)(m0 + row) * K + ch * 8;
+    pb[i] = B + (int64_t)(n0 + row) * K + ch * 8;
+  }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto issueA = [&](int kt, int buf, int g) { glds16(pa[g] + kt * 64, smem + buf * STAGE + (64 * g + 8 * wave_u) * 128); };
+  auto issueB = [&](int kt, int buf, int g) { glds16(pb[g] + kt * 64, smem + buf * STAGE + 256 * 128 + (64 * g + 8 * wave_u) * 128); };
+  const int ktiles = K / 64;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { issueA(0, 0, g); issueB(0, 0, g); }
+  if (ktiles > 1) { issueA(1, 1, 0); issueA(1, 1, 2); wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int b = kt & 1, nb = b ^ 1;
+    const char* cur = smem + b * STAGE;
+    const char* At = cur + (wr * 128) * 128;
+    const char* Bt = cur + 256 * 128 + (wc * 64) * 128;
+    auto quadrant = [&](int rh, int chh) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        Img::Frag fa[4], fb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = Img::frag(Bt + (chh * 32) * 128, j * 16, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = Img::frag(At + (rh * 64) * 128, i * 16, kk, lane);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[rh * 4 + i][chh * 2 + j] = mfma16(fb[j], fa[i], acc[rh * 4 + i][chh * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    };
+    const bool n1 = kt + 1 < ktiles, n2 = kt + 2 < ktiles;
+    if (n1) { issueA(kt + 1, nb, 1); issueA(kt + 1, nb, 3); issueB(kt + 1, nb, 0); }
+    quadrant(0, 0);
+    if (n1) { issueB(kt + 1, nb, 1); issueB(kt + 1, nb, 2); issueB(kt + 1, nb, 3); }
+    quadrant(0, 1);
+    __syncthreads();                       // every wave is done with A groups 0 and 2 of this buffer
+    if (n2) { issueA(kt + 2, b, 0); issueA(kt + 2, b, 2); }
+    quadrant(1, 1);
+    quadrant(1, 0);
+    if (n2) wait_vmcnt<2>(); else wait_vmcnt<0>();
+    __syncthreads();                       // next tile has landed for every wave; this buffer is free
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+      const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      *(uint2*)(C + (int64_t)m * N + n) = make_uint2(Vec16<bf16>::pk(acc[i][j][0], acc[i][j][1]), Vec16<bf16>::pk(acc[i][j][2], acc[i][j][3]));
+    }
+}
+
+// variant 3: variant 2's operand-group schedule with the guide's phase shape and wave-group stagger: every phase is
+// {ds_reads of the quadrant; s_barrier; 16 MFMAs; s_barrier}, and the waves of the lower half of the tile (wr == 1, the
+// second wave of every SIMD) run one barrier late, so on each SIMD one wave reads LDS while the other feeds the MFMA
+// pipe.  DMA issue points are moved later accordingly (a group is re-staged >= 2 phases after its last reader).
+__global__ __launch_bounds__(512, 1) void gemm256_stagger_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                                 bf16* __restrict__ C, int M, int N, int K, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef ImgNT<bf16> Img;
+  constexpr int STAGE = 512 * 128;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 2, wc = wave & 3;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wr_u = __builtin_amdgcn_readfirstlane(wr);
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int ch = nt_dma_chunk(t & 255);
+  const bf16* pa[4];
+  const bf16* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (t >> 3) + 64 * i;
+    pa[i] = A + (int64_t)(m0 + row) * K + ch * 8;
+    pb[i] = B + (int64_t)(n0 + row) * K + ch * 8;
+  }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto issueA = [&](int kt, int buf, int g) { glds16(pa[g] + kt * 64, smem + buf * STAGE + (64 * g + 8 * wave_u) * 128); };
+  auto issueB = [&](int kt, int buf, int g) { glds16(pb[g] + kt * 64, smem + buf * STAGE + 256 * 128 + (64 * g + 8 * wave_u) * 128); };
+  const int ktiles = K / 64;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { issueA(0, 0, g); issueB(0, 0, g); }
+  if (ktiles > 1) { issueA(1, 1, 0); issueA(1, 1, 2); wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+  __builtin_amdgcn_s_barrier();
+  if (wr_u == 1) __builtin_amdgcn_s_barrier();      // stagger: the second wave of every SIMD runs one barrier late
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int b = kt & 1, nb = b ^ 1;
+    const char* cur = smem + b * STAGE;
+    const char* At = cur + (wr * 128) * 128;
+    const char* Bt = cur + 256 * 128 + (wc * 64) * 128;
+    auto quadrant = [&](int rh, int chh) {
+      Img::Frag fa[2][4], fb[2][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[kk][j] = Img::frag(Bt + (chh * 32) * 128, j * 16, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[kk][i] = Img::frag(At + (rh * 64) * 128, i * 16, kk, lane);
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[rh * 4 + i][chh * 2 + j] = mfma16(fb[kk][j], fa[kk][i], acc[rh * 4 + i][chh * 2 + j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    };
+    const bool n1 = kt + 1 < ktiles, n2 = kt + 2 < ktiles;
+    quadrant(0, 0);
+    if (n1) { issueA(kt + 1, nb, 1); issueA(kt + 1, nb, 3); issueB(kt + 1, nb, 0); issueB(kt + 1, nb, 1); issueB(kt + 1, nb, 2); issueB(kt + 1, nb, 3); }
+    quadrant(0, 1);
+    quadrant(1, 1);
+    wait_vmcnt<0>();                       // the next tile (and, long ago, its A groups 0/2) has landed for this wave
+    if (n2) { issueA(kt + 2, b, 0); issueA(kt + 2, b, 2); }
+    quadrant(1, 0);
+  }
+  if (wr_u == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+      const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      *(uint2*)(C + (int64_t)m * N + n) = make_uint2(Vec16<bf16>::pk(acc[i][j][0], acc[i][j][1]), Vec16<bf16>::pk(acc[i][j][2], acc[i][j][3]));
+    }
+}
+
+// variant 4 = variant 3 + fragment reuse across phases (A sub-tile kept for two phases, B sub-tile for two): 28
+// instead of 48 ds_read_b128 per wave and k-tile.  variant 3 text: every phase is
+// {ds_reads of the quadrant; s_barrier; 16 MFMAs; s_barrier}, and the waves of the lower half of the tile (wr == 1, the
+// second wave of every SIMD) run one barrier late, so on each SIMD one wave reads LDS while the other feeds the MFMA
+// pipe.  DMA issue points are moved later accordingly (a group is re-staged >= 2 phases after its last reader).
+__global__ __launch_bounds__(512, 1) void gemm256_reuse_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                                 bf16* __restrict__ C, int M, int N, int K, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef ImgNT<bf16> Img;
+  constexpr int STAGE = 512 * 128;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 2, wc = wave & 3;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wr_u = __builtin_amdgcn_readfirstlane(wr);
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int ch = nt_dma_chunk(t & 255);
+  const bf16* pa[4];
+  const bf16* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (t >> 3) + 64 * i;
+    pa[i] = A + (int64_t)(m0 + row) * K + ch * 8;
+    pb[i] = B + (int64_t)(n0 + row) * K + ch * 8;
+  }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto issueA = [&](int kt, int buf, int g) { glds16(pa[g] + kt * 64, smem + buf * STAGE + (64 * g + 8 * wave_u) * 128); };
+  auto issueB = [&](int kt, int buf, int g) { glds16(pb[g] + kt * 64, smem + buf * STAGE + 256 * 128 + (64 * g + 8 * wave_u) * 128); };
+  const int ktiles = K / 64;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { issueA(0, 0, g); issueB(0, 0, g); }
+  if (ktiles > 1) { issueA(1, 1, 0); issueA(1, 1, 2); wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+  __builtin_amdgcn_s_barrier();
+  if (wr_u == 1) __builtin_amdgcn_s_barrier();      // stagger: the second wave of every SIMD runs one barrier late
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int b = kt & 1, nb = b ^ 1;
+    const char* cur = smem + b * STAGE;
+    const char* At = cur + (wr * 128) * 128;
+    const char* Bt = cur + 256 * 128 + (wc * 64) * 128;
+    Img::Frag fa[2][4], fb[2][2];
+    auto loadA = [&](int rh) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[kk][i] = Img::frag(At + (rh * 64) * 128, i * 16, kk, lane);
+    };
+    auto loadB = [&](int chh) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[kk][j] = Img::frag(Bt + (chh * 32) * 128, j * 16, kk, lane);
+    };
+    auto mma = [&](int rh, int chh) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[rh * 4 + i][chh * 2 + j] = mfma16(fb[kk][j], fa[kk][i], acc[rh * 4 + i][chh * 2 + j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    };
+    const bool n1 = kt + 1 < ktiles, n2 = kt + 2 < ktiles;
+    loadB(0); loadA(0); mma(0, 0);
+    if (n1) { issueA(kt + 1, nb, 1); issueA(kt + 1, nb, 3); issueB(kt + 1, nb, 0); issueB(kt + 1, nb, 1); issueB(kt + 1, nb, 2); issueB(kt + 1, nb, 3); }
+    loadB(1); mma(0, 1);
+    loadA(1); mma(1, 1);
+    wait_vmcnt<0>();                       // the next tile (and, long ago, its A groups 0/2) has landed for this wave
+    if (n2) { issueA(kt + 2, b, 0); issueA(kt + 2, b, 2); }
+    loadB(0); mma(1, 0);
+  }
+  if (wr_u == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+      const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      *(uint2*)(C + (int64_t)m * N + n) = make_uint2(Vec16<bf16>::pk(acc[i][j][0], acc[i][j][1]), Vec16<bf16>::pk(acc[i][j][2], acc[i][j][3]));
+    }
+}
+
+// variant 5 = variant 4 with the LDS reads retired BEFORE the mid-phase barrier (so a group may be re-staged one phase
+// after its last reader), DMA issue spread over phases 0-2 (4 + 2 + 2 per thread) and one counted vmcnt(2) per k-tile.
+// variant 4 = variant 3 + fragment reuse across phases (A sub-tile kept for two phases, B sub-tile for two): 28
+// instead of 48 ds_read_b128 per wave and k-tile.  variant 3 text: every phase is
+// {ds_reads of the quadrant; s_barrier; 16 MFMAs; s_barrier}, and the waves of the lower half of the tile (wr == 1, the
+// second wave of every SIMD) run one barrier late, so on each SIMD one wave reads LDS while the other feeds the MFMA
+// pipe.  DMA issue points are moved later accordingly (a group is re-staged >= 2 phases after its last reader).
+__global__ __launch_bounds__(512, 1) void gemm256_v5_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                                 bf16* __restrict__ C, int M, int N, int K, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef ImgNT<bf16> Img;
+  constexpr int STAGE = 512 * 128;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 2, wc = wave & 3;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wr_u = __builtin_amdgcn_readfirstlane(wr);
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int ch = nt_dma_chunk(t & 255);
+  const bf16* pa[4];
+  const bf16* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (t >> 3) + 64 * i;
+    pa[i] = A + (int64_t)(m0 + row) * K + ch * 8;
+    pb[i] = B + (int64_t)(n0 + row) * K + ch * 8;
+  }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto issueA = [&](int kt, int buf, int g) { glds16(pa[g] + kt * 64, smem + buf * STAGE + (64 * g + 8 * wave_u) * 128); };
+  auto issueB = [&](int kt, int buf, int g) { glds16(pb[g] + kt * 64, smem + buf * STAGE + 256 * 128 + (64 * g + 8 * wave_u) * 128); };
+  const int ktiles = K / 64;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { issueA(0, 0, g); issueB(0, 0, g); }
+  if (ktiles > 1) { issueA(1, 1, 0); issueA(1, 1, 2); wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+  __builtin_amdgcn_s_barrier();
+  if (wr_u == 1) __builtin_amdgcn_s_barrier();      // stagger: the second wave of every SIMD runs one barrier late
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int b = kt & 1, nb = b ^ 1;
+    const char* cur = smem + b * STAGE;
+    const char* At = cur + (wr * 128) * 128;
+    const char* Bt = cur + 256 * 128 + (wc * 64) * 128;
+    Img::Frag fa[2][4], fb[2][2];
+    auto loadA = [&](int rh) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[kk][i] = Img::frag(At + (rh * 64) * 128, i * 16, kk, lane);
+    };
+    auto loadB = [&](int chh) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[kk][j] = Img::frag(Bt + (chh * 32) * 128, j * 16, kk, lane);
+    };
+    auto mma = [&](int rh, int chh) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[rh * 4 + i][chh * 2 + j] = mfma16(fb[kk][j], fa[kk][i], acc[rh * 4 + i][chh * 2 + j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    };
+    const bool n1 = kt + 1 < ktiles, n2 = kt + 2 < ktiles;
+    if (n1) { issueA(kt + 1, nb, 1); issueA(kt + 1, nb, 3); issueB(kt + 1, nb, 0); issueB(kt + 1, nb, 1); }
+    loadB(0); loadA(0); mma(0, 0);
+    if (n1) { issueB(kt + 1, nb, 2); issueB(kt + 1, nb, 3); }
+    loadB(1); mma(0, 1);
+    if (n2) { issueA(kt + 2, b, 0); issueA(kt + 2, b, 2); }
+    loadA(1); mma(1, 1);
+    if (n2) wait_vmcnt<2>(); else wait_vmcnt<0>();   // the next tile has landed for this wave (A 0/2 of the one after may fly)
+    loadB(0); mma(1, 0);
+  }
+  if (wr_u == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+      const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      *(uint2*)(C + (int64_t)m * N + n) = make_uint2(Vec16<bf16>::pk(acc[i][j][0], acc[i][j][1]), Vec16<bf16>::pk(acc[i][j][2], acc[i][j][3]));
+    }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
@@ -123,13 +467,21 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dB, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
   CK(hipFuncSetAttribute((const void*)gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute((const void*)gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)gemm256_v5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)gemm256_reuse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)gemm256_stagger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)gemm256_phase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int variant = argc > 4 ? atoi(argv[4]) : 0;
   const int tiles_m = M / 256, tiles_n = N / 256;
   const size_t smem = 2 * 512 * 128;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if (variant == 1) gemm256_kernel<1><<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
+    if (variant == 5) gemm256_v5_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
+    else if (variant == 4) gemm256_reuse_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
+    else if (variant == 3) gemm256_stagger_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
+    else if (variant == 2) gemm256_phase_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
+    else if (variant == 1) gemm256_kernel<1><<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
     else gemm256_kernel<0><<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
   };
   for (int i = 0; i < 3; ++i) launch();
