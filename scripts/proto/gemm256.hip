@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 #include "gemm_core.h"
@@ -449,6 +450,204 @@ __global__ __launch_bounds__(512, 1) void gemm256_v5_kernel(const bf16* __restri
     }
 }
 
+// variant 6: software-pipelined fragments, ONE barrier per k-tile.  Four fragment register sets (A rows 0-63 / 64-127
+// of the wave's 128, B columns 0-31 / 32-63 of its 64; 96 VGPRs) are refilled while the previous quadrant's 16 MFMAs
+// run; the k-tile hand-over (all reads of this buffer retired, next tile landed, barrier) sits between quadrants 2 and 3,
+// the DMA of the tile after next goes into the just-freed buffer right after it (four phases of flight time).
+__global__ __launch_bounds__(512, 1) void gemm256_v6_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                            bf16* __restrict__ C, int M, int N, int K, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef ImgNT<bf16> Img;
+  constexpr int STAGE = 512 * 128;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 2, wc = wave & 3;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int ch = nt_dma_chunk(t & 255);
+  const bf16* pa[4];
+  const bf16* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (t >> 3) + 64 * i;
+    pa[i] = A + (int64_t)(m0 + row) * K + ch * 8;
+    pb[i] = B + (int64_t)(n0 + row) * K + ch * 8;
+  }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto issue_tile = [&](int kt, int buf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      glds16(pa[g] + kt * 64, smem + buf * STAGE + (64 * g + 8 * wave_u) * 128);
+      glds16(pb[g] + kt * 64, smem + buf * STAGE + 256 * 128 + (64 * g + 8 * wave_u) * 128);
+    }
+  };
+  Img::Frag fa[2][2][4], fb[2][2][2];      // [set][kk][frag]
+  auto loadA = [&](int set, int buf, int rh) {
+    const char* At = smem + buf * STAGE + (wr * 128 + rh * 64) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[set][kk][i] = Img::frag(At, i * 16, kk, lane);
+  };
+  auto loadB = [&](int set, int buf, int chh) {
+    const char* Bt = smem + buf * STAGE + 256 * 128 + (wc * 64 + chh * 32) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[set][kk][j] = Img::frag(Bt, j * 16, kk, lane);
+  };
+  auto mma = [&](int as, int bs, int rh, int chh) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[rh * 4 + i][chh * 2 + j] = mfma16(fb[bs][kk][j], fa[as][kk][i], acc[rh * 4 + i][chh * 2 + j]);
+  };
+  const int ktiles = K / 64;      // even
+  issue_tile(0, 0);
+  if (ktiles > 1) issue_tile(1, 1);
+  if (ktiles > 1) wait_vmcnt<8>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  loadA(0, 0, 0);
+  loadB(0, 0, 0);
+  // one k-tile; BS = register set holding B columns 0-31 of this tile (alternates between tiles)
+  auto tile = [&](int kt, auto bs_tag) {
+    constexpr int BS = decltype(bs_tag)::value;
+    const int b = kt & 1, nb = b ^ 1;
+    loadB(BS ^ 1, b, 1);
+    mma(0, BS, 0, 0);
+    loadA(1, b, 1);
+    mma(0, BS ^ 1, 0, 1);
+    loadB(BS, b, 0);
+    mma(1, BS ^ 1, 1, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of buffer b are retired
+    wait_vmcnt<0>();                                        // tile kt+1 (issued four quadrants ago) has landed
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < ktiles) issue_tile(kt + 2, b);
+    if (kt + 1 < ktiles) { loadA(0, nb, 0); loadB(BS ^ 1, nb, 0); }
+    mma(1, BS, 1, 0);
+  };
+  for (int kt = 0; kt < ktiles; kt += 2) {
+    tile(kt, std::integral_constant<int, 0>{});
+    tile(kt + 1, std::integral_constant<int, 1>{});
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+      const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      *(uint2*)(C + (int64_t)m * N + n) = make_uint2(Vec16<bf16>::pk(acc[i][j][0], acc[i][j][1]), Vec16<bf16>::pk(acc[i][j][2], acc[i][j][3]));
+    }
+}
+
+// variant 7 = variant 6 with SGPR-base + 32-bit-offset DMA addressing (two VGPRs of address state instead of 16).
+// variant 6: software-pipelined fragments, ONE barrier per k-tile.  Four fragment register sets (A rows 0-63 / 64-127
+// of the wave's 128, B columns 0-31 / 32-63 of its 64; 96 VGPRs) are refilled while the previous quadrant's 16 MFMAs
+// run; the k-tile hand-over (all reads of this buffer retired, next tile landed, barrier) sits between quadrants 2 and 3,
+// the DMA of the tile after next goes into the just-freed buffer right after it (four phases of flight time).
+__global__ __launch_bounds__(512, 1) void gemm256_v7_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                            bf16* __restrict__ C, int M, int N, int K, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef ImgNT<bf16> Img;
+  constexpr int STAGE = 512 * 128;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wr = wave >> 2, wc = wave & 3;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int ch = nt_dma_chunk(t & 255);
+  const unsigned voffA = (unsigned)(((t >> 3) * K + ch * 8) * 2);     // byte offset of this thread's chunk inside a 64-row group
+  const char* baseA = (const char*)(A + (int64_t)m0 * K);
+  const char* baseB = (const char*)(B + (int64_t)n0 * K);
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto dma = [&](const char* sbase, char* lds) {      // global_load_lds with a scalar base and a 32-bit per-lane offset
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voffA), "s"(sbase), "s"(dst)
+                 : "memory");
+  };
+  auto issue_tile = [&](int kt, int buf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      dma(baseA + ((int64_t)64 * g * K + kt * 64) * 2, smem + buf * STAGE + (64 * g + 8 * wave_u) * 128);
+      dma(baseB + ((int64_t)64 * g * K + kt * 64) * 2, smem + buf * STAGE + 256 * 128 + (64 * g + 8 * wave_u) * 128);
+    }
+  };
+  Img::Frag fa[2][2][4], fb[2][2][2];      // [set][kk][frag]
+  auto loadA = [&](int set, int buf, int rh) {
+    const char* At = smem + buf * STAGE + (wr * 128 + rh * 64) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[set][kk][i] = Img::frag(At, i * 16, kk, lane);
+  };
+  auto loadB = [&](int set, int buf, int chh) {
+    const char* Bt = smem + buf * STAGE + 256 * 128 + (wc * 64 + chh * 32) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[set][kk][j] = Img::frag(Bt, j * 16, kk, lane);
+  };
+  auto mma = [&](int as, int bs, int rh, int chh) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[rh * 4 + i][chh * 2 + j] = mfma16(fb[bs][kk][j], fa[as][kk][i], acc[rh * 4 + i][chh * 2 + j]);
+  };
+  const int ktiles = K / 64;      // even
+  issue_tile(0, 0);
+  if (ktiles > 1) issue_tile(1, 1);
+  if (ktiles > 1) wait_vmcnt<8>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  loadA(0, 0, 0);
+  loadB(0, 0, 0);
+  // one k-tile; BS = register set holding B columns 0-31 of this tile (alternates between tiles)
+  auto tile = [&](int kt, auto bs_tag) {
+    constexpr int BS = decltype(bs_tag)::value;
+    const int b = kt & 1, nb = b ^ 1;
+    loadB(BS ^ 1, b, 1);
+    mma(0, BS, 0, 0);
+    loadA(1, b, 1);
+    mma(0, BS ^ 1, 0, 1);
+    loadB(BS, b, 0);
+    mma(1, BS ^ 1, 1, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of buffer b are retired
+    wait_vmcnt<0>();                                        // tile kt+1 (issued four quadrants ago) has landed
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < ktiles) issue_tile(kt + 2, b);
+    if (kt + 1 < ktiles) { loadA(0, nb, 0); loadB(BS ^ 1, nb, 0); }
+    mma(1, BS, 1, 0);
+  };
+  for (int kt = 0; kt < ktiles; kt += 2) {
+    tile(kt, std::integral_constant<int, 0>{});
+    tile(kt + 1, std::integral_constant<int, 1>{});
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+      const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+      *(uint2*)(C + (int64_t)m * N + n) = make_uint2(Vec16<bf16>::pk(acc[i][j][0], acc[i][j][1]), Vec16<bf16>::pk(acc[i][j][2], acc[i][j][3]));
+    }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
@@ -467,6 +666,8 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dB, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
   CK(hipFuncSetAttribute((const void*)gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute((const void*)gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)gemm256_v7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void*)gemm256_v6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute((const void*)gemm256_v5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute((const void*)gemm256_reuse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute((const void*)gemm256_stagger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -477,7 +678,9 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&]() {
-    if (variant == 5) gemm256_v5_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
+    if (variant == 7) gemm256_v7_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
+    else if (variant == 6) gemm256_v6_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
+    else if (variant == 5) gemm256_v5_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
     else if (variant == 4) gemm256_reuse_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
     else if (variant == 3) gemm256_stagger_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
     else if (variant == 2) gemm256_phase_kernel<<<tiles_m * tiles_n, 512, smem>>>(dA, dB, dC, M, N, K, tiles_n);
