@@ -179,13 +179,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                                                        int64_t gs, int relu) {
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
+  const bool pow2 = (cprw & (cprw - 1)) == 0;
   const float* sc = stats + z * stats_gs + 2 * C;
   const float* sh = sc + C;
   const T* yy = y + z * gs;
   const T* rr = residual ? residual + z * gs : nullptr;
   T* oo = out + z * gs;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cprw) * VEC;
+    const int c0 = (pow2 ? (int)(i & (cprw - 1)) : (int)(i % cprw)) * VEC;   // 64-bit modulo only when needed
     float v[VEC], r[VEC];
     Vec16<T>::unpack(*(const uint4*)(yy + i * VEC), v);
     if (rr) Vec16<T>::unpack(*(const uint4*)(rr + i * VEC), r);
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            int64_t stats_gs, int mask_from_y) {
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
+  const bool pow2 = (cprw & (cprw - 1)) == 0;
   const float* sc = stats + z * stats_gs + 2 * C;
   const float* sh = sc + C;
   const float* k1 = coef + z * coef_gs;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   T* oo = dy + z * gs;
   T* go = gout ? gout + z * gs : nullptr;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cprw) * VEC;
+    const int c0 = (pow2 ? (int)(i & (cprw - 1)) : (int)(i % cprw)) * VEC;   // 64-bit modulo only when needed
     float d[VEC], m[VEC], v[VEC];
     Vec16<T>::unpack(*(const uint4*)(dd + i * VEC), d);
     Vec16<T>::unpack(*(const uint4*)(yy + i * VEC), v);
