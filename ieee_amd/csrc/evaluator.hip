@@ -90,7 +90,8 @@ __global__ void rownorm_kernel(const T* x, int64_t rows, int d, int metric, floa
 }
 
 // ---------------------------------------------------------------- CMC / mAP
-constexpr int RANK_CAP = 2048;   // match keys sorted per batch (LDS)
+constexpr int RANK_CAP = 1024;    // match keys sorted per batch (LDS)
+constexpr int RANK_CELLS = 2048;  // distance cells over the batch's match range
 
 __device__ __forceinline__ uint64_t make_key(float d, uint32_t idx) {
   uint32_t u = __float_as_uint(d);
@@ -122,18 +123,221 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* wsum, 
   return base + inc - v;
 }
 
+// Cell of a distance on the uniform grid laid over [dmin, dmax] of a batch's sorted match keys.  Every step
+// (subtract a constant, multiply by a non-negative constant, min, truncate) is monotone under rounding, so
+// a < b implies cell(a) <= cell(b): keys in lower cells are smaller, keys in higher cells are larger, and only
+// the keys sharing the element's cell have to be compared.
+__device__ __forceinline__ uint32_t rank_cell(float d, float dmin, float scale) {
+  return (uint32_t)(int)fminf((d - dmin) * scale, (float)(RANK_CELLS - 1));   // NaN -> last cell
+}
+
+__device__ __forceinline__ float key_dist(uint64_t key) {
+  uint32_t u = (uint32_t)(key >> 32);
+  u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+  return __uint_as_float(u);
+}
+
+// The common case of the evaluator, one workgroup per query: at most RANK_CAP true matches and at most RANK_CAP
+// removed entries (same identity, same camera).  No sort of the gallery row and no identity lookups while it is
+// streamed: the matches are sorted in LDS, a grid of RANK_CELLS cells over their distance range maps a streamed
+// distance to the few match keys it has to be compared with (usually none), every element adds 1 to
+// hist[slot], slot = 1 + cell + #{match keys < key} being monotone in the key, the removed entries are then
+// subtracted from the slots they were counted in, and the rank of match i is the inclusive prefix sum at
+// 1 + cell_i + i.  A query that does not fit writes first_out = -2 and is left to rank_query_kernel.
+__global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distmat, int64_t ldd, int num_g,
+                                                              const int32_t* q_pids, const int32_t* g_pids,
+                                                              const int32_t* q_camids, const int32_t* g_camids,
+                                                              double* ap_out, int32_t* first_out) {
+  constexpr int HIST = RANK_CELLS + RANK_CAP + 2;
+  __shared__ uint64_t keys[RANK_CAP];
+  __shared__ uint32_t removed[RANK_CAP];
+  __shared__ uint32_t hist[HIST + 512];          // slack: the scan reads whole per-thread spans
+  __shared__ uint32_t cellinfo[RANK_CELLS];      // first key index of the cell | keys in the cell << 16
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t counts[2];
+  __shared__ double dsum[256];
+  __shared__ int32_t imin[256];
+
+  const int q = blockIdx.x, t = threadIdx.x;
+  const float* row = distmat + (int64_t)q * ldd;
+  const int32_t qpid = q_pids[q], qcam = q_camids[q];
+  if (t < 2) counts[t] = 0;
+  __syncthreads();
+  // ---- collect the matches (as sort keys) and the removed entries (as gallery indices); any order
+  auto collect = [&](int32_t pid, int j) {
+    if (pid != qpid) return;
+    if (g_camids[j] != qcam) {
+      const uint32_t pos = atomicAdd(&counts[0], 1u);
+      if (pos < (uint32_t)RANK_CAP) keys[pos] = make_key(row[j], (uint32_t)j);
+    } else {
+      const uint32_t pos = atomicAdd(&counts[1], 1u);
+      if (pos < (uint32_t)RANK_CAP) removed[pos] = (uint32_t)j;
+    }
+  };
+  {
+    int j = 0;
+    for (; ((uintptr_t)g_pids & 15) == 0 && j + 1024 <= num_g; j += 1024) {
+      const int4 p4 = *(const int4*)(g_pids + j + t * 4);
+      collect(p4.x, j + t * 4);
+      collect(p4.y, j + t * 4 + 1);
+      collect(p4.z, j + t * 4 + 2);
+      collect(p4.w, j + t * 4 + 3);
+    }
+    for (j += t; j < num_g; j += 256) collect(g_pids[j], j);
+  }
+  __syncthreads();
+  const uint32_t nb = counts[0], nr = counts[1];
+  if (nb > (uint32_t)RANK_CAP || nr > (uint32_t)RANK_CAP) {
+    if (t == 0) first_out[q] = -2;
+    return;
+  }
+  if (nb == 0) {
+    if (t == 0) { ap_out[q] = -1.0; first_out[q] = -1; }   // rank.py:140-142: no valid match, query skipped
+    return;
+  }
+  // ---- bitonic sort of keys[0..np2) ascending, padded with +inf keys
+  uint32_t np2 = 1;
+  while (np2 < nb) np2 <<= 1;
+  for (uint32_t i = nb + t; i < np2; i += 256) keys[i] = ~0ull;
+  const uint32_t hlen = RANK_CELLS + nb + 2;
+  for (uint32_t i = t; i < hlen + 512; i += 256) hist[i] = 0;
+  for (uint32_t i = t; i < RANK_CELLS; i += 256) cellinfo[i] = 0;
+  __syncthreads();
+  for (uint32_t k = 2; k <= np2; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = t; i < np2; i += 256) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const uint64_t a = keys[i], b = keys[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const float dmin = key_dist(keys[0]), dmax = key_dist(keys[nb - 1]);
+  float scale = (float)RANK_CELLS / (dmax - dmin);
+  if (!(scale < 1e30f)) scale = 0.f;             // one distinct distance (or inf/NaN): a single cell
+  for (uint32_t i = t; i < nb; i += 256) atomicAdd(&cellinfo[rank_cell(key_dist(keys[i]), dmin, scale)], 1u);
+  __syncthreads();
+  {
+    constexpr int PER = RANK_CELLS / 256;
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) { c[e] = cellinfo[t * PER + e]; sum += c[e]; }
+    uint32_t tot;
+    uint32_t run = block_scan_excl(sum, wsum, &tot);
+#pragma unroll
+    for (int e = 0; e < PER; ++e) { cellinfo[t * PER + e] = run | (c[e] << 16); run += c[e]; }
+  }
+  __syncthreads();
+  // slot of an element, or -1 when it lies after every match (no rank depends on it).  Float compares decide
+  // whenever they can (d > dmax, d < dmin, a cell without keys); only elements that share a cell with match keys
+  // build the 64-bit (distance, index) key.  NaN distances go last, as in numpy's argsort.
+  auto slot_of = [&](float d, int k) -> int {
+    if (d > dmax) return -1;
+    if (d < dmin) return 0;
+    const uint32_t c = rank_cell(d, dmin, scale);
+    const uint32_t ci = cellinfo[c];
+    uint32_t lo = ci & 0xffffu;
+    if (ci >> 16) {
+      const uint64_t key = make_key(d, (uint32_t)k);
+      uint32_t hi = lo + (ci >> 16);             // lower_bound among the keys of this cell
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+      }
+    }
+    return (int)(1 + c + lo);
+  };
+  uint32_t below = 0;
+  auto visit = [&](float d, int k) {
+    const int sl = slot_of(d, k);
+    if (sl > 0) atomicAdd(&hist[sl], 1u);
+    else if (sl == 0) ++below;
+  };
+  // ---- stream the row: 4 independent 16-byte loads per thread in flight before any is used
+  constexpr int UNR = 4;
+  int kdone = 0;
+  if (((uintptr_t)row & 15) == 0) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (; kdone + UNR * 1024 <= num_g; kdone += UNR * 1024) {
+      f32x4 d4[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) d4[u] = __builtin_nontemporal_load((const f32x4*)(row + kdone + u * 1024 + t * 4));
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int k = kdone + u * 1024 + t * 4;
+        visit(d4[u].x, k);
+        visit(d4[u].y, k + 1);
+        visit(d4[u].z, k + 2);
+        visit(d4[u].w, k + 3);
+      }
+    }
+  }
+  for (int k = kdone + t; k < num_g; k += 256) visit(row[k], k);
+  if (below) atomicAdd(&hist[0], below);
+  __syncthreads();
+  // ---- take the removed entries (rank.py:136-137) out of the slots the stream counted them in
+  for (uint32_t i = t; i < nr; i += 256) {
+    const int k = (int)removed[i];
+    const int sl = slot_of(row[k], k);
+    if (sl >= 0) atomicSub(&hist[sl], 1u);
+  }
+  __syncthreads();
+  // ---- inclusive prefix sums over hist in place: a contiguous odd-length span per thread (conflict-free)
+  {
+    const uint32_t per = ((hlen + 255) / 256) | 1u;
+    uint32_t sum = 0;
+    for (uint32_t e = 0; e < per; ++e) sum += hist[t * per + e];
+    uint32_t tot;
+    uint32_t run = block_scan_excl(sum, wsum, &tot);
+    for (uint32_t e = 0; e < per; ++e) { run += hist[t * per + e]; hist[t * per + e] = run; }
+  }
+  __syncthreads();
+  double part = 0.0;
+  int32_t fmin = 0x7fffffff;
+  for (uint32_t i = t; i < nb; i += 256) {
+    const uint32_t c = rank_cell(key_dist(keys[i]), dmin, scale);
+    const uint32_t rank = hist[1 + c + i] - 1;         // 0-based position among kept (itself is counted)
+    part += (double)(i + 1) / (double)(rank + 1);      // rank.py:156-157; i matches precede match i
+    fmin = min(fmin, (int32_t)rank);
+  }
+  dsum[t] = part;
+  imin[t] = fmin;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { dsum[t] += dsum[t + o]; imin[t] = min(imin[t], imin[t + o]); }
+    __syncthreads();
+  }
+  if (t == 0) {
+    ap_out[q] = dsum[0] / (double)nb;                  // rank.py:153-158
+    first_out[q] = imin[0];
+  }
+}
+
+// The general case (any number of matches, in batches of RANK_CAP): launched after rank_query_fast_kernel, works
+// only on the queries that kernel flagged with first_out = -2.
+// One workgroup per query.  No sort of the gallery row: the (few) true matches are sorted in LDS, a grid of
+// RANK_CELLS cells over their distance range maps a streamed distance to the handful of match keys it has to be
+// compared with (usually none), and every kept element adds 1 to hist[1 + cell + #{batch keys < key}] -- an index
+// that is monotone in the key -- so the rank of match i is the inclusive prefix sum at 1 + cell_i + i.
 __global__ __launch_bounds__(256) void rank_query_kernel(const float* distmat, int64_t ldd, int num_g,
                                                          const int32_t* q_pids, const int32_t* g_pids,
                                                          const int32_t* q_camids, const int32_t* g_camids,
-                                                         double* ap_out, int32_t* first_out) {
+                                                         double* ap_out, int32_t* first_out, int only_flagged) {
+  constexpr int HIST = RANK_CELLS + RANK_CAP + 2;
   __shared__ uint64_t keys[RANK_CAP];
-  __shared__ uint32_t hist[RANK_CAP + 1];
+  __shared__ uint32_t hist[HIST + 512];          // slack: the scan reads whole per-thread spans
   __shared__ uint32_t histm[RANK_CAP + 1];
+  __shared__ uint32_t cellinfo[RANK_CELLS];      // first key index of the cell | keys in the cell << 16
   __shared__ uint32_t wsum[4];
   __shared__ double dsum[256];
   __shared__ int32_t imin[256];
 
   const int q = blockIdx.x, t = threadIdx.x;
+  if (only_flagged && first_out[q] != -2) return;
   const float* row = distmat + (int64_t)q * ldd;
   const int32_t qpid = q_pids[q], qcam = q_camids[q];
 
@@ -146,15 +350,30 @@ __global__ __launch_bounds__(256) void rank_query_kernel(const float* distmat, i
     // ---- collect up to RANK_CAP matches (same pid, different camera) in gallery-index order
     uint32_t nb = 0;
     int base = jstart;
+    const bool vec_ok = (((uintptr_t)row | (uintptr_t)g_pids) & 15) == 0;
     while (base < num_g) {
-      const int j = base + t;
-      const bool is = j < num_g && g_pids[j] == qpid && g_camids[j] != qcam;
+      // 4 consecutive gallery entries per thread, one block scan per 1024 (= RANK_CAP, so a chunk always fits)
+      const int j0 = base + t * 4;
+      int32_t pv[4];
+      if (vec_ok && j0 + 3 < num_g) {
+        const int4 p4 = *(const int4*)(g_pids + j0);
+        pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[e] = j0 + e < num_g ? g_pids[j0 + e] : (qpid ^ 0x40000000);
+      }
+      uint32_t mask = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (pv[e] == qpid && g_camids[j0 + e] != qcam) mask |= 1u << e;
       uint32_t tot;
-      const uint32_t pos = block_scan_excl(is ? 1u : 0u, wsum, &tot);
+      uint32_t pos = nb + block_scan_excl(__popc(mask), wsum, &tot);
       if (nb + tot > (uint32_t)RANK_CAP) break;   // uniform: leave this chunk for the next batch
-      if (is) keys[nb + pos] = make_key(row[j], (uint32_t)j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (mask & (1u << e)) keys[pos++] = make_key(row[j0 + e], (uint32_t)(j0 + e));
       nb += tot;
-      base += 256;
+      base += 1024;
     }
     jstart = base;
     if (nb == 0) continue;   // (jstart advanced to num_g) no match in the remainder
@@ -162,7 +381,10 @@ __global__ __launch_bounds__(256) void rank_query_kernel(const float* distmat, i
     uint32_t np2 = 1;
     while (np2 < nb) np2 <<= 1;
     for (uint32_t i = nb + t; i < np2; i += 256) keys[i] = ~0ull;
-    for (uint32_t i = t; i <= nb; i += 256) { hist[i] = 0; histm[i] = 0; }
+    const uint32_t hlen = RANK_CELLS + nb + 2;
+    for (uint32_t i = t; i < hlen + 512; i += 256) hist[i] = 0;
+    for (uint32_t i = t; i <= nb; i += 256) histm[i] = 0;
+    for (uint32_t i = t; i < RANK_CELLS; i += 256) cellinfo[i] = 0;
     __syncthreads();
     for (uint32_t k = 2; k <= np2; k <<= 1) {
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -177,62 +399,101 @@ __global__ __launch_bounds__(256) void rank_query_kernel(const float* distmat, i
         __syncthreads();
       }
     }
-    const uint64_t kmax = keys[nb - 1];
-    // ---- stream the row: for every kept element, idx = #{batch keys < key}; it precedes
-    //      batch matches idx..nb-1, so hist[idx]++ and ranks are prefix sums of hist.
-    for (int k0 = t * 4; k0 < num_g; k0 += 1024) {
-      float dv[4];
-      int32_t pv[4];
-      if (k0 + 3 < num_g && ((ldd & 3) == 0)) {
-        const float4 d4 = *(const float4*)(row + k0);
-        const int4 p4 = *(const int4*)(g_pids + k0);
-        dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
-        pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
-      } else {
+    const uint64_t kmin = keys[0], kmax = keys[nb - 1];
+    const float dmin = key_dist(kmin);
+    float scale = (float)RANK_CELLS / (key_dist(kmax) - dmin);
+    if (!(scale < 1e30f)) scale = 0.f;             // one distinct distance (or inf/NaN): a single cell
+    // ---- the cell table: count the keys of every cell, then an exclusive scan gives the first key of each
+    for (uint32_t i = t; i < nb; i += 256) atomicAdd(&cellinfo[rank_cell(key_dist(keys[i]), dmin, scale)], 1u);
+    __syncthreads();
+    {
+      constexpr int PER = RANK_CELLS / 256;
+      uint32_t c[PER], s = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dv[e] = k0 + e < num_g ? row[k0 + e] : 0.f;
-          pv[e] = k0 + e < num_g ? g_pids[k0 + e] : (qpid ^ 0x40000000);
-        }
-      }
+      for (int e = 0; e < PER; ++e) { c[e] = cellinfo[t * PER + e]; s += c[e]; }
+      uint32_t tot;
+      uint32_t run = block_scan_excl(s, wsum, &tot);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = k0 + e;
-        if (k >= num_g) continue;
-        bool ism = false;
-        if (pv[e] == qpid) {
-          if (g_camids[k] == qcam) continue;   // removed: same pid & same camera (rank.py:136-137)
-          ism = true;
-        }
-        const uint64_t key = make_key(dv[e], (uint32_t)k);
-        if (key > kmax) continue;
-        uint32_t lo = 0, hi = nb;              // lower_bound: first index with keys[idx] >= key
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (keys[mid] < key) lo = mid + 1; else hi = mid;
-        }
-        atomicAdd(&hist[lo], 1u);
-        if (ism) atomicAdd(&histm[lo], 1u);
-      }
+      for (int e = 0; e < PER; ++e) { cellinfo[t * PER + e] = run | (c[e] << 16); run += c[e]; }
     }
     __syncthreads();
-    // ---- inclusive prefix sums over hist / histm (chunks of 256 with a running carry)
-    uint32_t carry_h = 0, carry_m = 0;
+    // ---- stream the row
+    uint32_t below = 0;                            // elements before the first match: all land in hist[0]
+    auto visit = [&](float d, int32_t pid, int k) {
+      bool ism = false;
+      if (pid == qpid) {
+        if (g_camids[k] == qcam) return;       // removed: same pid & same camera (rank.py:136-137)
+        ism = true;
+      }
+      const uint64_t key = make_key(d, (uint32_t)k);
+      if (key > kmax) return;                  // after every match of the batch: no rank depends on it
+      if (key < kmin) {
+        ++below;
+        if (ism) atomicAdd(&histm[0], 1u);
+        return;
+      }
+      const uint32_t c = rank_cell(d, dmin, scale);
+      const uint32_t ci = cellinfo[c];
+      uint32_t lo = ci & 0xffffu, hi = lo + (ci >> 16);   // lower_bound among the keys of this cell
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+      }
+      atomicAdd(&hist[1 + c + lo], 1u);
+      if (ism) atomicAdd(&histm[lo], 1u);
+    };
+    // main loop: 4 independent 16-byte loads of distances (and of pids) per thread in flight before any is used
+    constexpr int UNR = 4;
+    int kdone = 0;
+    if (vec_ok) {
+      for (; kdone + UNR * 1024 <= num_g; kdone += UNR * 1024) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 d4[UNR];
+        int4 p4[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          d4[u] = __builtin_nontemporal_load((const f32x4*)(row + kdone + u * 1024 + t * 4));
+          p4[u] = *(const int4*)(g_pids + kdone + u * 1024 + t * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int k = kdone + u * 1024 + t * 4;
+          visit(d4[u].x, p4[u].x, k);
+          visit(d4[u].y, p4[u].y, k + 1);
+          visit(d4[u].z, p4[u].z, k + 2);
+          visit(d4[u].w, p4[u].w, k + 3);
+        }
+      }
+    }
+    for (int k = kdone + t; k < num_g; k += 256) visit(row[k], g_pids[k], k);
+    if (below) atomicAdd(&hist[0], below);
+    __syncthreads();
+    // ---- inclusive prefix sums over hist in place: a contiguous odd-length span per thread (conflict-free)
+    {
+      const uint32_t per = ((hlen + 255) / 256) | 1u;
+      uint32_t s = 0;
+      for (uint32_t e = 0; e < per; ++e) s += hist[t * per + e];
+      uint32_t tot;
+      uint32_t run = block_scan_excl(s, wsum, &tot);
+      for (uint32_t e = 0; e < per; ++e) { run += hist[t * per + e]; hist[t * per + e] = run; }
+    }
+    __syncthreads();
+    // ---- matches-before-it by chunked scans of histm; AP terms in the same order as before
+    uint32_t carry_m = 0;
     double part = 0.0;
     int32_t fmin = 0x7fffffff;
     for (uint32_t c0 = 0; c0 < nb; c0 += 256) {
       const uint32_t i = c0 + t;
-      const uint32_t hv = i < nb ? hist[i] : 0u, mv = i < nb ? histm[i] : 0u;
-      uint32_t th, tmm;
-      const uint32_t eh = block_scan_excl(hv, wsum, &th);
+      const uint32_t mv = i < nb ? histm[i] : 0u;
+      uint32_t tmm;
       const uint32_t em = block_scan_excl(mv, wsum, &tmm);
       if (i < nb) {
-        const uint32_t rank = carry_h + eh + hv - 1;    // 0-based position among kept (itself is in hist[i])
+        const uint32_t c = rank_cell(key_dist(keys[i]), dmin, scale);
+        const uint32_t rank = hist[1 + c + i] - 1;      // 0-based position among kept (itself is counted)
         const uint32_t mrank = carry_m + em + mv - 1;   // matches before it (all batches)
         part += (double)(mrank + 1) / (double)(rank + 1);   // rank.py:156-157
         fmin = min(fmin, (int32_t)rank);
       }
-      carry_h += th;
       carry_m += tmm;
     }
     dsum[t] = part;
@@ -270,11 +531,26 @@ __global__ void rank_finalize_kernel(const double* ap, const int32_t* first, int
   }
   __syncthreads();
   for (int r = t; r < max_rank; r += blockDim.x) summary[r] = (int64_t)cnt[r];
+  // sum of the valid APs in query order (one fixed order: the result does not depend on the launch), staged
+  // through LDS so that the serial adds do not each wait for a global load
+  __shared__ double stage[1024];
+  double s = 0.0;
+  for (int q0 = 0; q0 < num_q; q0 += 1024) {
+    __syncthreads();
+    for (int i = t; i < 1024; i += blockDim.x) stage[i] = (q0 + i < num_q && first[q0 + i] >= 0) ? ap[q0 + i] : 0.0;
+    __syncthreads();
+    if (t == 0) {
+      for (int i = 0; i < 1024; i += 8) {       // skipped queries add +0.0, which leaves the sum unchanged
+        double v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = stage[i + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+      }
+    }
+  }
   if (t == 0) {
     summary[max_rank] = (int64_t)nvalid;
-    double s = 0.0;
-    for (int q = 0; q < num_q; ++q)
-      if (first[q] >= 0) s += ap[q];
     summary[max_rank + 1] = __double_as_longlong(s);
   }
 }
@@ -328,8 +604,12 @@ extern "C" int ieee_rank_market1501(const float* distmat, int64_t ldd, int64_t n
   if (max_rank > num_g) max_rank = num_g;   // rank.py:110-115
   IEEE_REQUIRE(max_rank >= 1 && max_rank <= 1024, "rank: max_rank %ld out of range [1,1024]", (long)max_rank);
   hipStream_t st = (hipStream_t)stream;
+  const bool general_only = getenv("IEEE_RANK_GENERAL") && atoi(getenv("IEEE_RANK_GENERAL")) != 0;   // tests
+  if (!general_only)
+    rank_query_fast_kernel<<<(int)num_q, 256, 0, st>>>(distmat, ldd, (int)num_g, q_pids, g_pids, q_camids, g_camids,
+                                                       ap, first_pos);
   rank_query_kernel<<<(int)num_q, 256, 0, st>>>(distmat, ldd, (int)num_g, q_pids, g_pids, q_camids, g_camids, ap,
-                                                first_pos);
+                                                first_pos, general_only ? 0 : 1);
   rank_finalize_kernel<<<1, 256, 0, st>>>(ap, first_pos, (int)num_q, (int)max_rank, summary);
   return launch_status("rank_market1501");
 }

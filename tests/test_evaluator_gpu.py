@@ -69,8 +69,19 @@ def test_distmat_bf16_inputs():
 CASES = [("A", 5, False), ("B", 20, True), ("C", 20, True), ("D", 20, False), ("E", 20, False)]
 
 
+@pytest.fixture(params=["fast+general", "general-only"])
+def rank_path(request, monkeypatch):
+    """ieee_rank_market1501 runs rank_query_fast_kernel and leaves the queries that do not fit its LDS lists to
+    rank_query_kernel; IEEE_RANK_GENERAL=1 sends every query through the general kernel."""
+    if request.param == "general-only":
+        monkeypatch.setenv("IEEE_RANK_GENERAL", "1")
+    else:
+        monkeypatch.delenv("IEEE_RANK_GENERAL", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("tag,max_rank,tie", CASES)
-def test_rank_matches_reference_golden(G, tag, max_rank, tie):
+def test_rank_matches_reference_golden(G, tag, max_rank, tie, rank_path):
     from ieee_amd.metrics import evaluate_rank
     d = G[tag + "_dist"]
     if tie:
@@ -88,7 +99,7 @@ def test_rank_no_valid_query_raises(G):
 
 
 @pytest.mark.parametrize("nq,ng,nid,seed", [(300, 3000, 150, 0), (64, 10007, 13, 1), (2000, 20000, 1000, 2)])
-def test_rank_vs_oracle_random(nq, ng, nid, seed):
+def test_rank_vs_oracle_random(nq, ng, nid, seed, rank_path):
     from ieee_amd.metrics import evaluate_rank
     rng = np.random.RandomState(seed)
     d = (rng.rand(nq, ng) * 20).astype(np.float32)
@@ -100,7 +111,7 @@ def test_rank_vs_oracle_random(nq, ng, nid, seed):
     assert abs(m_ap - map_o) < 1e-12
 
 
-def test_rank_many_matches_multibatch_and_ties():
+def test_rank_many_matches_multibatch_and_ties(rank_path):
     """one identity owns 5000 gallery rows (> the 2048-key LDS batch) and distances have exact ties
     (tie order = gallery index, the order the oracle's stable sort defines)."""
     from ieee_amd.metrics import evaluate_rank
@@ -114,6 +125,42 @@ def test_rank_many_matches_multibatch_and_ties():
     qc, gc = rng.randint(0, 3, nq), rng.randint(0, 3, ng)
     cmc_o, map_o = ev.rank_market1501_c(d, qp, gp, qc, gc, 20)
     cmc, m_ap = evaluate_rank(d, qp, gp, qc, gc)
+    assert np.array_equal(cmc, cmc_o)
+    assert abs(m_ap - map_o) < 1e-12
+
+
+@pytest.mark.parametrize("case", ["ties", "many_removed", "one_match", "all_equal", "ragged_ld"])
+def test_rank_fast_path_edges(case, rank_path):
+    """edges of the cell-table kernel: exact distance ties between matches and non-matches (order = gallery index),
+    more removed entries than its LDS list holds, a single match (one distance cell), every distance equal, and a
+    row stride that is not a multiple of 4 (scalar loads)."""
+    from ieee_amd.metrics import evaluate_rank
+    rng = np.random.RandomState(21)
+    nq, ng = 48, 6151
+    d = (rng.rand(nq, ng) * 7).astype(np.float32)
+    qp, gp = rng.randint(0, 40, nq), rng.randint(0, 40, ng)
+    qc, gc = rng.randint(0, 3, nq), rng.randint(0, 3, ng)
+    if case == "ties":
+        d = rng.randint(0, 9, size=(nq, ng)).astype(np.float32)
+    elif case == "many_removed":
+        gp[:3000] = 7
+        gc[:2900] = 1
+        qp[:8], qc[:8] = 7, 1
+        rng.shuffle(gp)
+    elif case == "one_match":
+        gp[:] = rng.randint(100, 140, ng)
+        for i in range(nq):
+            gp[i], gc[i], qp[i], qc[i] = 1000 + i, 0, 1000 + i, 1
+    elif case == "all_equal":
+        d[:] = 3.5
+    cmc_o, map_o = ev.rank_market1501_c(d, qp, gp, qc, gc, 20)
+    dd = torch.from_numpy(d).cuda()
+    if case == "ragged_ld":
+        wide = torch.zeros(nq, ng + 3, device="cuda")
+        wide[:, :ng] = dd
+        dd = wide[:, :ng]
+        assert dd.stride(0) % 4 != 0
+    cmc, m_ap = evaluate_rank(dd, qp, gp, qc, gc)
     assert np.array_equal(cmc, cmc_o)
     assert abs(m_ap - map_o) < 1e-12
 
