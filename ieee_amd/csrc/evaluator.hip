@@ -91,7 +91,13 @@ __global__ void rownorm_kernel(const T* x, int64_t rows, int d, int metric, floa
 
 // ---------------------------------------------------------------- CMC / mAP
 constexpr int RANK_CAP = 1024;    // match keys sorted per batch (LDS)
-constexpr int RANK_CELLS = 2048;  // distance cells over the batch's match range
+#ifndef IEEE_RANK_CELLS
+#define IEEE_RANK_CELLS 512
+#endif
+#ifndef IEEE_RANK_UNR
+#define IEEE_RANK_UNR 8
+#endif
+constexpr int RANK_CELLS = IEEE_RANK_CELLS;  // distance cells over the batch's match range
 
 __device__ __forceinline__ uint64_t make_key(float d, uint32_t idx) {
   uint32_t u = __float_as_uint(d);
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distm
     else if (sl == 0) ++below;
   };
   // ---- stream the row: 4 independent 16-byte loads per thread in flight before any is used
-  constexpr int UNR = 4;
+  constexpr int UNR = IEEE_RANK_UNR;
   int kdone = 0;
   if (((uintptr_t)row & 15) == 0) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -514,44 +520,40 @@ __global__ __launch_bounds__(256) void rank_query_kernel(const float* distmat, i
   }
 }
 
-__global__ void rank_finalize_kernel(const double* ap, const int32_t* first, int num_q, int max_rank,
-                                     int64_t* summary) {
-  __shared__ unsigned long long cnt[1024];
-  __shared__ unsigned long long nvalid;
+// summary = [max_rank CMC counts, number of valid queries, bits of the AP sum].  One 256-thread workgroup; the AP
+// sum has one fixed association (a contiguous span per thread, then a binary tree over the threads), so it is the
+// same on every launch.
+__global__ __launch_bounds__(256) void rank_finalize_kernel(const double* ap, const int32_t* first, int num_q,
+                                                            int max_rank, int64_t* summary) {
+  __shared__ uint32_t fh[1024];        // queries whose first match sits at rank r
+  __shared__ double dsum[256];
+  __shared__ uint32_t nsum[256];
   const int t = threadIdx.x;
-  for (int r = t; r < max_rank; r += blockDim.x) cnt[r] = 0;
-  if (t == 0) nvalid = 0;
+  for (int r = t; r < max_rank; r += 256) fh[r] = 0;
   __syncthreads();
-  for (int q = t; q < num_q; q += blockDim.x) {
+  const int per = (num_q + 255) / 256;
+  double s = 0.0;
+  uint32_t nv = 0;
+  for (int q = t * per; q < min(num_q, (t + 1) * per); ++q) {
     const int f = first[q];
     if (f >= 0) {
-      atomicAdd(&nvalid, 1ull);
-      for (int r = f; r < max_rank; ++r) atomicAdd(&cnt[r], 1ull);   // cmc = min(cumsum,1): rank.py:145-150
+      ++nv;
+      s += ap[q];
+      if (f < max_rank) atomicAdd(&fh[f], 1u);
     }
   }
+  dsum[t] = s;
+  nsum[t] = nv;
   __syncthreads();
-  for (int r = t; r < max_rank; r += blockDim.x) summary[r] = (int64_t)cnt[r];
-  // sum of the valid APs in query order (one fixed order: the result does not depend on the launch), staged
-  // through LDS so that the serial adds do not each wait for a global load
-  __shared__ double stage[1024];
-  double s = 0.0;
-  for (int q0 = 0; q0 < num_q; q0 += 1024) {
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { dsum[t] += dsum[t + o]; nsum[t] += nsum[t + o]; }
     __syncthreads();
-    for (int i = t; i < 1024; i += blockDim.x) stage[i] = (q0 + i < num_q && first[q0 + i] >= 0) ? ap[q0 + i] : 0.0;
-    __syncthreads();
-    if (t == 0) {
-      for (int i = 0; i < 1024; i += 8) {       // skipped queries add +0.0, which leaves the sum unchanged
-        double v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = stage[i + e];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[e];
-      }
-    }
   }
   if (t == 0) {
-    summary[max_rank] = (int64_t)nvalid;
-    summary[max_rank + 1] = __double_as_longlong(s);
+    int64_t run = 0;
+    for (int r = 0; r < max_rank; ++r) { run += fh[r]; summary[r] = run; }   // cmc = min(cumsum,1): rank.py:145-150
+    summary[max_rank] = (int64_t)nsum[0];
+    summary[max_rank + 1] = __double_as_longlong(dsum[0]);
   }
 }
 
