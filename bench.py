@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
 TRAIN_GFLOP_PER_TRIPLE = 92.24
 
 
@@ -110,7 +111,29 @@ def bench_distmat(device):
     t0 = time.time()
     cmc, m_ap = evaluate_rank(dm, qp, gp, qc, gc)
     torch.cuda.synchronize()
-    out["rank_ms"] = (time.time() - t0) * 1e3
+    out["rank_ms"] = (time.time() - t0) * 1e3          # wall time of evaluate_rank (id upload + kernels + read-back)
+    # the ranking kernels alone, HIP events on their stream, ids already on the device: HBM-bound (4 B per pair)
+    from ieee_amd import _lib
+    lib = _lib.load()
+    ids = [torch.from_numpy(a.astype(np.int32)).to(device) for a in (qp, gp, qc, gc)]
+    ap_d = torch.empty(Q, dtype=torch.float64, device=device)
+    first_d = torch.empty(Q, dtype=torch.int32, device=device)
+    summ_d = torch.empty(22, dtype=torch.int64, device=device)
+    def rank_call():
+        _lib.check(lib.ieee_rank_market1501(_lib.ptr(dm), dm.stride(0), Q, G, _lib.ptr(ids[0]), _lib.ptr(ids[1]),
+                                            _lib.ptr(ids[2]), _lib.ptr(ids[3]), 20, _lib.ptr(ap_d), _lib.ptr(first_d),
+                                            _lib.ptr(summ_d), _lib.stream()))
+    rank_call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        rank_call()
+    e1.record()
+    torch.cuda.synchronize()
+    rk_ms = e0.elapsed_time(e1) / 5
+    out["rank_kernels_ms"] = rk_ms
+    out["roofline_rank"] = {"bound": "hbm", "achieved": 4.0 * Q * G / rk_ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": 4.0 * Q * G / rk_ms / 1e6 / PEAK_HBM_GBS, "traffic": None}
     out["workload"] = "10000 x 100000 x 768 (BASELINE config 4)"
     out["roofline_fp32"] = {"bound": "mfma", "achieved": out["fp32"]["GFLOP/s"] / 1e3, "peak": PEAK_F32_TFLOPS,
                             "unit": "TFLOP/s", "frac": out["fp32"]["GFLOP/s"] / 1e3 / PEAK_F32_TFLOPS}

@@ -1,7 +1,7 @@
 """CMC / mAP on MI355X.  Mirrors torchreid/metrics/rank.py:246-287 (evaluate_rank ->
 evaluate_py -> eval_market1501 :103-171); the per-query ranking runs in
-ieee_rank_market1501 (no sort: each true match's rank is counted with a
-binary-search histogram over the streamed distance row)."""
+ieee_rank_market1501 (no sort: the true matches are sorted in LDS and each one's
+rank is a prefix sum of a histogram filled while the distance row streams past)."""
 import numpy as np
 import torch
 
