@@ -204,7 +204,6 @@ struct ConvArgs {
   int M, N;          // GEMM rows (pixels) / cols (output channels of this GEMM)
   int ldw, ktiles;   // packed-weight row length (elements), number of k-tiles
   int tiles_m, tiles_n;
-  int dbg;           // tuning experiments only (IEEE_DBG)
   int group;         // m-tiles per group in the grouped tile order
   int64_t src_gs, w_gs, dst_gs;   // per-modality strides (elements)
 };
@@ -250,7 +249,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
       // no pixel decode, no tap masks (their set-up rivals the whole k-loop of the K = 64..256 layers)
       LoaderPlainNT<T, 4> la;
       la.init(src, a.g.Cs, m0, a.g.npix, a.g.Cs, ch);
-      gemm_nt_dma<128, BN, PIPE>(la, lbd, epi, a.ktiles, m0, n0, smem, a.dbg);
+      gemm_nt_dma<128, BN, PIPE>(la, lbd, epi, a.ktiles, m0, n0, smem);
     } else {
       LoaderIm2colNT<T, 4> la;
       la.init(src, a.g, m0, ch);
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
   } else {
     LoaderIm2colNT<T, 4> la;
     la.init(src, a.g, m0);
-    gemm_nt<T, 128, BN, (sizeof(T) == 2 ? 1 : 2)>(la, lb, epi, a.ktiles, m0, n0, smem, a.dbg & 1);
+    gemm_nt<T, 128, BN, (sizeof(T) == 2 ? 1 : 2)>(la, lb, epi, a.ktiles, m0, n0, smem);
   }
   }
 }
@@ -612,7 +611,6 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   a.N = N;
   a.ldw = ldw;
   a.ktiles = cdiv(Ktrue, BK);
-  { const char* e = getenv("IEEE_DBG"); a.dbg = e ? atoi(e) : 0; }
   { static const int grp = getenv("IEEE_TILE_GROUP") ? atoi(getenv("IEEE_TILE_GROUP")) : 8; a.group = grp; }
   a.src_gs = src_gs;
   a.w_gs = w_gs;
@@ -632,7 +630,6 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
     if (smem < epi_bytes) smem = epi_bytes;
     if (smem < red_bytes) smem = red_bytes;
   }
-  if (const char* e = getenv("IEEE_DBG_LDS")) smem = (size_t)atoi(e);   // occupancy experiments
   const bool stats = bn_partial != nullptr;
   if (stats && (slow || sizeof(T) != 2)) {
     set_error(IEEE_ERR_UNSUPPORTED, "conv: fused BN statistics need the bf16 vector path");

@@ -102,7 +102,6 @@ template <> struct ImgTN<float> {
   }
 };
 
-__device__ int g_dbg_nok_dummy;
 // ------------------------------------------------------------------ cores
 // Loader contract:  uint4 load(int slot)  -> 16 bytes of the CURRENT k-tile for
 // this thread's slot (zero-filled when out of range);  void next()  -> advance
@@ -116,7 +115,7 @@ __device__ int g_dbg_nok_dummy;
 // k-tile -- half the LDS, so twice the workgroups per CU; measured faster wherever it was tried (occupancy hides
 // the load latency better than the second buffer does).
 template <typename T, int BM, int BN, int STAGES, class LA, class LB, class Epi>
-__device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem, int g_dbg_nok = 0) {
+__device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem) {
   typedef ImgNT<T> Img;
   constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;
   constexpr int FM = BM / 32, FN = BN / 32;
@@ -146,7 +145,8 @@ __device__ __forceinline__ void gemm_nt(LA& la, LB& lb, Epi& epi, int ktiles, in
     char* nxt = STAGES == 1 ? smem : smem + ((kt + 1) & 1) * STAGE;
     const bool has_next = (kt + 1) < ktiles;
     if (has_next) {
-      if (!g_dbg_nok) { la.next(); lb.next(); }
+      la.next();
+      lb.next();
 #pragma unroll
       for (int i = 0; i < ACH; ++i) ra[i] = la.load(i);
 #pragma unroll
@@ -312,7 +312,7 @@ template <int PER> __device__ __forceinline__ void wait_tiles(int tiles_in_fligh
 }
 
 template <int BM, int BN, int STAGES, class LA, class LB, class Epi>
-__device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem, int dbg = 0) {
+__device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem) {
   typedef ImgNT<bf16> Img;
   constexpr int DMA_STAGES = STAGES;
   constexpr int ACH = BM * 8 / 256, BCH = BN * 8 / 256;
@@ -327,20 +327,12 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int dbg_kt = 0;
   auto issue = [&](int stage_idx) {
     char* stage = smem + stage_idx * STAGE;
-    // tuning experiments (IEEE_DBG): 2 = skip the B operand's loads on odd k-tiles, 4 = skip the A operand's (wrong
-    // results, same structure: shows how much of the k-loop is the per-CU load path)
-    const bool odd = (dbg_kt++ & 1) != 0;
-    if (!((dbg & 4) && odd)) {
 #pragma unroll
-      for (int i = 0; i < ACH; ++i) glds16(la.addr(i), stage + (32 * i + 8 * wave_u) * 128);
-    }
-    if (!((dbg & 2) && odd)) {
+    for (int i = 0; i < ACH; ++i) glds16(la.addr(i), stage + (32 * i + 8 * wave_u) * 128);
 #pragma unroll
-      for (int i = 0; i < BCH; ++i) glds16(lb.addr(i), stage + BM * 128 + (32 * i + 8 * wave_u) * 128);
-    }
+    for (int i = 0; i < BCH; ++i) glds16(lb.addr(i), stage + BM * 128 + (32 * i + 8 * wave_u) * 128);
   };
   auto compute = [&](const char* cur) {
     const char* At = cur + (wm * (BM / 2)) * 128;
