@@ -94,6 +94,21 @@ def bench_distmat(device):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         out[name] = {"ms": ms, "GFLOP/s": 2.0 * Q * G * D / ms / 1e6}
+    # fp32 rows as exact bf16 pieces on the bf16 matrix cores (six piece products: fp32-grade accuracy)
+    for name, prec, terms in (("split_bf16x3", "split6", 6),):
+        compute_distance_matrix(qf, gf, precision=prec)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dm = compute_distance_matrix(qf, gf, precision=prec)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        out[name] = {"ms": ms, "GFLOP/s": 2.0 * Q * G * D / ms / 1e6, "mfma_TFLOP/s": terms * 2.0 * Q * G * D / ms / 1e9,
+                     "mfma_frac_of_bf16_peak": terms * 2.0 * Q * G * D / ms / 1e9 / PEAK_BF16_TFLOPS,
+                     "note": "includes the piece-splitting pre-pass; GFLOP/s counts the 2*Q*G*D of the fp32 problem"}
+    del dm
     # the model's real descriptor width (2304 = 3 x 768, ieee3modalPart.py:502), fp32, smaller gallery
     g2 = torch.Generator(device="cpu").manual_seed(2)
     q3, g3 = torch.randn(10000, 2304, generator=g2).abs().to(device), torch.randn(50000, 2304, generator=g2).abs().to(device)

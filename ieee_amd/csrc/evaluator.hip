@@ -89,6 +89,54 @@ __global__ void rownorm_kernel(const T* x, int64_t rows, int d, int metric, floa
   if (lane == 0) out[row] = metric == 0 ? s : 1.0f / fmaxf(sqrtf(s), 1e-12f);
 }
 
+// ---------------------------------------------------------------- split-bf16 operands
+// An fp32 value is the exact sum of three bf16 pieces (8 + 8 + 8 mantissa bits): hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid); every piece product is exact in the fp32 MFMA accumulator.  q.g is then a bf16 GEMM over
+// a K axis that lists the piece products, smallest first:
+//   6 terms (fp32-grade; drops only the 2^-24-relative mid.lo, lo.mid, lo.lo):  lo.hi  hi.lo  mid.mid  mid.hi  hi.mid  hi.hi
+//   3 terms (two pieces, ~2^-16 relative):                                       lo.hi  hi.lo  hi.hi
+// This kernel writes one operand's row as [terms][d] bf16: side 0 = the query pieces of each term, side 1 = the
+// gallery pieces.
+template <int TERMS>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, bf16* __restrict__ out,
+                                                         int64_t rows, int d, int side) {
+  const int chunks = d / 8;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * chunks) return;
+  const int64_t row = i / chunks;
+  const int k = (int)(i - row * chunks) * 8;
+  const float* p = x + row * d + k;
+  float v[8], hi[8], mid[8], lo[8];
+  Vec16<float>::unpack(*(const uint4*)p, v);
+  Vec16<float>::unpack(*(const uint4*)(p + 4), v + 4);
+  const uint4 hp = Vec16<bf16>::pack(v);
+  Vec16<bf16>::unpack(hp, hi);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mid[e] = v[e] - hi[e];          // exact
+  const uint4 mp = Vec16<bf16>::pack(mid);                     // TERMS == 3: this is the second (last) piece
+  uint4 lp = mp;
+  if (TERMS == 6) {
+    float mr[8];
+    Vec16<bf16>::unpack(mp, mr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lo[e] = mid[e] - mr[e];        // exact
+    lp = Vec16<bf16>::pack(lo);
+  }
+  bf16* o = out + row * (int64_t)(TERMS * d) + k;
+  if (TERMS == 6) {
+    // query side:   lo hi mid mid hi hi      gallery side:   hi lo mid hi mid hi
+    const uint4 a[6] = {lp, hp, mp, mp, hp, hp};
+    const uint4 b[6] = {hp, lp, mp, hp, mp, hp};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) *(uint4*)(o + (int64_t)t * d) = side == 0 ? a[t] : b[t];
+  } else {
+    const uint4 a[3] = {mp, hp, hp};
+    const uint4 b[3] = {hp, mp, hp};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *(uint4*)(o + (int64_t)t * d) = side == 0 ? a[t] : b[t];
+  }
+}
+
 // ---------------------------------------------------------------- CMC / mAP
 constexpr int RANK_CAP = 1024;    // match keys sorted per batch (LDS)
 #ifndef IEEE_RANK_CELLS
@@ -593,6 +641,51 @@ extern "C" int ieee_sqeuclid_distmat(const void* q, const void* g, int64_t m, in
     IEEE_REQUIRE(false, "distmat: unsupported dtype %d", dtype);
   }
   return launch_status("distmat");
+}
+
+static int64_t split_align(int64_t bytes) { return (bytes + 255) / 256 * 256; }
+
+extern "C" int64_t ieee_sqeuclid_distmat_split_workspace_bytes(int64_t m, int64_t n, int64_t d, int64_t terms) {
+  if (m <= 0 || n <= 0 || d <= 0 || (terms != 3 && terms != 6)) return -1;
+  return split_align((m + n) * 4) + split_align(m * terms * d * 2) + split_align(n * terms * d * 2);
+}
+
+extern "C" int ieee_sqeuclid_distmat_split(const float* q, const float* g, int64_t m, int64_t n, int64_t d,
+                                           int64_t terms, int metric, float* out, int64_t ldo, void* work,
+                                           int64_t work_bytes, void* stream) {
+  IEEE_REQUIRE(q && g && out && work, "distmat_split: null pointer");
+  IEEE_REQUIRE(m > 0 && n > 0 && d > 0, "distmat_split: empty input (m=%ld n=%ld d=%ld)", (long)m, (long)n, (long)d);
+  IEEE_REQUIRE(d % 8 == 0, "distmat_split: feature dim %ld must be a multiple of 8", (long)d);
+  IEEE_REQUIRE(terms == 3 || terms == 6, "distmat_split: terms must be 3 or 6, got %ld", (long)terms);
+  IEEE_REQUIRE(ldo >= n, "distmat_split: ldo < n");
+  IEEE_REQUIRE(metric == 0 || metric == 1, "distmat_split: unknown metric %d", metric);
+  IEEE_REQUIRE(m < (1ll << 31) && n < (1ll << 31) && terms * d < (1ll << 31), "distmat_split: too large");
+  IEEE_REQUIRE(work_bytes >= ieee_sqeuclid_distmat_split_workspace_bytes(m, n, d, terms),
+               "distmat_split: workspace of %ld bytes is too small", (long)work_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  float* qn = (float*)work;
+  float* gn = qn + m;
+  bf16* qs = (bf16*)((char*)work + split_align((m + n) * 4));
+  bf16* gs = (bf16*)((char*)qs + split_align(m * terms * d * 2));
+  // row norms from the fp32 rows themselves (exactly as the fp32 path)
+  rownorm_kernel<float><<<cdiv(m, 4), 256, 0, st>>>(q, m, (int)d, metric, qn);
+  rownorm_kernel<float><<<cdiv(n, 4), 256, 0, st>>>(g, n, (int)d, metric, gn);
+  if (terms == 6) {
+    split_rows_kernel<6><<<cdiv(m * (d / 8), 256), 256, 0, st>>>(q, qs, m, (int)d, 0);
+    split_rows_kernel<6><<<cdiv(n * (d / 8), 256), 256, 0, st>>>(g, gs, n, (int)d, 1);
+  } else {
+    split_rows_kernel<3><<<cdiv(m * (d / 8), 256), 256, 0, st>>>(q, qs, m, (int)d, 0);
+    split_rows_kernel<3><<<cdiv(n * (d / 8), 256), 256, 0, st>>>(g, gs, n, (int)d, 1);
+  }
+  const int tiles_m = cdiv(m, 128), tiles_n = cdiv(n, 128);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)distmat_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  distmat_kernel<bf16><<<tiles_m * tiles_n, 256, 256 * 128, st>>>(qs, gs, qn, gn, out, (int)m, (int)n, (int)(terms * d),
+                                                                 ldo, metric, tiles_m, tiles_n);
+  return launch_status("distmat_split");
 }
 
 extern "C" int ieee_rank_market1501(const float* distmat, int64_t ldd, int64_t num_q, int64_t num_g,

@@ -1,6 +1,13 @@
 """Distance matrices on MI355X.  Same names, arguments and error behaviour as the
 reference's torchreid/metrics/distance.py:6-80; the arithmetic runs in
-ieee_sqeuclid_distmat (tiled MFMA GEMM with the norm epilogue fused)."""
+ieee_sqeuclid_distmat (tiled MFMA GEMM with the norm epilogue fused).
+
+`precision` (keyword, or IEEE_DISTMAT_PRECISION; not in the reference) picks the matrix pipe for fp32 inputs:
+"fp32" (default) = fp32 MFMA; "split6" = the fp32 rows as three exact bf16 pieces and six piece products on the bf16
+matrix cores (fp32-grade accuracy, faster than the fp32 pipe); "split3" = two pieces (~2^-16 relative); "bf16" =
+round the inputs to bf16."""
+import os
+
 import torch
 
 from .. import _lib
@@ -13,10 +20,17 @@ def _as_device(x, dtype):
     return x.to(dtype).contiguous(), dev
 
 
-def _distmat(input1, input2, metric_id, compute_dtype=None):
+PRECISIONS = ("fp32", "split6", "split3", "bf16")
+
+
+def _distmat(input1, input2, metric_id, compute_dtype=None, precision=None):
     lib = _lib.require_gpu()
+    if precision is None:
+        precision = os.environ.get("IEEE_DISTMAT_PRECISION", "fp32")
+    if precision not in PRECISIONS:
+        raise ValueError("Unknown distmat precision: {}. Choose one of {}".format(precision, PRECISIONS))
     if compute_dtype is None:
-        compute_dtype = torch.bfloat16 if input1.dtype == torch.bfloat16 else torch.float32
+        compute_dtype = torch.bfloat16 if (input1.dtype == torch.bfloat16 or precision == "bf16") else torch.float32
     a, dev = _as_device(input1, compute_dtype)
     b, _ = _as_device(input2, compute_dtype)
     m, d = a.shape
@@ -29,6 +43,13 @@ def _distmat(input1, input2, metric_id, compute_dtype=None):
         a = torch.nn.functional.pad(a, (0, pad))
         b = torch.nn.functional.pad(b, (0, pad))
         d += pad
+    if compute_dtype == torch.float32 and precision in ("split6", "split3"):
+        terms = 6 if precision == "split6" else 3
+        nbytes = lib.ieee_sqeuclid_distmat_split_workspace_bytes(m, n, d, terms)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+        _lib.check(lib.ieee_sqeuclid_distmat_split(_lib.ptr(a), _lib.ptr(b), m, n, d, terms, metric_id, _lib.ptr(out), n,
+                                                   _lib.ptr(work), nbytes, _lib.stream()))
+        return out if dev.type == "cuda" else out.to(dev)
     work = torch.empty(m + n, dtype=torch.float32, device=a.device)
     dt = _lib.IEEE_BF16 if compute_dtype == torch.bfloat16 else _lib.IEEE_F32
     _lib.check(lib.ieee_sqeuclid_distmat(_lib.ptr(a), _lib.ptr(b), m, n, d, dt, metric_id, _lib.ptr(out), n,
@@ -36,7 +57,7 @@ def _distmat(input1, input2, metric_id, compute_dtype=None):
     return out if dev.type == "cuda" else out.to(dev)
 
 
-def compute_distance_matrix(input1, input2, metric='euclidean'):
+def compute_distance_matrix(input1, input2, metric='euclidean', precision=None):
     """Reference torchreid/metrics/distance.py:6-46.  CPU inputs are staged through the GPU and the
     result is returned on the inputs' device (the reference's caller, Engine._evaluate, passes CPU
     tensors, engine/engine.py:368-399); CUDA inputs stay on the device."""
@@ -47,9 +68,9 @@ def compute_distance_matrix(input1, input2, metric='euclidean'):
     assert input1.size(1) == input2.size(1)
 
     if metric == 'euclidean':
-        distmat = euclidean_squared_distance(input1, input2)
+        distmat = euclidean_squared_distance(input1, input2, precision)
     elif metric == 'cosine':
-        distmat = cosine_distance(input1, input2)
+        distmat = cosine_distance(input1, input2, precision)
     else:
         raise ValueError(
             'Unknown distance metric: {}. '
@@ -58,11 +79,11 @@ def compute_distance_matrix(input1, input2, metric='euclidean'):
     return distmat
 
 
-def euclidean_squared_distance(input1, input2):
+def euclidean_squared_distance(input1, input2, precision=None):
     """distance.py:49-64 — |a|^2 + |b|^2 - 2 a.b (squared, no sqrt)."""
-    return _distmat(input1, input2, 0)
+    return _distmat(input1, input2, 0, precision=precision)
 
 
-def cosine_distance(input1, input2):
+def cosine_distance(input1, input2, precision=None):
     """distance.py:67-80 — 1 - a^.b^ with F.normalize's eps of 1e-12."""
-    return _distmat(input1, input2, 1)
+    return _distmat(input1, input2, 1, precision=precision)

@@ -54,6 +54,14 @@ int ieee_device_is_gfx950(void);
  * L2-normalised with eps 1e-12 and out = 1 - q^.g^). */
 int ieee_sqeuclid_distmat(const void* q, const void* g, int64_t m, int64_t n, int64_t d, int dtype,
                           int metric, float* out, int64_t ldo, void* work, void* stream);
+/* the same matrix from fp32 rows on the bf16 matrix cores: every value is split into bf16 pieces that sum to it
+ * exactly (3 pieces = all 24 mantissa bits) and q.g becomes one bf16 GEMM over the piece products, smallest first,
+ * accumulated in fp32.  terms = 6: hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi -- the dropped products are below
+ * 2^-24 of the result, i.e. fp32-grade accuracy at about 6 bf16 GEMMs; terms = 3: two pieces, ~2^-16 relative.
+ * Row norms come from the fp32 rows as above.  work: ieee_sqeuclid_distmat_split_workspace_bytes() bytes. */
+int64_t ieee_sqeuclid_distmat_split_workspace_bytes(int64_t m, int64_t n, int64_t d, int64_t terms);
+int ieee_sqeuclid_distmat_split(const float* q, const float* g, int64_t m, int64_t n, int64_t d, int64_t terms,
+                                int metric, float* out, int64_t ldo, void* work, int64_t work_bytes, void* stream);
 
 /* ---- evaluator: CMC / mAP ----------------------------------------------- */
 /* torchreid/metrics/rank.py:103-171 eval_market1501 (and the disabled native

@@ -5,6 +5,9 @@ cosine_np          <- torchreid/metrics/distance.py:67-80
 rank_market1501_np <- torchreid/metrics/rank.py:103-171  (eval_market1501, python path)
 rank_market1501_c  <- same, compiled C (oracle/rank_oracle.c), for full-size runs
 accuracy_np        <- torchreid/metrics/accuracy.py:4-38
+bf16_pieces / sqeuclid_split_np: the split-bf16 arithmetic of ieee_sqeuclid_distmat_split (not in the reference; it is
+                      a way of computing distance.py:49-64 on the bf16 matrix cores), restated in float64 so that
+                      a test separates what the split drops from what fp32 accumulation rounds
 
 Pinned by tests/golden/evaluator_golden.npz, generated from the imported
 reference by tests/golden/gen_evaluator_golden.py, and by oracle/_ref (the
@@ -39,6 +42,37 @@ def sqeuclid_np(q: np.ndarray, g: np.ndarray) -> np.ndarray:
     distmat = mat1 + mat2                                     # distance.py:62
     distmat = distmat + np.float32(-2.0) * (q @ g.T)          # distance.py:63 addmm_(beta=1, alpha=-2)
     return distmat.astype(np.float32)
+
+
+def _bf16_rne(x: np.ndarray) -> np.ndarray:
+    """fp32 -> nearest bf16 (ties to even), returned as fp32"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def bf16_pieces(x: np.ndarray, pieces: int = 3):
+    """x (fp32) as `pieces` bf16 values hi, mid, lo with hi + mid + lo == x exactly when pieces == 3"""
+    x = np.asarray(x, dtype=np.float32)
+    out, r = [], x
+    for _ in range(pieces):
+        p = _bf16_rne(r)
+        out.append(p)
+        r = (r - p).astype(np.float32)          # exact: the residual fits fp32
+    return out
+
+
+def sqeuclid_split_np(q: np.ndarray, g: np.ndarray, terms: int = 6) -> np.ndarray:
+    """|q|^2 + |g|^2 - 2 q.g with q.g restricted to the piece products the device keeps (float64 sums)"""
+    assert terms in (3, 6)
+    qp, gp = bf16_pieces(q, 3 if terms == 6 else 2), bf16_pieces(g, 3 if terms == 6 else 2)
+    pairs = [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)] if terms == 6 else [(1, 0), (0, 1), (0, 0)]
+    dot = np.zeros((q.shape[0], g.shape[0]), dtype=np.float64)
+    for a, b in pairs:
+        dot += qp[a].astype(np.float64) @ gp[b].astype(np.float64).T
+    qn = (q.astype(np.float64) ** 2).sum(1)[:, None]
+    gn = (g.astype(np.float64) ** 2).sum(1)[None, :]
+    return qn + gn - 2.0 * dot
 
 
 def cosine_np(q, g):

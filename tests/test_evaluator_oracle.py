@@ -76,3 +76,28 @@ def test_oracle_vs_reference_native_evaluator():
     assert abs(m_ap - float(map_ref)) < 1e-6      # the Cython path accumulates AP in float32
     cmc32, map32 = ev.rank_market1501_c(d, qp, gp, qc, gc, 20, f32_accum=True)
     assert abs(map32 - float(map_ref)) < 1e-6
+
+
+def test_bf16_pieces_sum_exactly_and_split6_is_fp32_grade():
+    """the split-bf16 restatement: three bf16 pieces reproduce every fp32 value exactly, and the six kept piece
+    products differ from the exact product sum by less than fp32 rounding of the result"""
+    rng = np.random.RandomState(3)
+    x = (rng.randn(64, 768) * np.exp(rng.randn(64, 768) * 3)).astype(np.float32)
+    hi, mid, lo = ev.bf16_pieces(x, 3)
+    for p in (hi, mid, lo):
+        assert np.all((p.view(np.uint32) & 0xFFFF) == 0)           # each piece is a bf16 value
+    assert np.array_equal((hi.astype(np.float64) + mid + lo).astype(np.float32), x)
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), x.astype(np.float64))
+    q = np.abs(rng.randn(50, 768)).astype(np.float32)
+    g = np.abs(rng.randn(70, 768)).astype(np.float32)
+    q64, g64 = q.astype(np.float64), g.astype(np.float64)
+    exact = (q64 ** 2).sum(1)[:, None] + (g64 ** 2).sum(1)[None, :] - 2.0 * (q64 @ g64.T)
+    d6 = ev.sqeuclid_split_np(q, g, 6)
+    d3 = ev.sqeuclid_split_np(q, g, 3)
+    scale = np.abs(q.astype(np.float64)) @ np.abs(g.astype(np.float64)).T      # sum |q_k g_k|
+    assert np.max(np.abs(d6 - exact) / scale) < 2.0 ** -22
+    assert np.max(np.abs(d3 - exact) / scale) < 2.0 ** -14
+    # integer-grid features are single-piece values: nothing is dropped
+    qi = rng.randint(-3, 4, size=(9, 24)).astype(np.float32)
+    gi = rng.randint(-3, 4, size=(11, 24)).astype(np.float32)
+    assert np.array_equal(ev.sqeuclid_split_np(qi, gi, 6), ev.sqeuclid_np(qi, gi).astype(np.float64))
