@@ -94,8 +94,8 @@ def bench_distmat(device):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         out[name] = {"ms": ms, "GFLOP/s": 2.0 * Q * G * D / ms / 1e6}
-    # fp32 rows as exact bf16 pieces on the bf16 matrix cores (six piece products: fp32-grade accuracy)
-    for name, prec, terms in (("split_bf16x3", "split6", 6),):
+    # fp32 rows as exact 16-bit pieces on the bf16 / fp16 matrix cores (6 resp. 3 piece products: fp32-grade accuracy)
+    for name, prec, terms in (("split_bf16x3", "bf16x3", 6), ("split_f16x2", "f16x2", 3)):
         compute_distance_matrix(qf, gf, precision=prec)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -106,7 +106,7 @@ def bench_distmat(device):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         out[name] = {"ms": ms, "GFLOP/s": 2.0 * Q * G * D / ms / 1e6, "mfma_TFLOP/s": terms * 2.0 * Q * G * D / ms / 1e9,
-                     "mfma_frac_of_bf16_peak": terms * 2.0 * Q * G * D / ms / 1e9 / PEAK_BF16_TFLOPS,
+                     "mfma_frac_of_16bit_peak": terms * 2.0 * Q * G * D / ms / 1e9 / PEAK_BF16_TFLOPS,
                      "note": "includes the piece-splitting pre-pass; GFLOP/s counts the 2*Q*G*D of the fp32 problem"}
     del dm
     # the model's real descriptor width (2304 = 3 x 768, ieee3modalPart.py:502), fp32, smaller gallery

@@ -21,26 +21,75 @@ __device__ __forceinline__ void tile_map(int tiles_m, int tiles_n, int group, in
   tn = in / gsz;
 }
 
+// Epilogue of the distance GEMM, staged through LDS: a lane's accumulators are 4 consecutive columns of ONE row, so
+// storing them directly scatters 64-byte pieces over 16 rows per instruction (the 4 GB output of the 10k x 100k case
+// then costs 2.3 ms); instead each half of the 128 x 128 tile (64 rows, exactly the 32 KB operand stage) goes through
+// an XOR-swizzled LDS image and leaves as full 512-byte rows, norms (and the fp16 split's row scales) applied on the
+// way out.
 struct DistEpi {
-  static constexpr bool kStaged = false;
+  static constexpr bool kStaged = true;
   float* out;
   const float* qn;
   const float* gn;
   int64_t ldo;
   int m, n, metric;
-  __device__ __forceinline__ void operator()(int i, int j, f32x4 v) const {
-    if (i >= m) return;
-    float* o = out + (int64_t)i * ldo + j;
-    if (metric == 0) {
-      const float a = qn[i];
+  const float* qsc;   // optional per-row powers of two that undo the operand scaling of the fp16 split (else null)
+  const float* gsc;
+  __device__ __forceinline__ float value(float v, float a, float b) const {
+    return metric == 0 ? (a + b) + (-2.0f * v)      // distance.py:62-63
+                       : 1.0f - v * a * b;          // distance.py:77-79 (a, b hold 1/max(|.|,eps))
+  }
+  template <int BM, int BN, int FM, int FN>
+  __device__ __forceinline__ void finish(f32x4 (&acc)[FM][FN], char* smem, int m0, int n0) const {
+    static_assert(BM == 128 && BN == 128, "DistEpi: 128 x 128 tiles");
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int ch = t & 31, r0 = t >> 5;            // read-back: 16-byte chunk of the row, first row of the pass
+    const int col = n0 + ch * 4;
+    float gnv[4], gsv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (j + r < n) o[r] = (a + gn[j + r]) + (-2.0f * v[r]);   // distance.py:62-63
-    } else {
-      const float a = qn[i];   // holds 1/max(|q|,eps)
+    for (int r = 0; r < 4; ++r) {
+      gnv[r] = col + r < n ? gn[col + r] : 0.f;
+      gsv[r] = (gsc && col + r < n) ? gsc[col + r] : 1.f;
+    }
+    const bool vec_ok = (((uintptr_t)out | (uintptr_t)(ldo * 4)) & 15) == 0 && col + 3 < n;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (j + r < n) o[r] = 1.0f - v[r] * a * gn[j + r];         // distance.py:77-79
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();   // h = 0: every wave is done with the operand stage; h = 1: the first half has been read
+      if (wm == h) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int r = i * 16 + (lane & 15);
+            const int c = wn * 16 + j * 4 + (lane >> 4);           // 16-byte chunk index within the 512-byte row
+            *(float4*)(smem + r * 512 + ((c ^ (r & 31)) << 4)) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pss = 0; pss < 8; ++pss) {
+        const int r = r0 + 8 * pss;
+        const int row = m0 + h * 64 + r;
+        if (row >= m || col >= n) continue;
+        const float4 v4 = *(const float4*)(smem + r * 512 + ((ch ^ (r & 31)) << 4));
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const float a = qn[row];
+        if (qsc) {
+          const float sq = qsc[row];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= sq * gsv[e];
+        }
+        float* o = out + (int64_t)row * ldo + col;
+        if (vec_ok) {
+          *(float4*)o = make_float4(value(v[0], a, gnv[0]), value(v[1], a, gnv[1]), value(v[2], a, gnv[2]),
+                                    value(v[3], a, gnv[3]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < n) o[e] = value(v[e], a, gnv[e]);
+        }
+      }
     }
   }
 };
@@ -48,21 +97,22 @@ struct DistEpi {
 #ifndef IEEE_DIST_STAGES
 #define IEEE_DIST_STAGES 1   // one LDS stage for fp32 too: 32 KB -> more workgroups per CU, 112 -> 121 TFLOP/s
 #endif
-template <typename T>
+template <typename T, bool F16 = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void distmat_kernel(const T* q, const T* g, const float* qn, const float* gn,
                                                       float* out, int m, int n, int d, int64_t ldo, int metric,
-                                                      int tiles_m, int tiles_n) {
+                                                      int tiles_m, int tiles_n, const float* qsc = nullptr,
+                                                      const float* gsc = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   tile_map(tiles_m, tiles_n, 8, tm, tn);
   const int m0 = tm * 128, n0 = tn * 128;
   LoaderPlainNT<T, 4> la, lb;
-  DistEpi epi{out, qn, gn, ldo, m, n, metric};
+  DistEpi epi{out, qn, gn, ldo, m, n, metric, qsc, gsc};
   if constexpr (sizeof(T) == 2) {   // single-stage LDS-DMA pipeline, 4 workgroups per CU (see conv.hip plan_gather)
     const int ch = nt_dma_chunk(threadIdx.x);
     la.init(q, d, m0, m, d, ch);
     lb.init(g, d, n0, n, d, ch);
-    gemm_nt_dma<128, 128, 1>(la, lb, epi, (d + 63) / 64, m0, n0, smem);
+    gemm_nt_dma<128, 128, 1, F16>(la, lb, epi, (d + 63) / 64, m0, n0, smem);
     return;
   }
   la.init(q, d, m0, m, d);
@@ -134,6 +184,46 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     const uint4 b[3] = {hp, mp, hp};
 #pragma unroll
     for (int t = 0; t < 3; ++t) *(uint4*)(o + (int64_t)t * d) = side == 0 ? a[t] : b[t];
+  }
+}
+
+// Two fp16 pieces (11 + 11 mantissa bits) and three products lo.hi, hi.lo, hi.hi: 2^-22 relative, at half the MFMA
+// work of the six bf16 products.  fp16 has a narrow exponent, so every row is first scaled by a power of two that
+// puts its largest magnitude just below 2^14 (exact); the inverse scales go to `inv_scale` and the GEMM epilogue
+// multiplies them back (exact as well).  One wave per row.
+__global__ __launch_bounds__(256) void split_rows_f16_kernel(const float* __restrict__ x, uint16_t* __restrict__ out,
+                                                             float* __restrict__ inv_scale, int64_t rows, int d,
+                                                             int side) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = x + row * d;
+  float mx = 0.f;
+  for (int k = lane * 4; k < d; k += 256) {
+    const float4 v = *(const float4*)(p + k);
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  mx = wave_max(mx);
+  int e = 0;
+  if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);        // mx = f * 2^e, f in [0.5, 1)
+  const float sc = ldexpf(1.0f, 14 - e), isc = ldexpf(1.0f, e - 14);
+  if (lane == 0) inv_scale[row] = isc;
+  typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+  uint16_t* o = out + row * (int64_t)(3 * d);
+  for (int k = lane * 4; k < d; k += 256) {
+    const float4 v = *(const float4*)(p + k);
+    const float y[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+    f16x4 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      hi[c] = (_Float16)y[c];
+      lo[c] = (_Float16)(y[c] - (float)hi[c]);               // the subtraction is exact
+    }
+    const uint2 hp = __builtin_bit_cast(uint2, hi), lp = __builtin_bit_cast(uint2, lo);
+    // query side: lo hi hi      gallery side: hi lo hi
+    *(uint2*)(o + k) = side == 0 ? lp : hp;
+    *(uint2*)(o + d + k) = side == 0 ? hp : lp;
+    *(uint2*)(o + 2 * (int64_t)d + k) = hp;
   }
 }
 
@@ -644,47 +734,64 @@ extern "C" int ieee_sqeuclid_distmat(const void* q, const void* g, int64_t m, in
 }
 
 static int64_t split_align(int64_t bytes) { return (bytes + 255) / 256 * 256; }
+static int split_terms(int64_t scheme) {
+  return scheme == IEEE_SPLIT_BF16X3 ? 6 : (scheme == IEEE_SPLIT_BF16X2 || scheme == IEEE_SPLIT_F16X2) ? 3 : 0;
+}
 
-extern "C" int64_t ieee_sqeuclid_distmat_split_workspace_bytes(int64_t m, int64_t n, int64_t d, int64_t terms) {
-  if (m <= 0 || n <= 0 || d <= 0 || (terms != 3 && terms != 6)) return -1;
-  return split_align((m + n) * 4) + split_align(m * terms * d * 2) + split_align(n * terms * d * 2);
+extern "C" int64_t ieee_sqeuclid_distmat_split_workspace_bytes(int64_t m, int64_t n, int64_t d, int64_t scheme) {
+  const int terms = split_terms(scheme);
+  if (m <= 0 || n <= 0 || d <= 0 || terms == 0) return -1;
+  return split_align((m + n) * 8) + split_align(m * terms * d * 2) + split_align(n * terms * d * 2);
 }
 
 extern "C" int ieee_sqeuclid_distmat_split(const float* q, const float* g, int64_t m, int64_t n, int64_t d,
-                                           int64_t terms, int metric, float* out, int64_t ldo, void* work,
+                                           int64_t scheme, int metric, float* out, int64_t ldo, void* work,
                                            int64_t work_bytes, void* stream) {
   IEEE_REQUIRE(q && g && out && work, "distmat_split: null pointer");
   IEEE_REQUIRE(m > 0 && n > 0 && d > 0, "distmat_split: empty input (m=%ld n=%ld d=%ld)", (long)m, (long)n, (long)d);
   IEEE_REQUIRE(d % 8 == 0, "distmat_split: feature dim %ld must be a multiple of 8", (long)d);
-  IEEE_REQUIRE(terms == 3 || terms == 6, "distmat_split: terms must be 3 or 6, got %ld", (long)terms);
+  const int terms = split_terms(scheme);
+  IEEE_REQUIRE(terms != 0, "distmat_split: unknown scheme %ld (IEEE_SPLIT_BF16X3 / _BF16X2 / _F16X2)", (long)scheme);
   IEEE_REQUIRE(ldo >= n, "distmat_split: ldo < n");
   IEEE_REQUIRE(metric == 0 || metric == 1, "distmat_split: unknown metric %d", metric);
   IEEE_REQUIRE(m < (1ll << 31) && n < (1ll << 31) && terms * d < (1ll << 31), "distmat_split: too large");
-  IEEE_REQUIRE(work_bytes >= ieee_sqeuclid_distmat_split_workspace_bytes(m, n, d, terms),
+  IEEE_REQUIRE(work_bytes >= ieee_sqeuclid_distmat_split_workspace_bytes(m, n, d, scheme),
                "distmat_split: workspace of %ld bytes is too small", (long)work_bytes);
   hipStream_t st = (hipStream_t)stream;
-  float* qn = (float*)work;
+  float* qn = (float*)work;           // [m] norms, [n] norms, [m] inverse scales, [n] inverse scales
   float* gn = qn + m;
-  bf16* qs = (bf16*)((char*)work + split_align((m + n) * 4));
-  bf16* gs = (bf16*)((char*)qs + split_align(m * terms * d * 2));
+  float* qsc = gn + n;
+  float* gsc = qsc + m;
+  char* qs = (char*)work + split_align((m + n) * 8);
+  char* gs = qs + split_align(m * terms * d * 2);
   // row norms from the fp32 rows themselves (exactly as the fp32 path)
   rownorm_kernel<float><<<cdiv(m, 4), 256, 0, st>>>(q, m, (int)d, metric, qn);
   rownorm_kernel<float><<<cdiv(n, 4), 256, 0, st>>>(g, n, (int)d, metric, gn);
-  if (terms == 6) {
-    split_rows_kernel<6><<<cdiv(m * (d / 8), 256), 256, 0, st>>>(q, qs, m, (int)d, 0);
-    split_rows_kernel<6><<<cdiv(n * (d / 8), 256), 256, 0, st>>>(g, gs, n, (int)d, 1);
-  } else {
-    split_rows_kernel<3><<<cdiv(m * (d / 8), 256), 256, 0, st>>>(q, qs, m, (int)d, 0);
-    split_rows_kernel<3><<<cdiv(n * (d / 8), 256), 256, 0, st>>>(g, gs, n, (int)d, 1);
-  }
   const int tiles_m = cdiv(m, 128), tiles_n = cdiv(n, 128);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)distmat_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)distmat_kernel<bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     attr_done = true;
   }
-  distmat_kernel<bf16><<<tiles_m * tiles_n, 256, 256 * 128, st>>>(qs, gs, qn, gn, out, (int)m, (int)n, (int)(terms * d),
-                                                                 ldo, metric, tiles_m, tiles_n);
+  if (scheme == IEEE_SPLIT_F16X2) {
+    split_rows_f16_kernel<<<cdiv(m, 4), 256, 0, st>>>(q, (uint16_t*)qs, qsc, m, (int)d, 0);
+    split_rows_f16_kernel<<<cdiv(n, 4), 256, 0, st>>>(g, (uint16_t*)gs, gsc, n, (int)d, 1);
+    distmat_kernel<bf16, true><<<tiles_m * tiles_n, 256, 256 * 128, st>>>((const bf16*)qs, (const bf16*)gs, qn, gn, out,
+                                                                         (int)m, (int)n, (int)(terms * d), ldo, metric,
+                                                                         tiles_m, tiles_n, qsc, gsc);
+    return launch_status("distmat_split");
+  }
+  if (terms == 6) {
+    split_rows_kernel<6><<<cdiv(m * (d / 8), 256), 256, 0, st>>>(q, (bf16*)qs, m, (int)d, 0);
+    split_rows_kernel<6><<<cdiv(n * (d / 8), 256), 256, 0, st>>>(g, (bf16*)gs, n, (int)d, 1);
+  } else {
+    split_rows_kernel<3><<<cdiv(m * (d / 8), 256), 256, 0, st>>>(q, (bf16*)qs, m, (int)d, 0);
+    split_rows_kernel<3><<<cdiv(n * (d / 8), 256), 256, 0, st>>>(g, (bf16*)gs, n, (int)d, 1);
+  }
+  distmat_kernel<bf16><<<tiles_m * tiles_n, 256, 256 * 128, st>>>((const bf16*)qs, (const bf16*)gs, qn, gn, out, (int)m,
+                                                                 (int)n, (int)(terms * d), ldo, metric, tiles_m, tiles_n);
   return launch_status("distmat_split");
 }
 

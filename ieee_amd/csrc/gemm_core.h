@@ -28,6 +28,14 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// 16-bit fragments issued as v_mfma_f32_16x16x32_f16 (F16) or ..._bf16: same LDS image, same lane layout
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool F16> __device__ __forceinline__ f32x4 mfma16_16bit(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 // ------------------------------------------------------------------ LDS images
 // NT image: [rows][128 bytes of K]; 16-byte chunks XOR-swizzled so that the
@@ -311,7 +319,7 @@ template <int PER> __device__ __forceinline__ void wait_tiles(int tiles_in_fligh
   else wait_vmcnt<0>();
 }
 
-template <int BM, int BN, int STAGES, class LA, class LB, class Epi>
+template <int BM, int BN, int STAGES, bool F16 = false, class LA, class LB, class Epi>
 __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem) {
   typedef ImgNT<bf16> Img;
   constexpr int DMA_STAGES = STAGES;
@@ -347,7 +355,7 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16_16bit<F16>(fb[j], fa[i], acc[i][j]);
     }
   };
   if constexpr (DMA_STAGES == 5) {
@@ -379,7 +387,7 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[kk][j], fa[kk][i], acc[i][j]);
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16_16bit<F16>(fb[kk][j], fa[kk][i], acc[i][j]);
     }
   } else if constexpr (DMA_STAGES == 1) {
     // one LDS stage, nothing staged in registers: the fetch of the next tile is not overlapped inside the

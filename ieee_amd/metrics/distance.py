@@ -3,9 +3,9 @@ reference's torchreid/metrics/distance.py:6-80; the arithmetic runs in
 ieee_sqeuclid_distmat (tiled MFMA GEMM with the norm epilogue fused).
 
 `precision` (keyword, or IEEE_DISTMAT_PRECISION; not in the reference) picks the matrix pipe for fp32 inputs:
-"fp32" (default) = fp32 MFMA; "split6" = the fp32 rows as three exact bf16 pieces and six piece products on the bf16
-matrix cores (fp32-grade accuracy, faster than the fp32 pipe); "split3" = two pieces (~2^-16 relative); "bf16" =
-round the inputs to bf16."""
+"fp32" (default) = fp32 MFMA; "bf16x3" = the fp32 rows as three exact bf16 pieces and six piece products on the bf16
+matrix cores (fp32-grade accuracy); "f16x2" = two fp16 pieces of the power-of-two-scaled rows and three products
+(2^-22 relative, the fastest fp32-grade path); "bf16x2" = two bf16 pieces (~2^-16); "bf16" = round the inputs to bf16."""
 import os
 
 import torch
@@ -20,7 +20,8 @@ def _as_device(x, dtype):
     return x.to(dtype).contiguous(), dev
 
 
-PRECISIONS = ("fp32", "split6", "split3", "bf16")
+PRECISIONS = ("fp32", "bf16x3", "f16x2", "bf16x2", "bf16")
+_SPLIT_SCHEME = {"bf16x3": 6, "bf16x2": 3, "f16x2": 2}     # IEEE_SPLIT_* in include/ieee_amd.h
 
 
 def _distmat(input1, input2, metric_id, compute_dtype=None, precision=None):
@@ -43,8 +44,8 @@ def _distmat(input1, input2, metric_id, compute_dtype=None, precision=None):
         a = torch.nn.functional.pad(a, (0, pad))
         b = torch.nn.functional.pad(b, (0, pad))
         d += pad
-    if compute_dtype == torch.float32 and precision in ("split6", "split3"):
-        terms = 6 if precision == "split6" else 3
+    if compute_dtype == torch.float32 and precision in _SPLIT_SCHEME:
+        terms = _SPLIT_SCHEME[precision]
         nbytes = lib.ieee_sqeuclid_distmat_split_workspace_bytes(m, n, d, terms)
         work = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
         _lib.check(lib.ieee_sqeuclid_distmat_split(_lib.ptr(a), _lib.ptr(b), m, n, d, terms, metric_id, _lib.ptr(out), n,

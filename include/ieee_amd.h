@@ -54,13 +54,20 @@ int ieee_device_is_gfx950(void);
  * L2-normalised with eps 1e-12 and out = 1 - q^.g^). */
 int ieee_sqeuclid_distmat(const void* q, const void* g, int64_t m, int64_t n, int64_t d, int dtype,
                           int metric, float* out, int64_t ldo, void* work, void* stream);
-/* the same matrix from fp32 rows on the bf16 matrix cores: every value is split into bf16 pieces that sum to it
- * exactly (3 pieces = all 24 mantissa bits) and q.g becomes one bf16 GEMM over the piece products, smallest first,
- * accumulated in fp32.  terms = 6: hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi -- the dropped products are below
- * 2^-24 of the result, i.e. fp32-grade accuracy at about 6 bf16 GEMMs; terms = 3: two pieces, ~2^-16 relative.
+/* the same matrix from fp32 rows on the 16-bit matrix cores: every value is split into 16-bit pieces that sum to it
+ * and q.g becomes ONE 16-bit GEMM over the piece products, smallest first, accumulated in fp32 (each product is exact
+ * there).  scheme:
+ *   IEEE_SPLIT_BF16X3  three bf16 pieces (all 24 mantissa bits), six products hi.hi hi.mid mid.hi mid.mid hi.lo lo.hi;
+ *                      what is dropped is below 2^-24 of the result
+ *   IEEE_SPLIT_F16X2   two fp16 pieces (22 bits) of the row scaled by a power of two (undone in the epilogue), three
+ *                      products hi.hi hi.lo lo.hi: 2^-22, half the matrix work of BF16X3
+ *   IEEE_SPLIT_BF16X2  two bf16 pieces, three products: ~2^-16
  * Row norms come from the fp32 rows as above.  work: ieee_sqeuclid_distmat_split_workspace_bytes() bytes. */
-int64_t ieee_sqeuclid_distmat_split_workspace_bytes(int64_t m, int64_t n, int64_t d, int64_t terms);
-int ieee_sqeuclid_distmat_split(const float* q, const float* g, int64_t m, int64_t n, int64_t d, int64_t terms,
+#define IEEE_SPLIT_BF16X3 6
+#define IEEE_SPLIT_BF16X2 3
+#define IEEE_SPLIT_F16X2 2
+int64_t ieee_sqeuclid_distmat_split_workspace_bytes(int64_t m, int64_t n, int64_t d, int64_t scheme);
+int ieee_sqeuclid_distmat_split(const float* q, const float* g, int64_t m, int64_t n, int64_t d, int64_t scheme,
                                 int metric, float* out, int64_t ldo, void* work, int64_t work_bytes, void* stream);
 
 /* ---- evaluator: CMC / mAP ----------------------------------------------- */

@@ -62,14 +62,33 @@ def bf16_pieces(x: np.ndarray, pieces: int = 3):
     return out
 
 
-def sqeuclid_split_np(q: np.ndarray, g: np.ndarray, terms: int = 6) -> np.ndarray:
+def f16_pieces(x: np.ndarray):
+    """rows of x (fp32) scaled by the power of two that puts the row maximum just below 2^14, as two fp16 pieces
+    hi, lo (returned as float64, scaled) and the inverse scale per row"""
+    x = np.asarray(x, dtype=np.float32)
+    mx = np.abs(x).max(axis=1)
+    e = np.where(mx > 0, np.frexp(mx)[1], 0).astype(np.int64)
+    sc = np.ldexp(np.float32(1.0), (14 - e).astype(np.int32)).astype(np.float32)
+    y = (x * sc[:, None]).astype(np.float32)                 # exact (power of two)
+    hi = y.astype(np.float16)
+    lo = (y - hi.astype(np.float32)).astype(np.float32).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64), (1.0 / sc.astype(np.float64))
+
+
+def sqeuclid_split_np(q: np.ndarray, g: np.ndarray, scheme="bf16x3") -> np.ndarray:
     """|q|^2 + |g|^2 - 2 q.g with q.g restricted to the piece products the device keeps (float64 sums)"""
-    assert terms in (3, 6)
-    qp, gp = bf16_pieces(q, 3 if terms == 6 else 2), bf16_pieces(g, 3 if terms == 6 else 2)
-    pairs = [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)] if terms == 6 else [(1, 0), (0, 1), (0, 0)]
-    dot = np.zeros((q.shape[0], g.shape[0]), dtype=np.float64)
-    for a, b in pairs:
-        dot += qp[a].astype(np.float64) @ gp[b].astype(np.float64).T
+    assert scheme in ("bf16x3", "bf16x2", "f16x2")
+    if scheme == "f16x2":
+        qh, ql, qs = f16_pieces(q)
+        gh, gl, gs = f16_pieces(g)
+        dot = (ql @ gh.T + qh @ gl.T + qh @ gh.T) * qs[:, None] * gs[None, :]
+    else:
+        np_ = 3 if scheme == "bf16x3" else 2
+        qp, gp = bf16_pieces(q, np_), bf16_pieces(g, np_)
+        pairs = [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)] if np_ == 3 else [(1, 0), (0, 1), (0, 0)]
+        dot = np.zeros((q.shape[0], g.shape[0]), dtype=np.float64)
+        for a, b in pairs:
+            dot += qp[a].astype(np.float64) @ gp[b].astype(np.float64).T
     qn = (q.astype(np.float64) ** 2).sum(1)[:, None]
     gn = (g.astype(np.float64) ** 2).sum(1)[None, :]
     return qn + gn - 2.0 * dot

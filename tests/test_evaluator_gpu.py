@@ -66,7 +66,7 @@ def test_distmat_bf16_inputs():
     np.testing.assert_allclose(dm, ref, rtol=1e-5, atol=2e-3)
 
 
-@pytest.mark.parametrize("precision", ["split6", "split3"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x2", "f16x2"])
 def test_distmat_split_bf16_exact_on_integer_grid_and_ragged(G, precision):
     """small integers are single-piece bf16 values: the split GEMM is exact, on the goldens and on ragged shapes"""
     from ieee_amd.metrics import compute_distance_matrix
@@ -82,15 +82,16 @@ def test_distmat_split_bf16_exact_on_integer_grid_and_ragged(G, precision):
         assert np.array_equal(dm, ev.sqeuclid_np(q, g))
 
 
-def test_distmat_split6_is_fp32_grade(G):
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_distmat_split_is_fp32_grade(G, precision):
     """six piece products on the bf16 matrix cores against (a) the reference golden at the fp32 tolerance, (b) the
     float64 restatement of the same piece products -- what is left is fp32 accumulation rounding, and it is no
     larger than the fp32-MFMA path's own --, (c) identical CMC / mAP"""
     from ieee_amd.metrics import compute_distance_matrix, evaluate_rank
     q = torch.from_numpy(G["F_qf"].astype(np.float32))
     g = torch.from_numpy(G["F_gf"].astype(np.float32))
-    np.testing.assert_allclose(compute_distance_matrix(q, g, precision="split6").numpy(), G["F_dist"], rtol=1e-5, atol=1e-3)
-    np.testing.assert_allclose(compute_distance_matrix(q, g, "cosine", precision="split6").numpy(), G["F_cos"], rtol=0,
+    np.testing.assert_allclose(compute_distance_matrix(q, g, precision=precision).numpy(), G["F_dist"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(compute_distance_matrix(q, g, "cosine", precision=precision).numpy(), G["F_cos"], rtol=0,
                                atol=2e-6)
     rng = np.random.RandomState(17)
     qf = np.abs(rng.randn(500, 768)).astype(np.float32)
@@ -98,12 +99,17 @@ def test_distmat_split6_is_fp32_grade(G):
     q64, g64 = qf.astype(np.float64), gf.astype(np.float64)
     exact = (q64 ** 2).sum(1)[:, None] + (g64 ** 2).sum(1)[None, :] - 2.0 * (q64 @ g64.T)
     d32 = compute_distance_matrix(torch.from_numpy(qf).cuda(), torch.from_numpy(gf).cuda()).cpu().numpy()
-    d6 = compute_distance_matrix(torch.from_numpy(qf).cuda(), torch.from_numpy(gf).cuda(), precision="split6").cpu().numpy()
-    d3 = compute_distance_matrix(torch.from_numpy(qf).cuda(), torch.from_numpy(gf).cuda(), precision="split3").cpu().numpy()
+    d6 = compute_distance_matrix(torch.from_numpy(qf).cuda(), torch.from_numpy(gf).cuda(), precision=precision).cpu().numpy()
+    d3 = compute_distance_matrix(torch.from_numpy(qf).cuda(), torch.from_numpy(gf).cuda(), precision="bf16x2").cpu().numpy()
     e32, e6, e3 = np.abs(d32 - exact).max(), np.abs(d6 - exact).max(), np.abs(d3 - exact).max()
     assert e6 <= 1.5 * e32 + 1e-4, (e6, e32)
-    assert np.abs(d6 - ev.sqeuclid_split_np(qf, gf, 6)).max() <= 1.5 * e32 + 1e-4
-    assert e3 < 0.05 and np.abs(d3 - ev.sqeuclid_split_np(qf, gf, 3)).max() <= 1.5 * e32 + 1e-4
+    assert np.abs(d6 - ev.sqeuclid_split_np(qf, gf, precision)).max() <= 1.5 * e32 + 1e-4
+    assert e3 < 0.05 and np.abs(d3 - ev.sqeuclid_split_np(qf, gf, "bf16x2")).max() <= 1.5 * e32 + 1e-4
+    # rows of very different magnitude (the fp16 pieces rely on the per-row scaling)
+    qw = (qf[:64] * np.exp2(rng.randint(-30, 30, size=(64, 1)))).astype(np.float32)
+    dw = compute_distance_matrix(torch.from_numpy(qw).cuda(), torch.from_numpy(gf).cuda(), precision=precision).cpu().numpy()
+    dw32 = compute_distance_matrix(torch.from_numpy(qw).cuda(), torch.from_numpy(gf).cuda()).cpu().numpy()
+    np.testing.assert_allclose(dw, dw32, rtol=2e-5, atol=1e-3)
     qp, gp = rng.randint(0, 100, 500), rng.randint(0, 100, 3000)
     qc, gc = rng.randint(0, 4, 500), rng.randint(0, 4, 3000)
     cmc_a, map_a = evaluate_rank(d32, qp, gp, qc, gc)
@@ -121,8 +127,9 @@ def test_distmat_split_errors():
     out = torch.empty(4, 4, device="cuda")
     work = torch.empty(1 << 16, dtype=torch.uint8, device="cuda")
     assert lib.ieee_sqeuclid_distmat_split_workspace_bytes(4, 4, 8, 5) == -1
+    assert lib.ieee_sqeuclid_distmat_split_workspace_bytes(4, 4, 8, 2) > 0
     assert lib.ieee_sqeuclid_distmat_split(L.ptr(q), L.ptr(q), 4, 4, 8, 5, 0, L.ptr(out), 4, L.ptr(work), 1 << 16, L.stream()) != 0
-    assert b"terms" in lib.ieee_last_error()
+    assert b"scheme" in lib.ieee_last_error()
     assert lib.ieee_sqeuclid_distmat_split(L.ptr(q), L.ptr(q), 4, 4, 8, 6, 0, L.ptr(out), 4, L.ptr(work), 16, L.stream()) != 0
     assert b"workspace" in lib.ieee_last_error()
 

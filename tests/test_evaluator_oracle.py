@@ -78,7 +78,7 @@ def test_oracle_vs_reference_native_evaluator():
     assert abs(map32 - float(map_ref)) < 1e-6
 
 
-def test_bf16_pieces_sum_exactly_and_split6_is_fp32_grade():
+def test_split_pieces_sum_exactly_and_kept_products_are_fp32_grade():
     """the split-bf16 restatement: three bf16 pieces reproduce every fp32 value exactly, and the six kept piece
     products differ from the exact product sum by less than fp32 rounding of the result"""
     rng = np.random.RandomState(3)
@@ -92,12 +92,21 @@ def test_bf16_pieces_sum_exactly_and_split6_is_fp32_grade():
     g = np.abs(rng.randn(70, 768)).astype(np.float32)
     q64, g64 = q.astype(np.float64), g.astype(np.float64)
     exact = (q64 ** 2).sum(1)[:, None] + (g64 ** 2).sum(1)[None, :] - 2.0 * (q64 @ g64.T)
-    d6 = ev.sqeuclid_split_np(q, g, 6)
-    d3 = ev.sqeuclid_split_np(q, g, 3)
+    d6 = ev.sqeuclid_split_np(q, g, "bf16x3")
+    d3 = ev.sqeuclid_split_np(q, g, "bf16x2")
+    dh = ev.sqeuclid_split_np(q, g, "f16x2")
     scale = np.abs(q.astype(np.float64)) @ np.abs(g.astype(np.float64)).T      # sum |q_k g_k|
     assert np.max(np.abs(d6 - exact) / scale) < 2.0 ** -22
     assert np.max(np.abs(d3 - exact) / scale) < 2.0 ** -14
+    assert np.max(np.abs(dh - exact) / scale) < 2.0 ** -20
+    # rows of very different magnitude: the per-row power-of-two scaling keeps the fp16 pieces in range
+    qw = (q * np.exp2(rng.randint(-40, 40, size=(50, 1)))).astype(np.float32)
+    qw64 = qw.astype(np.float64)
+    exact_w = (qw64 ** 2).sum(1)[:, None] + (g64 ** 2).sum(1)[None, :] - 2.0 * (qw64 @ g64.T)
+    scale_w = np.abs(qw64) @ np.abs(g64).T
+    assert np.max(np.abs(ev.sqeuclid_split_np(qw, g, "f16x2") - exact_w) / (scale_w + (qw64 ** 2).sum(1)[:, None])) < 2.0 ** -20
     # integer-grid features are single-piece values: nothing is dropped
     qi = rng.randint(-3, 4, size=(9, 24)).astype(np.float32)
     gi = rng.randint(-3, 4, size=(11, 24)).astype(np.float32)
-    assert np.array_equal(ev.sqeuclid_split_np(qi, gi, 6), ev.sqeuclid_np(qi, gi).astype(np.float64))
+    for scheme in ("bf16x3", "bf16x2", "f16x2"):
+        assert np.array_equal(ev.sqeuclid_split_np(qi, gi, scheme), ev.sqeuclid_np(qi, gi).astype(np.float64))
