@@ -183,11 +183,15 @@ template <typename T, int MODE> struct StagedStoreEpi {
   }
 };
 
+// fp32 split-K slab of the weight gradient, staged through LDS like the distance matrix (evaluator.hip DistEpi): the
+// tile leaves as full 512-byte rows instead of 64-byte pieces scattered over 16 rows per store instruction.
+// WROWS = 64: 128-row tile in two 64-row halves (each exactly the 32 KB operand stage); WROWS = 32 (HALF_M): one.
 struct SlabEpi {
-  static constexpr bool kStaged = false;
+  static constexpr bool kStaged = true;
   float* out;
   int64_t ld;
   int M, N;
+  // direct form (register-staged gemm_tn: fp32 and the element-gather loaders)
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v) const {
     if (m >= M || n >= N) return;
     float* o = out + (int64_t)m * ld + n;
@@ -195,6 +199,44 @@ struct SlabEpi {
       *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
     } else {
       for (int r = 0; r < 4 && n + r < N; ++r) o[r] = v[r];
+    }
+  }
+  template <int WROWS, int FM>
+  __device__ __forceinline__ void finish(f32x4 (&acc)[FM][4], char* smem, int m0, int n0) const {
+    constexpr int HALVES = WROWS == 64 ? 2 : 1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int ch = t & 31, r0 = t >> 5;
+    const int col = n0 + ch * 4;
+    const bool vec_ok = (((uintptr_t)out | (uintptr_t)(ld * 4)) & 15) == 0 && col + 3 < N;
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+      __syncthreads();
+      if (HALVES == 1 || wm == h) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = (HALVES == 1 ? wm * WROWS : 0) + i * 16 + (lane & 15);
+            const int c = wn * 16 + j * 4 + (lane >> 4);
+            *(float4*)(smem + r * 512 + ((c ^ (r & 31)) << 4)) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pss = 0; pss < 8; ++pss) {
+        const int r = r0 + 8 * pss;
+        const int row = m0 + h * 64 + r;
+        if (row >= M || col >= N) continue;
+        const float4 v = *(const float4*)(smem + r * 512 + ((ch ^ (r & 31)) << 4));
+        float* o = out + (int64_t)row * ld + col;
+        if (vec_ok) {
+          *(float4*)o = v;
+        } else {
+          const float f[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4 && col + e < N; ++e) o[e] = f[e];
+        }
+      }
     }
   }
 };

@@ -508,11 +508,15 @@ __device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles
   }
   }
 
+  if constexpr (Epi::kStaged) {
+    epi.template finish<WROWS, FM>(acc, smem, m0, n0);
+  } else {
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      epi(m0 + wm * WROWS + i * 16 + (lane & 15), n0 + wn * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+      for (int j = 0; j < 4; ++j)
+        epi(m0 + wm * WROWS + i * 16 + (lane & 15), n0 + wn * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+  }
 }
 
 // ------------------------------------------------------------------ loaders
