@@ -35,6 +35,7 @@ struct DistEpi {
   int m, n, metric;
   const float* qsc;   // optional per-row powers of two that undo the operand scaling of the fp16 split (else null)
   const float* gsc;
+  int nt;             // non-temporal stores (outputs beyond the 256 MB of MALL: 4.8 instead of 4.0 TB/s)
   __device__ __forceinline__ float value(float v, float a, float b) const {
     return metric == 0 ? (a + b) + (-2.0f * v)      // distance.py:62-63
                        : 1.0f - v * a * b;          // distance.py:77-79 (a, b hold 1/max(|.|,eps))
@@ -82,8 +83,10 @@ struct DistEpi {
         }
         float* o = out + (int64_t)row * ldo + col;
         if (vec_ok) {
-          *(float4*)o = make_float4(value(v[0], a, gnv[0]), value(v[1], a, gnv[1]), value(v[2], a, gnv[2]),
-                                    value(v[3], a, gnv[3]));
+          typedef float f32x4v __attribute__((ext_vector_type(4)));
+          const f32x4v ov = {value(v[0], a, gnv[0]), value(v[1], a, gnv[1]), value(v[2], a, gnv[2]), value(v[3], a, gnv[3])};
+          if (nt) __builtin_nontemporal_store(ov, (f32x4v*)o);   // output larger than the caches: stream it
+          else *(f32x4v*)o = ov;
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void distmat_kernel(
   tile_map(tiles_m, tiles_n, 8, tm, tn);
   const int m0 = tm * 128, n0 = tn * 128;
   LoaderPlainNT<T, 4> la, lb;
-  DistEpi epi{out, qn, gn, ldo, m, n, metric, qsc, gsc};
+  DistEpi epi{out, qn, gn, ldo, m, n, metric, qsc, gsc, (int64_t)m * n * 4 > (256ll << 20) ? 1 : 0};
   if constexpr (sizeof(T) == 2) {   // single-stage LDS-DMA pipeline, 4 workgroups per CU (see conv.hip plan_gather)
     const int ch = nt_dma_chunk(threadIdx.x);
     la.init(q, d, m0, m, d, ch);
