@@ -32,6 +32,36 @@ __global__ void nchw_to_nhwc_kernel(const float* x0, const float* x1, const floa
   }
 }
 
+// the executor's stem layout (bf16, Cpad = 4, even padded width): one thread writes TWO adjacent padded pixels as one
+// 16-byte store and reads its (up to) 3 x 2 source values with 32-bit index arithmetic; a wave reads 512-byte runs of
+// each colour plane and writes 1 KB runs (the generic kernel above moves one 2-byte element per thread)
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_bf16_kernel(const float* x0, const float* x1, const float* x2,
+                                                                 bf16* out, int B, int C, int H, int W, int pad) {
+  const int z = blockIdx.y;
+  const float* x = z == 0 ? x0 : (z == 1 ? x1 : x2);
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad, Wh = Wp >> 1;
+  const int total = B * Hp * Wh;
+  uint4* o = (uint4*)(out + (int64_t)z * B * Hp * Wp * 4);
+  const int plane = H * W;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int wq = i % Wh;
+    const int t = i / Wh;
+    const int hp = t % Hp, b = t / Hp;
+    const int h = hp - pad, w = wq * 2 - pad;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)h < (unsigned)H) {
+      const float* src = x + ((int64_t)b * C * H + h) * W;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c >= C) break;
+        if ((unsigned)w < (unsigned)W) v[c] = src[c * plane + w];
+        if ((unsigned)(w + 1) < (unsigned)W) v[4 + c] = src[c * plane + w + 1];
+      }
+    }
+    o[i] = Vec16<bf16>::pack(v);
+  }
+}
+
 // MaxPool2d(kernel 3, stride 2, pad 1) over NHWC; arg = window-local index (0..8) of the first maximum
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out,
@@ -40,16 +70,16 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
   const int cprw = C / VEC;
-  const int64_t total = (int64_t)B * Ho * Wo * cprw;
+  const int total = B * Ho * Wo * cprw;   // < 2^31 (checked by the launcher): 32-bit index arithmetic
   x += z * x_gs;
   out += z * o_gs;
   arg += z * o_gs;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % cprw);
-    int64_t p = i / cprw;
-    const int q = (int)(p % Wo); p /= Wo;
-    const int pp = (int)(p % Ho);
-    const int b = (int)(p / Ho);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ch = i % cprw;
+    int p = i / cprw;
+    const int q = p % Wo; p /= Wo;
+    const int pp = p % Ho;
+    const int b = p / Ho;
     float best[VEC];
     int bi[VEC];
 #pragma unroll
@@ -90,16 +120,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
   const int cprw = C / VEC;
-  const int64_t total = (int64_t)B * Hi * Wi * cprw;
+  const int total = B * Hi * Wi * cprw;   // < 2^31 (checked by the launcher): 32-bit index arithmetic
   dout += z * o_gs;
   arg += z * o_gs;
   dx += z * x_gs;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % cprw);
-    int64_t p = i / cprw;
-    const int w = (int)(p % Wi); p /= Wi;
-    const int h = (int)(p % Hi);
-    const int b = (int)(p / Hi);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ch = i % cprw;
+    int p = i / cprw;
+    const int w = p % Wi; p /= Wi;
+    const int h = p % Hi;
+    const int b = p / Hi;
     float acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
@@ -552,6 +582,12 @@ extern "C" int ieee_nchw_to_nhwc3(const float* x_rgb, const float* x_ni, const f
   IEEE_REQUIRE(x_rgb && x_ni && x_ti && out, "nchw_to_nhwc3: null pointer");
   IEEE_REQUIRE(Cpad >= C && pad >= 0, "nchw_to_nhwc3: Cpad < C or negative padding");
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == IEEE_BF16 && Cpad == 4 && C <= 4 && ((W + 2 * pad) & 1) == 0 &&
+      B * (H + 2 * pad) * (W + 2 * pad) < (1ll << 30)) {
+    dim3 grid2(ew_blocks2(B * (H + 2 * pad) * ((W + 2 * pad) / 2)), 3);
+    nchw_to_nhwc4_bf16_kernel<<<grid2, 256, 0, st>>>(x_rgb, x_ni, x_ti, (bf16*)out, (int)B, (int)C, (int)H, (int)W, (int)pad);
+    return launch_status("nchw_to_nhwc4_bf16_kernel");
+  }
   dim3 grid(ew_blocks2(B * Cpad * (H + 2 * pad) * (W + 2 * pad)), 3);
   DISPATCH_T(dtype, (nchw_to_nhwc_kernel<float><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (float*)out, (int)B, (int)C, (int)H, (int)W, (int)Cpad, (int)pad)),
              (nchw_to_nhwc_kernel<bf16><<<grid, 256, 0, st>>>(x_rgb, x_ni, x_ti, (bf16*)out, (int)B, (int)C, (int)H, (int)W, (int)Cpad, (int)pad)));
@@ -562,6 +598,7 @@ extern "C" int ieee_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, 
                                      int64_t Hi, int64_t Wi, int64_t C, void* stream) {
   IEEE_REQUIRE(x && out && argmax, "maxpool_fwd: null pointer");
   IEEE_REQUIRE(C % vecw(dtype) == 0, "maxpool_fwd: C not a multiple of the vector width");
+  IEEE_REQUIRE(B * Hi * Wi * C < (1ll << 31), "maxpool_fwd: more than 2^31 elements per group");
   const int Ho = (int)((Hi + 2 - 3) / 2 + 1), Wo = (int)((Wi + 2 - 3) / 2 + 1);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(ew_blocks2(B * Ho * Wo * C / vecw(dtype)), (unsigned)groups);
@@ -574,6 +611,7 @@ extern "C" int ieee_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, 
 extern "C" int ieee_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int dtype, int64_t groups,
                                      int64_t B, int64_t Hi, int64_t Wi, int64_t C, void* stream) {
   IEEE_REQUIRE(dout && dx && argmax, "maxpool_bwd: null pointer");
+  IEEE_REQUIRE(B * Hi * Wi * C < (1ll << 31), "maxpool_bwd: more than 2^31 elements per group");
   const int Ho = (int)((Hi + 2 - 3) / 2 + 1), Wo = (int)((Wi + 2 - 3) / 2 + 1);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(ew_blocks2(B * Hi * Wi * C / vecw(dtype)), (unsigned)groups);
