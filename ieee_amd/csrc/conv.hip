@@ -486,7 +486,7 @@ struct PackDesc {
   int64_t dst_off, dst_gs;   // elements of T, relative to the workspace base given to the kernel
   int Co, Ci, R, S, ld, mode, Ci_src, S_src;
   int block_begin;           // first blockIdx.x of this descriptor
-  int pad_;                  // 0 = direct form, 1..3 = the LDS-tiled forms below
+  int pad_;                  // 0 = direct form, 1..3 = the LDS-tiled forms below, 4 = 1x1 forward (vector convert)
   int R_src, reserved_;      // rows of the fp32 source (R_src <= R: zero rows beyond)
 };
 template <typename T>
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
   }
   const PackDesc d = descs[lo];
   const int z = blockIdx.y;
-  __shared__ float lds[32 * 289];   // 36 KB, shared by the three tiled forms
+  __shared__ __attribute__((aligned(16))) float lds[32 * 289];   // 36 KB, shared by the three tiled forms
   const int t = threadIdx.x;
   if (d.pad_ == 1) {
     // 1x1 dgrad operand as a 64x64 LDS-tiled transpose: coalesced 256-B row reads of [co][ci], coalesced 16-byte
@@ -517,12 +517,14 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     }
     __syncthreads();
     T* dst = (T*)ws + d.dst_off + z * d.dst_gs + ((int64_t)tci * 64) * d.ld + tco * 64;
+    constexpr int VEC = 16 / (int)sizeof(T), CPR = 64 / VEC;   // one 16-byte store = VEC consecutive co of a ci row
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = (t >> 3) + 32 * i, r8 = (t & 7) * 8;   // dst row = ci (tile column), 8 consecutive co
-      T* o = dst + (int64_t)c * d.ld + r8;
+    for (int idx = t; idx < 64 * CPR; idx += 256) {
+      const int c = idx / CPR, r0 = (idx % CPR) * VEC;
+      float f[VEC];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(tile[r8 + e][c]);
+      for (int e = 0; e < VEC; ++e) f[e] = tile[r0 + e][c];
+      *(uint4*)(dst + (int64_t)c * d.ld + r0) = Vec16<T>::pack(f);
     }
     return;
   }
@@ -533,18 +535,30 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     const int chunks = d.Ci / 64, units = d.Co * chunks;
     const int u0 = (b - d.block_begin) * 4;
     const float* src = params + d.src_off + z * d.src_gs;
-    for (int idx = t; idx < 4 * 576; idx += 256) {
-      const int u = u0 + idx / 576, j = idx % 576;
-      if (u < units) lds[idx] = src[(int64_t)u * 576 + j];   // unit u = (co = u / chunks, chunk = u % chunks): contiguous
+    const float* s0 = src + (int64_t)u0 * 576;
+    if (((uintptr_t)s0 & 15) == 0) {
+      for (int idx = t; idx < 576; idx += 256) {               // 4 units x 144 float4
+        const int u = u0 + idx / 144;
+        if (u < units) *(float4*)(lds + idx * 4) = *(const float4*)(s0 + idx * 4);
+      }
+    } else {
+      for (int idx = t; idx < 4 * 576; idx += 256) {
+        const int u = u0 + idx / 576;
+        if (u < units) lds[idx] = s0[idx];   // unit u = (co = u / chunks, chunk = u % chunks): contiguous
+      }
     }
     __syncthreads();
     T* dst = (T*)ws + d.dst_off + z * d.dst_gs;
-    for (int idx = t; idx < 4 * 576; idx += 256) {
-      const int ul = idx / 576, r = idx % 576, tap = r >> 6, c = r & 63;
+    constexpr int VEC = 16 / (int)sizeof(T), CPR = 64 / VEC;   // 16-byte stores: VEC consecutive channels of a tap
+    for (int idx = t; idx < 4 * 9 * CPR; idx += 256) {
+      const int ul = idx / (9 * CPR), r = idx % (9 * CPR), tap = r / CPR, c0 = (r % CPR) * VEC;
       const int u = u0 + ul;
       if (u >= units) continue;
       const int co = u / chunks, ch = u - co * chunks;
-      dst[(int64_t)co * d.ld + tap * d.Ci + ch * 64 + c] = from_f32<T>(lds[ul * 576 + c * 9 + tap]);
+      float f[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) f[e] = lds[ul * 576 + (c0 + e) * 9 + tap];
+      *(uint4*)(dst + (int64_t)co * d.ld + tap * d.Ci + ch * 64 + c0) = Vec16<T>::pack(f);
     }
     return;
   }
@@ -553,16 +567,45 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
     const int tiles_ci = d.Ci / 32;
     const int tb = b - d.block_begin, tco = tb / tiles_ci, tci = tb - tco * tiles_ci;
     const float* src = params + d.src_off + z * d.src_gs + ((int64_t)tco * 32 * d.Ci + tci * 32) * 9;
-    for (int idx = t; idx < 32 * 288; idx += 256) {
-      const int co = idx / 288, j = idx % 288;
-      lds[co * 289 + j] = src[(int64_t)co * d.Ci * 9 + j];   // lds[co][ci*9 + tap], rows padded to 289 (bank spread)
+    if (((uintptr_t)src & 15) == 0) {
+      for (int idx = t; idx < 32 * 72; idx += 256) {           // 32 rows x 72 float4
+        const int co = idx / 72, j = (idx % 72) * 4;
+        const float4 v = *(const float4*)(src + (int64_t)co * d.Ci * 9 + j);
+        float* l = lds + co * 289 + j;                         // rows padded to 289 (bank spread): scalar LDS writes
+        l[0] = v.x; l[1] = v.y; l[2] = v.z; l[3] = v.w;
+      }
+    } else {
+      for (int idx = t; idx < 32 * 288; idx += 256) {
+        const int co = idx / 288, j = idx % 288;
+        lds[co * 289 + j] = src[(int64_t)co * d.Ci * 9 + j];   // lds[co][ci*9 + tap]
+      }
     }
     __syncthreads();
     T* dst = (T*)ws + d.dst_off + z * d.dst_gs;
-    for (int idx = t; idx < 32 * 288; idx += 256) {
-      const int co = idx & 31, r = idx >> 5, tap = r % 9, ci = r / 9;   // 32 consecutive threads = 32 co of one (ci, tap)
-      dst[(int64_t)(tci * 32 + ci) * d.ld + tap * d.Co + tco * 32 + co] = from_f32<T>(lds[co * 289 + ci * 9 + tap]);
+    constexpr int VEC = 16 / (int)sizeof(T), CPR = 32 / VEC;   // 16-byte stores: VEC consecutive co of one (ci, tap)
+    for (int idx = t; idx < 288 * CPR; idx += 256) {
+      const int co0 = (idx % CPR) * VEC, r = idx / CPR, tap = r % 9, ci = r / 9;
+      float f[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) f[e] = lds[(co0 + e) * 289 + ci * 9 + tap];
+      *(uint4*)(dst + (int64_t)(tci * 32 + ci) * d.ld + tap * d.Co + tco * 32 + co0) = Vec16<T>::pack(f);
     }
+    return;
+  }
+  if (d.pad_ == 4) {
+    // 1x1 forward operand: same layout, only the dtype changes -- 16-byte stores (one element per thread was 4x slower)
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const unsigned total = (unsigned)d.Co * (unsigned)d.ld;
+    const unsigned i = ((unsigned)(b - d.block_begin) * 256u + threadIdx.x) * VEC;
+    if (i >= total) return;
+    const float* src = params + d.src_off + z * d.src_gs + i;
+    float f[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e += 4) {
+      const float4 v = *(const float4*)(src + e);
+      f[e] = v.x; f[e + 1] = v.y; f[e + 2] = v.z; f[e + 3] = v.w;
+    }
+    *(uint4*)((T*)ws + d.dst_off + z * d.dst_gs + i) = Vec16<T>::pack(f);
     return;
   }
   const unsigned rows = d.mode == 0 ? d.Co : d.Ci;

@@ -1046,9 +1046,15 @@ extern "C" int ieee_net_bind(void* handle, float* params, float* grads, float* b
         // 3x3 operands: LDS-tiled forms 2 (forward) / 3 (dgrad) of pack_all_kernel
         const bool k3 = u.R == 3 && u.S == 3 && u.Ci == u.Ci_src && u.S == u.S_src && u.Co % 32 == 0 && u.Ci % 64 == 0 &&
                         ld == 9 * (mode == 0 ? u.Ci : u.Co);
-        d.pad_ = tiled ? 1 : (k3 ? (mode == 0 ? 2 : 3) : 0);
+        // 1x1 forward operand with unpadded rows: pure dtype conversion, 16 bytes out per thread (form 4); needs the
+        // fp32 source 16-byte aligned (slot offsets and group strides multiples of 4 elements)
+        const int vec = 16 / es;
+        const bool conv1 = mode == 0 && u.R == 1 && u.S == 1 && ld == u.Ci && u.Ci == u.Ci_src && (u.Co * ld) % vec == 0 &&
+                           d.src_off % 4 == 0 && d.src_gs % 4 == 0;
+        d.pad_ = tiled ? 1 : (k3 ? (mode == 0 ? 2 : 3) : (conv1 ? 4 : 0));
         blocks += tiled ? (u.Co / 64) * (u.Ci / 64)
-                        : (k3 ? (mode == 0 ? cdiv(u.Co * (u.Ci / 64), 4) : (u.Co / 32) * (u.Ci / 32)) : cdiv(rows * ld, 256));
+                        : (k3 ? (mode == 0 ? cdiv(u.Co * (u.Ci / 64), 4) : (u.Co / 32) * (u.Ci / 32))
+                              : (conv1 ? cdiv(rows * ld, 256 * vec) : cdiv(rows * ld, 256)));
         tab.push_back(d);
       }
     }
