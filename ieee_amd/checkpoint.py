@@ -20,42 +20,45 @@ from .engine import save_checkpoint   # noqa: F401  (same function, reference to
 RESNET50_FILE = "resnet50-19c8e357.pth"      # the file the reference downloads (resnet.py:25-26)
 
 
+def _torch_load(path, **extra):
+    device = None if torch.cuda.is_available() else 'cpu'      # CPU-only hosts can open GPU-written files
+    return torch.load(path, map_location=device, weights_only=False, **extra)
+
+
 def load_checkpoint(fpath):
-    """torchtools.py:61-95 (python2 pickles handled the same way)"""
+    """Reads a checkpoint file written by either implementation (reference torchtools.py:61-95): ValueError for a
+    missing argument, FileNotFoundError for a missing file; a python-2 pickle is retried with latin-1 decoding."""
     if fpath is None:
-        raise ValueError('File path is None')
-    if not osp.exists(fpath):
-        raise FileNotFoundError('File is not found at "{}"'.format(fpath))
-    map_location = None if torch.cuda.is_available() else 'cpu'
+        raise ValueError('no checkpoint path given (fpath is None)')
+    if not osp.isfile(fpath):
+        raise FileNotFoundError('no checkpoint file at "{}"'.format(fpath))
     try:
-        checkpoint = torch.load(fpath, map_location=map_location, weights_only=False)
+        return _torch_load(fpath)
     except UnicodeDecodeError:
-        pickle.load = partial(pickle.load, encoding="latin1")
-        pickle.Unpickler = partial(pickle.Unpickler, encoding="latin1")
-        checkpoint = torch.load(fpath, pickle_module=pickle, map_location=map_location, weights_only=False)
+        legacy = type(pickle)('pickle_latin1')                 # a pickle look-alike module that decodes py2 strings
+        legacy.__dict__.update(pickle.__dict__)
+        legacy.load = partial(pickle.load, encoding='latin1')
+        legacy.Unpickler = partial(pickle.Unpickler, encoding='latin1')
+        return _torch_load(fpath, pickle_module=legacy)
     except Exception:
-        print('Unable to load checkpoint from "{}"'.format(fpath))
+        print('could not read the checkpoint "{}"'.format(fpath))
         raise
-    return checkpoint
 
 
 def resume_from_checkpoint(fpath, model, optimizer=None, scheduler=None):
-    """torchtools.py:98-133; returns start_epoch"""
-    print('Loading checkpoint from "{}"'.format(fpath))
-    checkpoint = load_checkpoint(fpath)
-    model.load_state_dict(checkpoint['state_dict'])
-    print('Loaded model weights')
-    if optimizer is not None and 'optimizer' in checkpoint.keys():
-        optimizer.load_state_dict(checkpoint['optimizer'])
-        print('Loaded optimizer')
-    if scheduler is not None and 'scheduler' in checkpoint.keys():
-        scheduler.load_state_dict(checkpoint['scheduler'])
-        print('Loaded scheduler')
-    start_epoch = checkpoint['epoch']
-    print('Last epoch = {}'.format(start_epoch))
-    if 'rank1' in checkpoint.keys():
-        print('Last rank1 = {:.1%}'.format(checkpoint['rank1']))
-    return start_epoch
+    """Restores model (and, when given and present, optimizer / scheduler) state and returns the epoch to continue
+    from (reference torchtools.py:98-133; same checkpoint keys: state_dict, optimizer, scheduler, epoch, rank1)."""
+    ckpt = load_checkpoint(fpath)
+    restored = ['model']
+    model.load_state_dict(ckpt['state_dict'])
+    for name, target in (('optimizer', optimizer), ('scheduler', scheduler)):
+        if target is not None and name in ckpt:
+            target.load_state_dict(ckpt[name])
+            restored.append(name)
+    epoch = ckpt['epoch']
+    note = ', rank-1 then {:.1%}'.format(ckpt['rank1']) if 'rank1' in ckpt else ''
+    print('resumed {} from "{}": epoch {}{}'.format(' + '.join(restored), fpath, epoch, note))
+    return epoch
 
 
 def _matching(model_dict, state_dict, prefix=''):
