@@ -147,8 +147,13 @@ def bench_distmat(device):
     torch.cuda.synchronize()
     rk_ms = e0.elapsed_time(e1) / 5
     out["rank_kernels_ms"] = rk_ms
+    rk_traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_evaluator.json)
+    try:
+        rk_traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_evaluator.json")))["rank_query_fast"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     out["roofline_rank"] = {"bound": "hbm", "achieved": 4.0 * Q * G / rk_ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": 4.0 * Q * G / rk_ms / 1e6 / PEAK_HBM_GBS, "traffic": None}
+                            "frac": 4.0 * Q * G / rk_ms / 1e6 / PEAK_HBM_GBS, "traffic": rk_traffic}
     out["workload"] = "10000 x 100000 x 768 (BASELINE config 4)"
     out["roofline_fp32"] = {"bound": "mfma", "achieved": out["fp32"]["GFLOP/s"] / 1e3, "peak": PEAK_F32_TFLOPS,
                             "unit": "TFLOP/s", "frac": out["fp32"]["GFLOP/s"] / 1e3 / PEAK_F32_TFLOPS}
