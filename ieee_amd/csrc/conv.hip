@@ -154,6 +154,10 @@ template <typename T, int MODE> struct StagedStoreEpi {
               Vec16<T>::unpack(*(const uint4*)(bmask + (int64_t)m * ld + n), mk);
 #pragma unroll
               for (int e = 0; e < VEC; ++e) f[e] = mk[e] > 0.f ? f[e] : 0.f;
+              // the MASKED gradient g = dout * [out > 0] is what leaves the tile: the BatchNorm backward of that unit then
+              // reads g and y only (no second pass over the mask tensor, no separate g output) -- 12 instead of 20 bytes
+              // per element of the widest tensors of every block
+              v = Vec16<T>::pack(f);
             } else if (bstats != nullptr) {
 #pragma unroll
               for (int e = 0; e < VEC; ++e) f[e] = (yv[e] * bstats[2 * N + n + e] + bstats[3 * N + n + e]) > 0.f ? f[e] : 0.f;

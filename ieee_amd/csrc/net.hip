@@ -784,8 +784,15 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     Xout = P(N.gbuf[set_of(bi - 1)]);
     const ConvUnit &c1 = N.units[b.c1], &c2 = N.units[b.c2], &c3 = N.units[b.c3];
     const void* xin = bi == 0 ? P(N.pool) : P(N.units[N.blocks[bi - 1].c3].a);
-    // out = relu(bn3(y3) + identity): g = dout*[out>0] -> Q ; dy3 -> X (in place)
-    IEEE_TRY(bn_bwd(c3, X, P(c3.a), X, Q));
+    // out = relu(bn3(y3) + identity): g = dout*[out>0] is the identity-branch gradient, dy3 the conv3 one.
+    // bf16, every block but the last: the dgrad that produced X stored it already masked (X = g, conv.hip MODE 2 with
+    // the mask tensor), so the BatchNorm backward reads g and y3 only and writes dy3 into Q; the two names then swap.
+    if (dt == IEEE_BF16 && bi + 1 < (int)N.blocks.size()) {
+      IEEE_TRY(bn_bwd(c3, X, nullptr, Q, nullptr));
+      std::swap(X, Q);
+    } else {
+      IEEE_TRY(bn_bwd(c3, X, P(c3.a), X, Q));   // g -> Q ; dy3 -> X (in place)
+    }
     const int bslot = 4 + (bi == 0 ? 0 : (bi == 3 ? 1 : (bi == 7 ? 2 : 3)));
     const bool par_ds = b.ds >= 0 && branch_enabled(2);
     if (par_ds) {   // the downsample branch's backward beside the conv3 -> conv2 -> conv1 chain

@@ -144,7 +144,9 @@ int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* dx, const vo
 /* bn_partial != NULL (bf16 only): dx is the gradient w.r.t. the output of a BN(+ReLU) whose input is bn_y; the
  * dgrad epilogue also emits that BN's backward sums [2][Ci][rblocks] (sum g, sum g*y; g = dx * [mask], mask from
  * bn_mask > 0, or from bn_y*scale+shift > 0 with bn_stats = that BN's [4][Ci] stats, or none), rblocks =
- * ceil(N*Hi*Wi/128): pass it to ieee_bn2d_bwd(stats_rblocks) and the separate reduction pass disappears */
+ * ceil(N*Hi*Wi/128): pass it to ieee_bn2d_bwd(stats_rblocks) and the separate reduction pass disappears.
+ * With bn_mask (the ReLU behind a residual add, resnet.py:181-182) dx is stored ALREADY MASKED, dx = g: the
+ * BatchNorm backward that follows then takes out_mask = NULL and reads g and y only */
 
 /* dw (fp32, OIHW, the layout of param.grad) = or += sum over pixels; deterministic split-K:
  * partial slabs in `work` (size from the query below) are reduced in a fixed order */

@@ -171,8 +171,13 @@ def test_fused_bn_partials_in_conv_epilogues():
                                       1, 1, dy[0].numel(), wpd.stride(0), dx[0].numel(), L.ptr(p2), L.ptr(ypre),
                                       L.ptr(amask) if mode == "mask" else None, L.ptr(stats) if mode == "stats" else None,
                                       L.stream()))
-        assert torch.equal(dx, dx_ref)
-        d, yv = dx.float().view(G, M, Ci), ypre.float().view(G, M, Ci)
+        # mask-tensor mode stores the MASKED gradient g = (dgrad + addend) * [mask > 0] (what the BatchNorm backward of
+        # the block output consumes); the other two modes store dgrad + addend unchanged
+        if mode == "mask":
+            assert torch.equal(dx, dx_ref * (amask > 0).to(dt))
+        else:
+            assert torch.equal(dx, dx_ref)
+        d, yv = dx_ref.float().view(G, M, Ci), ypre.float().view(G, M, Ci)
         if mode == "mask":
             gq = d * (amask.float().view(G, M, Ci) > 0)
         elif mode == "stats":
