@@ -46,6 +46,36 @@ def make_batch(B, seed, device):
             "timeid": torch.zeros(B, dtype=torch.long)}
 
 
+def host_cores():
+    """(physical cores, logical CPUs) of the host: distinct (package, core) pairs of /proc/cpuinfo"""
+    logical = os.cpu_count() or 1
+    try:
+        pairs, pkg = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pkg = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((pkg, line.split(":")[1].strip()))
+        return (len(pairs) or None), logical
+    except Exception:
+        return None, logical
+
+
+def committed_traffic(key, field="hbm_bytes_per_launch"):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/rNN_pmc_*.json); these come from separate
+    rocprofv3 --pmc passes (FETCH_SIZE doubled per the guide's gfx950 note, + WRITE_SIZE), NOT from this run"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if key in d and field in d[key]:
+                return d[key][field], "%s (separate rocprofv3 --pmc passes%s; not measured in this run)" % (
+                    os.path.relpath(path, ROOT), ", build " + d["_build"] if "_build" in d else "")
+        except Exception:
+            continue
+    return None, None
+
+
 def cpu_baseline_train(seconds_budget=25.0):
     """oracle (stock torch CPU ops arranged like the reference) on a bounded sample: B=8 steps"""
     from ieee_amd import detgen
@@ -61,6 +91,7 @@ def cpu_baseline_train(seconds_budget=25.0):
     # and is ~5x slower than 16 threads; the baseline uses 16 and says so
     threads = min(16, torch.get_num_threads())
     torch.set_num_threads(threads)
+    phys, logical = host_cores()
     om.train_step(sd, xs, pids, C)                       # warm-up
     t0, n = time.time(), 0
     while n < 2 or (time.time() - t0 < seconds_budget and n < 6):
@@ -68,7 +99,9 @@ def cpu_baseline_train(seconds_budget=25.0):
         n += 1
     dt = (time.time() - t0) / n
     return {"value": B / dt, "unit": "3-modal images/s", "cores": threads, "kind": "port",
-            "sample": "%d oracle train steps at batch %d (fp32, torch CPU ops, %d threads), %.2f s/step" % (n, B, threads, dt)}
+            "host_physical_cores": phys, "host_logical_cpus": logical,
+            "sample": "%d oracle train steps at batch %d (fp32, torch CPU ops, %d threads of a host with %s physical cores / "
+                      "%d logical CPUs), %.2f s/step" % (n, B, threads, phys, logical, dt)}
 
 
 def bench_distmat(device):
@@ -147,13 +180,9 @@ def bench_distmat(device):
     torch.cuda.synchronize()
     rk_ms = e0.elapsed_time(e1) / 5
     out["rank_kernels_ms"] = rk_ms
-    rk_traffic = None   # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_evaluator.json)
-    try:
-        rk_traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_evaluator.json")))["rank_query_fast"]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    rk_traffic, rk_src = committed_traffic("rank_query_fast")
     out["roofline_rank"] = {"bound": "hbm", "achieved": 4.0 * Q * G / rk_ms / 1e6, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": 4.0 * Q * G / rk_ms / 1e6 / PEAK_HBM_GBS, "traffic": rk_traffic}
+                            "frac": 4.0 * Q * G / rk_ms / 1e6 / PEAK_HBM_GBS, "traffic": rk_traffic, "traffic_source": rk_src}
     out["workload"] = "10000 x 100000 x 768 (BASELINE config 4)"
     out["roofline_fp32"] = {"bound": "mfma", "achieved": out["fp32"]["GFLOP/s"] / 1e3, "peak": PEAK_F32_TFLOPS,
                             "unit": "TFLOP/s", "frac": out["fp32"]["GFLOP/s"] / 1e3 / PEAK_F32_TFLOPS}
@@ -176,12 +205,13 @@ def bench_distmat(device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # >= 50 timed steps after 10 warm-up steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="triples per GPU (BASELINE config 2/3: 64)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-distmat", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the short fp32 parity-mode throughput leg")
     args = ap.parse_args()
 
     from ieee_amd import _lib, dist as ddp
@@ -201,6 +231,7 @@ def main():
                         compute_dtype=cdt, device=device)
     opt = build_optimizer(model, optim="sgd", lr=1e-3, weight_decay=5e-4, momentum=0.9)
     engine = Image3MEngine(_FakeDM(C), model, opt, margin=1, weight_m=1, weight_x=1, use_gpu=True, label_smooth=True)
+    engine.dp_presharded = True          # weak scaling: every rank generates its own 64 triples (identity-aligned)
     model.train()
     B = args.batch
     batch = make_batch(B, seed=rank, device=device)
@@ -236,15 +267,12 @@ def main():
     g_ms, g_fl, g_n, w_ms, w_fl, w_n = list(out6)
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-    traffic = None      # HBM bytes per launch of this kernel from the committed PMC passes (rocprofv3 --pmc
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # FETCH_SIZE / WRITE_SIZE, FETCH doubled per guide)
-    if args.dtype == "bf16" and B == 64 and os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath))["conv_gather"]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    traffic = traffic_src = None
+    if args.dtype == "bf16" and B == 64:
+        traffic, traffic_src = committed_traffic("conv_gather")
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": traffic, "kernel": "conv_gather_kernel (implicit-GEMM forward + dgrad)",
+                "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "conv_gather_kernel (implicit-GEMM forward + dgrad)",
                 "launches": int(g_n), "avg_launch_us": g_ms * 1e3 / max(g_n, 1),
                 "flops_per_launch": g_fl / max(g_n, 1),
                 "wgrad": {"achieved": (w_fl / (w_ms * 1e-3) / 1e12) if w_ms > 0 else 0.0, "launches": int(w_n),
@@ -274,10 +302,32 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train()
-        if world == 1 and not args.no_distmat:
+        if world == 1 and (not args.no_distmat or not args.no_fp32):
             del engine, net
             model._nets.clear()
             torch.cuda.empty_cache()
+        if world == 1 and args.dtype == "bf16" and not args.no_fp32:
+            # the fp32 PARITY mode (exact fp32 MFMA end to end: the mode that meets north_star's 1e-3 contract), same
+            # workload, a short run: the headline `value` above is the bf16 speed mode
+            m32 = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, use_gpu=True,
+                              compute_dtype=torch.float32, device=device)
+            e32 = Image3MEngine(_FakeDM(C), m32, build_optimizer(m32, optim="sgd", lr=1e-3, weight_decay=5e-4, momentum=0.9),
+                                margin=1, weight_m=1, weight_x=1, use_gpu=True, label_smooth=True)
+            m32.train()
+            for _ in range(2):
+                e32.forward_backward(batch)
+            torch.cuda.synchronize()
+            t1, n32 = time.time(), 6
+            for _ in range(n32):
+                e32.forward_backward(batch)
+            torch.cuda.synchronize()
+            d32 = (time.time() - t1) / n32
+            line["fp32_parity_mode"] = {"value": B / d32, "unit": "3-modal images/s", "ms_per_step": d32 * 1e3, "steps": n32,
+                                        "whole_step_frac_of_fp32_mfma_peak": B / d32 * TRAIN_GFLOP_PER_TRIPLE * 1e9 /
+                                        (PEAK_F32_TFLOPS * 1e12)}
+            del e32, m32
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_distmat:
             line["distmat"] = bench_distmat(device)
         print(json.dumps(line))
     if world > 1:

@@ -15,9 +15,26 @@ from functools import partial
 
 import torch
 
-from .engine import save_checkpoint   # noqa: F401  (same function, reference torchtools.py:20-58)
 
 RESNET50_FILE = "resnet50-19c8e357.pth"      # the file the reference downloads (resnet.py:25-26)
+
+
+def save_checkpoint(state, save_dir, is_best=False, remove_module_from_keys=False):
+    """Writes `state` (keys as in the reference: state_dict, epoch, mAP / rank1, optimizer, scheduler) to
+    <save_dir>/model.pth.tar-<epoch>, the file name resume_from_checkpoint / load_pretrained_weights of either
+    implementation expect (reference torchtools.py:20-58); is_best also leaves a copy as model-best.pth.tar."""
+    os.makedirs(save_dir, exist_ok=True)
+    if remove_module_from_keys:        # weights saved from inside nn.DataParallel
+        state = dict(state)
+        state['state_dict'] = OrderedDict((name[len('module.'):] if name.startswith('module.') else name, tensor)
+                                          for name, tensor in state['state_dict'].items())
+    target = osp.join(save_dir, 'model.pth.tar-%s' % state['epoch'])
+    torch.save(state, target)
+    print('Checkpoint saved to "{}"'.format(target))
+    if is_best:
+        import shutil
+        shutil.copy(target, osp.join(save_dir, 'model-best.pth.tar'))
+    return target
 
 
 def _torch_load(path, **extra):

@@ -4,7 +4,6 @@ data/datasets/dataset.py:320-351, utils/tools.py:98-119).  On-disk format: <root
 (PIL 'RGB'); resize / flip / normalisation happen on the device for the whole batch (transforms.DeviceTransform)."""
 import glob
 import os.path as osp
-import warnings
 
 import numpy as np
 from PIL import Image
@@ -12,17 +11,15 @@ from torch.utils.data import Dataset
 
 
 def read_image(path):
-    """tools.py:98-119: PIL open + convert('RGB'), retrying on IOError"""
-    got_img = False
+    """decoded 'RGB' PIL image; a missing file is an IOError, a failed read is retried like the reference does
+    (utils/tools.py:98-119: network file systems hiccup)"""
     if not osp.exists(path):
         raise IOError('"{}" does not exist'.format(path))
-    while not got_img:
+    while True:
         try:
-            img = Image.open(path).convert('RGB')
-            got_img = True
+            return Image.open(path).convert('RGB')
         except IOError:
             print('IOError incurred when reading "{}". Will redo. Don\'t worry. Just chill.'.format(path))
-    return img
 
 
 def _file_name(path):
@@ -47,41 +44,42 @@ class MultiModalImageDataset(Dataset):
         return {'img': imgs, 'pid': pid, 'camid': camid, 'impath': list(img_path), 'timeid': timeid}
 
 
+def _parse_name(name):
+    """<pid6>_cam<X>_...: (identity, zero-based camera)"""
+    fields = name.split('_')
+    return int(fields[0][:6]), int(fields[1][3]) - 1
+
+
 class RGBNT201(object):
+    """<root>/RGBNT201/train_171 for training, <root>/RGBNT201/test for BOTH query and gallery (the evaluator's
+    same-identity-same-camera filter removes the self match): reference data/datasets/image/RGBNT201.py:13-79"""
     dataset_dir = 'RGBNT201'
+    splits = (('train', 'train_171', True), ('query', 'test', False), ('gallery', 'test', False))
 
     def __init__(self, root='', **kwargs):
         self.root = osp.abspath(osp.expanduser(root))
-        self.dataset_dir = osp.join(self.root, self.dataset_dir)
-        self.data_dir = self.dataset_dir
-        if not osp.isdir(self.data_dir):
-            warnings.warn('The current data structure is deprecated.')
-        self.train_dir = osp.join(self.data_dir, 'train_171')
-        self.query_dir = osp.join(self.data_dir, 'test')
-        self.gallery_dir = osp.join(self.data_dir, 'test')
-        for f in (self.data_dir, self.train_dir, self.query_dir, self.gallery_dir):
-            if not osp.exists(f):
-                raise RuntimeError('"{}" is not found'.format(f))
-        self.train = self.process_dir(self.train_dir, relabel=True)
-        self.query = self.process_dir(self.query_dir, relabel=False)
-        self.gallery = self.process_dir(self.gallery_dir, relabel=False)
-        self.num_train_pids = len(set(d[1] for d in self.train))
-        self.num_train_cams = len(set(d[2] for d in self.train))
+        self.dataset_dir = self.data_dir = osp.join(self.root, self.dataset_dir)
+        needed = [self.data_dir]
+        for split, folder, _ in self.splits:
+            setattr(self, split + '_dir', osp.join(self.data_dir, folder))
+            needed.append(getattr(self, split + '_dir'))
+        for path in needed:
+            if not osp.exists(path):
+                raise RuntimeError('"{}" is not found'.format(path))
+        for split, _, relabel in self.splits:
+            setattr(self, split, self.process_dir(getattr(self, split + '_dir'), relabel=relabel))
+        self.num_train_pids = len({rec[1] for rec in self.train})
+        self.num_train_cams = len({rec[2] for rec in self.train})
 
     def process_dir(self, dir_path, relabel=False):
-        """RGBNT201.py:47-79 (pid = first 6 characters, camid = 4th character of the second '_' field, minus 1)"""
-        img_paths_RGB = glob.glob(osp.join(dir_path, 'RGB', '*.jpg'))
-        pid_container = set()
-        for p in img_paths_RGB:
-            pid_container.add(int(_file_name(p).split('_')[0][0:6]))
-        pid2label = {pid: label for label, pid in enumerate(pid_container)}
-        data = []
-        for p in img_paths_RGB:
-            name = _file_name(p)
-            img = [p, osp.join(dir_path, 'NI', name), osp.join(dir_path, 'TI', name)]
-            pid = int(name.split('_')[0][0:6])
-            camid = int(name.split('_')[1][3]) - 1
-            if relabel:
-                pid = pid2label[pid]
-            data.append((img, pid, camid, 0))
-        return data
+        """one record per RGB file: ([RGB, NI, TI] paths with the same file name, pid, camid, 0).  relabel maps the
+        identities to 0..n-1 in the iteration order of a set of ints, exactly as the reference's
+        `{pid: label for label, pid in enumerate(pid_container)}` does (RGBNT201.py:49-54)."""
+        names = [(_file_name(p), p) for p in glob.glob(osp.join(dir_path, 'RGB', '*.jpg'))]
+        label_of = {pid: label for label, pid in enumerate({_parse_name(n)[0] for n, _ in names})}
+        records = []
+        for name, rgb_path in names:
+            pid, cam = _parse_name(name)
+            paths = [rgb_path] + [osp.join(dir_path, folder, name) for folder in ('NI', 'TI')]
+            records.append((paths, label_of[pid] if relabel else pid, cam, 0))
+        return records

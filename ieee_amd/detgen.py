@@ -97,3 +97,26 @@ def generate_images(batch: int, seed: int = 0, height: int = 256, width: int = 1
     torchreid/data/transforms.py:269-272), order [RGB, NI, TI]."""
     return [det_tensor("img.%s" % m, (batch, 3, height, width), seed, "normal")
             for m in ("RGB", "NI", "TI")]
+
+
+def generate_identity_images(pids, cams, seed: int = 0, height: int = 256, width: int = 128, noise: float = 0.25):
+    """Three [n,3,H,W] float32 tensors whose content depends on the identity: per (identity, modality, channel) a
+    constant level and a vertical ramp, a small per-camera level, plus N(0, noise^2) pixel noise.  Gives the evaluation
+    tests query / gallery sets whose descriptors separate by identity (pure-noise images all pool to nearly the same
+    descriptor, and their distances are rounding noise).  Exact arithmetic only, like everything in this module."""
+    pids = [int(p) for p in pids]
+    cams = [int(c) for c in cams]
+    n = len(pids)
+    base = generate_images(n, seed, height, width)
+    ramp = ((np.arange(height, dtype=np.float64) / float(height - 1)) - 0.5) * 2.0          # -1 .. 1 down the image
+    out = []
+    for m, x in enumerate(base):
+        x = x.astype(np.float64) * noise
+        for i in range(n):
+            lv = det_uniform("id.level.%d" % pids[i], 9, seed=0)[3 * m:3 * m + 3] * 2.0 - 1.0
+            sl = det_uniform("id.slope.%d" % pids[i], 9, seed=0)[3 * m:3 * m + 3] * 2.0 - 1.0
+            cl = det_uniform("cam.level.%d" % cams[i], 9, seed=0)[3 * m:3 * m + 3] * 0.2 - 0.1
+            for c in range(3):
+                x[i, c] += (lv[c] + cl[c]) + sl[c] * ramp[:, None]
+        out.append(x.astype(np.float32))
+    return out

@@ -83,8 +83,59 @@ def allreduce_sum_(flat):
     return flat
 
 
-def ce_grad_scale():
-    return 1.0 / world_size()
+_global_rows = {}
+
+
+def global_rows(local_rows):
+    """sum of the ranks' batch sizes (one tiny all-reduce, cached per local size: loaders give every rank the same
+    size sequence)"""
+    if world_size() == 1:
+        return int(local_rows)
+    key = (int(local_rows), world_size())
+    if key not in _global_rows:
+        t = torch.tensor([float(local_rows)], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _global_rows[key] = int(round(float(t.item())))
+    return _global_rows[key]
+
+
+def ce_grad_scale(local_rows=None, total_rows=None):
+    """Factor on this rank's cross-entropy so that the SUM of the ranks' gradients is the gradient of the reference's
+    batch MEAN over the global batch (cross_entropy_loss.py:50): B_local / B_global -- 1/world only when every rank
+    holds the same number of rows (shard_bounds hands out uneven shards when the identities do not divide)."""
+    if world_size() == 1:
+        return 1.0
+    if local_rows is None:
+        return 1.0 / world_size()
+    if total_rows is None:
+        total_rows = global_rows(local_rows)
+    return float(local_rows) / float(total_rows)
+
+
+def sync_replicas(model, optimizer=None, buffers_only=False, src=0):
+    """Every rank takes rank `src`'s parameters, running statistics and counters (and a fused optimizer's state): the
+    replicas start identical whatever each process drew at construction, and an evaluation after training uses ONE set
+    of BatchNorm running statistics -- rank 0's, which is what nn.DataParallel keeps (the statistics themselves stay
+    rank-local during training).  The reference gets both for free from its per-step broadcast."""
+    if world_size() == 1:
+        return
+    flats = [model._flat_buffers, model._flat_counters]
+    if not buffers_only:
+        flats.insert(0, model._flat_params)
+        if optimizer is not None and hasattr(optimizer, "flat_state"):
+            flats.extend(optimizer.flat_state())
+    gloo = dist.get_backend() == "gloo"
+    for t in flats:
+        if gloo and t.is_cuda:              # gloo stages device tensors through the host anyway
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src)
+    if hasattr(model, "invalidate_eval_cache"):
+        model.invalidate_eval_cache()
 
 
 def reduce_summary_(vec):
@@ -92,6 +143,43 @@ def reduce_summary_(vec):
     if world_size() > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     return vec
+
+
+def gather_feature_batches(local, rows_per_batch, width, device):
+    """Sharded feature extraction (SURVEY.md §8e row 2): rank r ran the forward for loader batches r, r + world, ...;
+    `local` maps its batch indices to [rows, width] fp32 tensors.  ONE all_gather of the (padded) per-rank blocks gives
+    every rank the full [sum(rows), width] matrix in loader order."""
+    world, me = world_size(), rank()
+    n = len(rows_per_batch)
+    per_rank = [sum(rows_per_batch[r::world]) for r in range(world)]
+    pad = max(per_rank) if per_rank else 0
+    mine = torch.zeros((max(pad, 1), width), dtype=torch.float32, device=device)
+    pos = 0
+    for b in range(me, n, world):
+        f = local[b]
+        mine[pos:pos + f.shape[0]] = f
+        pos += f.shape[0]
+    if world == 1:
+        blocks = [mine]
+    else:
+        gloo = dist.get_backend() == "gloo"
+        send = mine.cpu() if gloo else mine
+        blocks = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(blocks, send)
+        blocks = [b.to(device) for b in blocks]
+    out = torch.empty((sum(rows_per_batch), width), dtype=torch.float32, device=device)
+    starts = [0] * n
+    acc = 0
+    for b in range(n):
+        starts[b] = acc
+        acc += rows_per_batch[b]
+    for r in range(world):
+        pos = 0
+        for b in range(r, n, world):
+            k = rows_per_batch[b]
+            out[starts[b]:starts[b] + k] = blocks[r][pos:pos + k]
+            pos += k
+    return out
 
 
 def query_shard(num_q, world=None, rank_=None):
@@ -108,7 +196,9 @@ def sharded_evaluate_rank(qf, gf, q_pids, g_pids, q_camids, g_camids, max_rank=2
     """Multi-GPU evaluator: per-query AP and CMC rows are independent, so every rank takes a slice
     of the QUERIES against the whole gallery -- its own distmat block and its own ranking pass -- and the only
     exchange is ONE all_reduce(sum) of [max_rank CMC counts, num_valid_q, AP sum] (22 numbers at max_rank 20).
-    Every rank returns the same (cmc, mAP) as the single-device evaluate_rank (reference metrics/rank.py:103-171).
+    Every rank returns the same (cmc, mAP) as the single-device evaluate_rank (reference metrics/rank.py:103-171) on
+    the features it is given (Engine._evaluate makes those identical on every rank: ONE set of running statistics,
+    sync_replicas, and one all-gather of the sharded forward).
     distmat_fn / counts_fn: the per-shard distance and ranking functions (default: the device kernels)."""
     import numpy as np
     from .metrics.distance import compute_distance_matrix

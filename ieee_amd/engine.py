@@ -1,265 +1,259 @@
-"""Mirror of torchreid.engine for the hot path: the generic loop (reference torchreid/engine/engine.py:
-Engine.run :126-232, train :234-282, test :287-337, _evaluate :339-441) and the two live image engines
-(Image3MEngine, engine/image/margin.py:62-154; MultiModalImageSoftmaxEngine, engine/image/softmax.py:
-11-132).  Same constructor / method names, argument meaning and loss_summary keys.
+"""Training / evaluation drivers with the reference's call surface (torchreid/engine/engine.py: Engine.run :126-232,
+train :234-282, test :287-337, _evaluate :339-441; engine/image/margin.py:62-154 Image3MEngine; engine/image/softmax.py:
+11-132 MultiModalImageSoftmaxEngine): same constructor arguments, method names, keyword meaning, printed report and
+loss_summary keys, so scripts/mainMultiModal.py-style callers run unchanged.  What is underneath is this package's own:
 
-Two ways through `forward_backward`:
-  * fused (native model + ieee_amd.optim.FusedSGD): forward, 18-head CE, 3M, backward, the single RCCL
-    gradient all-reduce and the SGD step are each one native call; no autograd graph, one small
-    device->host read-back for the logging dict (the reference does >= 27 host syncs per step).
-  * generic (any other optimizer): autograd over the same native forward/backward + HIP-backed criteria.
-Evaluation keeps features on the device and feeds the distance-matrix and CMC/mAP kernels directly
-(the reference copies every feature batch to the host and runs both on the CPU, engine.py:368-417)."""
+  * fused step (native model + FusedSGD / FusedAdam): forward, 18-head cross entropy, 3M, backward, the RCCL gradient
+    all-reduce and the optimizer update are each one native call; no autograd graph and ONE small device->host read
+    per step for the logging dict (the reference synchronises >= 27 times per step).
+  * generic step (any other torch.optim optimizer): autograd over the same native forward / backward.
+  * data parallel (one process per GPU, ieee_amd/dist.py): the step shards the batch on identity boundaries, the
+    replicas are synchronised once before the first step, evaluation shards the feature extraction (one all-gather of
+    the descriptors) and the ranking (22 numbers all-reduced) under rank 0's running statistics.
+  * evaluation keeps descriptors, the distance matrix and the ranking on the device (the reference copies every
+    feature batch to the host and runs both on the CPU, engine.py:368-417)."""
 from __future__ import absolute_import, division, print_function
 
 import datetime
 import os
 import os.path as osp
 import time
-from collections import OrderedDict, defaultdict
+from collections import OrderedDict, namedtuple
 
 import numpy as np
 import torch
 from torch.nn import functional as F
 
 from . import _lib, dist as ddp
+from .checkpoint import save_checkpoint
 from .losses import CrossEntropyLoss, DeepSupervision, multiModalMarginLossNew
+from .meters import AverageMeter, MetricMeter
 from .metrics import accuracy, compute_distance_matrix, evaluate_rank
 from .optim import FusedAdam, FusedSGD
 
-
-class AverageMeter(object):
-    """reference utils/avgmeter.py:8-31"""
-
-    def __init__(self):
-        self.reset()
-
-    def reset(self):
-        self.val = self.avg = self.sum = self.count = 0
-
-    def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / self.count
+_Entry = namedtuple("_Entry", "model optim sched")
+_SUMMARY_3M = ('loss', 'LossX', 'LossM', 'accR', 'lossR', 'accN', 'lossN', 'accT', 'lossT')
 
 
-class MetricMeter(object):
-    """reference utils/avgmeter.py:34-73 (tensors are .item()'d, :63-65)"""
-
-    def __init__(self, delimiter='\t'):
-        self.meters = defaultdict(AverageMeter)
-        self.delimiter = delimiter
-
-    def update(self, input_dict):
-        if input_dict is None:
-            return
-        if not isinstance(input_dict, dict):
-            raise TypeError('Input to MetricMeter.update() must be a dictionary')
-        for k, v in input_dict.items():
-            if isinstance(v, torch.Tensor):
-                v = v.item()
-            self.meters[k].update(v)
-
-    def __str__(self):
-        return self.delimiter.join('{} {:.4f} ({:.4f})'.format(n, m.val, m.avg) for n, m in self.meters.items())
-
-
-def save_checkpoint(state, save_dir, is_best=False, remove_module_from_keys=False):
-    """reference utils/torchtools.py:20-58: <save_dir>/model.pth.tar-<epoch>"""
-    os.makedirs(save_dir, exist_ok=True)
-    if remove_module_from_keys:
-        state['state_dict'] = OrderedDict((k[7:] if k.startswith('module.') else k, v)
-                                          for k, v in state['state_dict'].items())
-    fpath = osp.join(save_dir, 'model.pth.tar-' + str(state['epoch']))
-    torch.save(state, fpath)
-    print('Checkpoint saved to "{}"'.format(fpath))
-    if is_best:
-        import shutil
-        shutil.copy(fpath, osp.join(osp.dirname(fpath), 'model-best.pth.tar'))
+def _hms(seconds):
+    return str(datetime.timedelta(seconds=int(seconds)))
 
 
 class Engine(object):
+    """Base driver.  Subclasses set self.model / optimizer / scheduler, register them and implement
+    forward_backward(data) -> dict of scalars."""
+
     def __init__(self, datamanager, use_gpu=True):
         self.datamanager = datamanager
-        self.train_loader = self.datamanager.train_loader
-        self.test_loader = self.datamanager.test_loader
-        self.use_gpu = (torch.cuda.is_available() and use_gpu)
+        self.train_loader = datamanager.train_loader
+        self.test_loader = datamanager.test_loader
+        self.use_gpu = bool(use_gpu) and torch.cuda.is_available()
         self.writer = None
         self.epoch = 0
-        self.model = None
-        self.optimizer = None
-        self.scheduler = None
-        self._models = OrderedDict()
-        self._optims = OrderedDict()
-        self._scheds = OrderedDict()
+        self.model = self.optimizer = self.scheduler = None
+        self._registry = OrderedDict()       # name -> _Entry
+        self._replicas_synced = False
+        # data parallel: True when every rank's loader already yields that rank's shard (bench.py); otherwise each
+        # rank is handed the global batch and keeps its identity-aligned slice (dist.shard_batch)
+        self.dp_presharded = False
 
+    # ---- registry ------------------------------------------------------------------------------------------------
     def register_model(self, name='model', model=None, optim=None, sched=None):
-        self._models[name] = model
-        self._optims[name] = optim
-        self._scheds[name] = sched
+        self._registry[name] = _Entry(model, optim, sched)
+
+    # the three dicts the reference keeps (engine.py:48-50), as read-only views of the registry
+    @property
+    def _models(self):
+        return OrderedDict((k, e.model) for k, e in self._registry.items())
+
+    @property
+    def _optims(self):
+        return OrderedDict((k, e.optim) for k, e in self._registry.items())
+
+    @property
+    def _scheds(self):
+        return OrderedDict((k, e.sched) for k, e in self._registry.items())
 
     def get_model_names(self, names=None):
-        names_real = list(self._models.keys())
-        if names is not None:
-            if not isinstance(names, list):
-                names = [names]
-            for name in names:
-                assert name in names_real
-            return names
-        return names_real
-
-    def save_model(self, epoch, mAP, save_dir, is_best=False):
-        if ddp.rank() != 0:
-            return
-        for name in self.get_model_names():
-            save_checkpoint({
-                'state_dict': self._models[name].state_dict(),
-                'epoch': epoch + 1,
-                'mAP': mAP,
-                'optimizer': self._optims[name].state_dict(),
-                'scheduler': self._scheds[name].state_dict() if self._scheds[name] is not None else None,
-            }, osp.join(save_dir, name), is_best=is_best)
+        if names is None:
+            return list(self._registry)
+        wanted = names if isinstance(names, list) else [names]
+        for n in wanted:
+            assert n in self._registry
+        return wanted
 
     def set_model_mode(self, mode='train', names=None):
         assert mode in ['train', 'eval', 'test']
-        for name in self.get_model_names(names):
-            self._models[name].train(mode == 'train')
+        for n in self.get_model_names(names):
+            self._registry[n].model.train(mode == 'train')
 
     def get_current_lr(self, names=None):
-        return self._optims[self.get_model_names(names)[0]].param_groups[-1]['lr']
+        first = self.get_model_names(names)[0]
+        return self._registry[first].optim.param_groups[-1]['lr']
 
     def update_lr(self, names=None):
-        for name in self.get_model_names(names):
-            if self._scheds[name] is not None:
-                self._scheds[name].step()
+        for n in self.get_model_names(names):
+            sched = self._registry[n].sched
+            if sched is not None:
+                sched.step()
 
+    def save_model(self, epoch, mAP, save_dir, is_best=False):
+        """one file per registered model: <save_dir>/<name>/model.pth.tar-<epoch+1> (engine.py:77-101); rank 0 writes"""
+        if ddp.rank() != 0:
+            return
+        for n, e in self._registry.items():
+            state = {'state_dict': e.model.state_dict(), 'epoch': epoch + 1, 'mAP': mAP,
+                     'optimizer': e.optim.state_dict(),
+                     'scheduler': None if e.sched is None else e.sched.state_dict()}
+            save_checkpoint(state, osp.join(save_dir, n), is_best=is_best)
+
+    # ---- the loop ------------------------------------------------------------------------------------------------
     def run(self, save_dir='log', max_epoch=0, start_epoch=0, print_freq=10, fixbase_epoch=0, open_layers=None,
             start_eval=0, eval_freq=-1, test_only=False, dist_metric='euclidean', normalize_feature=False,
             visrank=False, visrank_topk=10, use_metric_cuhk03=False, ranks=[1, 5, 10, 20], rerank=False):
-        """engine.py:126-232.  Like the reference there is no evaluation / checkpoint after the last
-        epoch (the `(epoch+1) != max_epoch` guard, :216)."""
+        """engine.py:126-232.  As in the reference there is NO evaluation or checkpoint after the last epoch (the
+        `(epoch + 1) != max_epoch` guard, :216), and re-ranking applies to test_only runs (its docstring, :171-172;
+        the in-loop test call does not pass it on, :217-225)."""
+        if visrank and not test_only:
+            raise ValueError('visrank can be set to True only if test_only=True')
         if visrank:
-            raise NotImplementedError('visrank (cv2 visualisation) is out of scope')
-        if rerank:
-            raise NotImplementedError('re-ranking is a "next" row (SURVEY.md §8f N3)')
+            raise NotImplementedError('visrank (the cv2 / t-SNE visualisation) is outside the hot path')
+        eval_args = dict(dist_metric=dist_metric, normalize_feature=normalize_feature, save_dir=save_dir,
+                         use_metric_cuhk03=use_metric_cuhk03, ranks=ranks)
         if test_only:
-            self.test(dist_metric=dist_metric, normalize_feature=normalize_feature, save_dir=save_dir,
-                      use_metric_cuhk03=use_metric_cuhk03, ranks=ranks)
+            self.test(rerank=rerank, **eval_args)
             return
-        time_start = time.time()
-        self.start_epoch = start_epoch
-        self.max_epoch = max_epoch
+        began = time.time()
+        self.start_epoch, self.max_epoch = start_epoch, max_epoch
         print('=> Start training')
-        train_begin = time.time()
-        for self.epoch in range(self.start_epoch, self.max_epoch):
-            epoch_begin = time.time()
+        for self.epoch in range(start_epoch, max_epoch):
+            lap = time.time()
             self.train(print_freq=print_freq, fixbase_epoch=fixbase_epoch, open_layers=open_layers)
-            print("Epoch Time: {}\t Total Time: {}\n".format(
-                str(datetime.timedelta(seconds=int(time.time() - epoch_begin))),
-                str(datetime.timedelta(seconds=int(time.time() - train_begin)))))
-            if (self.epoch + 1) >= start_eval and eval_freq > 0 and (self.epoch + 1) % eval_freq == 0 \
-                    and (self.epoch + 1) != self.max_epoch:
-                mAP = self.test(dist_metric=dist_metric, normalize_feature=normalize_feature, save_dir=save_dir,
-                                use_metric_cuhk03=use_metric_cuhk03, ranks=ranks)
+            print("Epoch Time: {}\t Total Time: {}\n".format(_hms(time.time() - lap), _hms(time.time() - began)))
+            done = self.epoch + 1
+            due = eval_freq > 0 and done >= start_eval and done % eval_freq == 0
+            if due and done != max_epoch:
+                mAP = self.test(**eval_args)
                 self.save_model(self.epoch, mAP, save_dir)
-        print('Elapsed {}'.format(str(datetime.timedelta(seconds=round(time.time() - time_start)))))
+        print('Elapsed {}'.format(str(datetime.timedelta(seconds=round(time.time() - began)))))
+        if self.writer is not None:
+            self.writer.close()
 
     def train(self, print_freq=10, fixbase_epoch=0, open_layers=None):
-        losses = MetricMeter()
-        batch_time = AverageMeter()
-        data_time = AverageMeter()
+        """one epoch (engine.py:234-282): forward_backward per batch, a report every print_freq batches, then the
+        scheduler step"""
+        log, t_batch, t_data = MetricMeter(), AverageMeter(), AverageMeter()
         self.set_model_mode('train')
         self.two_stepped_transfer_learning(self.epoch, fixbase_epoch, open_layers)
         self.num_batches = len(self.train_loader)
-        end = time.time()
+        mark = time.time()
         for self.batch_idx, data in enumerate(self.train_loader):
-            data_time.update(time.time() - end)
-            loss_summary = self.forward_backward(data)
-            batch_time.update(time.time() - end)
-            losses.update(loss_summary)
-            if (self.batch_idx + 1) % print_freq == 0 and ddp.rank() == 0:
-                print('epoch: [{0}/{1}][{2}/{3}]\tlr {lr:.6f}\n{losses}\t'.format(
-                    self.epoch + 1, self.max_epoch, self.batch_idx + 1, self.num_batches,
-                    lr=self.get_current_lr(), losses=losses))
-            end = time.time()
+            t_data.update(time.time() - mark)
+            log.update(self.forward_backward(data))
+            t_batch.update(time.time() - mark)
+            seen = self.batch_idx + 1
+            if seen % print_freq == 0 and ddp.rank() == 0:
+                print('epoch: [{}/{}][{}/{}]\tlr {:.6f}\n{}\t'.format(self.epoch + 1, self.max_epoch, seen, self.num_batches,
+                                                                      self.get_current_lr(), log))
+            if self.writer is not None:
+                step = self.epoch * self.num_batches + self.batch_idx
+                self.writer.add_scalar('Train/time', t_batch.avg, step)
+                self.writer.add_scalar('Train/data', t_data.avg, step)
+                for key, meter in log.meters.items():
+                    self.writer.add_scalar('Train/' + key, meter.avg, step)
+                self.writer.add_scalar('Train/lr', self.get_current_lr(), step)
+            mark = time.time()
         self.update_lr()
 
     def forward_backward(self, data):
         raise NotImplementedError
 
+    # ---- evaluation ----------------------------------------------------------------------------------------------
     def test(self, dist_metric='euclidean', normalize_feature=False, visrank=False, visrank_topk=10, save_dir='',
              use_metric_cuhk03=False, ranks=[1, 5, 10, 20], rerank=False):
+        """every target dataset in turn (engine.py:287-337); returns the last one's mAP like the reference"""
         self.set_model_mode('eval')
         mAP = 0.0
-        for name in list(self.test_loader.keys()):
-            domain = 'source' if name in self.datamanager.sources else 'target'
-            print('##### Evaluating {} ({}) #####'.format(name, domain))
-            rank1, mAP = self._evaluate(dataset_name=name, query_loader=self.test_loader[name]['query'],
-                                        gallery_loader=self.test_loader[name]['gallery'], dist_metric=dist_metric,
+        for name, loaders in self.test_loader.items():
+            where = 'source' if name in self.datamanager.sources else 'target'
+            print('##### Evaluating {} ({}) #####'.format(name, where))
+            rank1, mAP = self._evaluate(dataset_name=name, query_loader=loaders['query'],
+                                        gallery_loader=loaders['gallery'], dist_metric=dist_metric,
                                         normalize_feature=normalize_feature, use_metric_cuhk03=use_metric_cuhk03,
                                         ranks=ranks, rerank=rerank)
+            if self.writer is not None:
+                self.writer.add_scalar('Test/{}/rank1'.format(name), rank1, self.epoch)
+                self.writer.add_scalar('Test/{}/mAP'.format(name), mAP, self.epoch)
         return mAP
+
+    def _descriptors(self, loader, clock):
+        """[rows, 2304] descriptors of one loader, on the device, with the identity / camera labels.  With several
+        ranks each one runs the forward for every world-th batch and one all-gather completes the matrix."""
+        world, me = ddp.world_size(), ddp.rank()
+        mine, rows, pids, cams = {}, [], [], []
+        for b, data in enumerate(loader):
+            imgs, p, c, timeids = self.parse_data_for_eval(data)
+            p, c = np.asarray(p).reshape(-1), np.asarray(c).reshape(-1)
+            pids.append(p)
+            cams.append(c)
+            rows.append(len(p))
+            if b % world != me:
+                continue
+            if self.use_gpu:
+                imgs = [im.cuda(non_blocking=True) for im in imgs]
+            t0 = time.time()
+            mine[b] = self.extract_features(imgs, timeids).clone()
+            clock.update(time.time() - t0)
+        if world == 1:
+            feats = torch.cat([mine[b] for b in range(len(rows))], 0)
+        else:
+            some = next(iter(mine.values())) if mine else None
+            width = some.shape[1] if some is not None else 2304
+            device = some.device if some is not None else torch.device('cuda' if self.use_gpu else 'cpu')
+            feats = ddp.gather_feature_batches(mine, rows, width, device)
+        return feats, np.concatenate(pids), np.concatenate(cams)
 
     @torch.no_grad()
     def _evaluate(self, dataset_name='', query_loader=None, gallery_loader=None, dist_metric='euclidean',
                   normalize_feature=False, visrank=False, visrank_topk=10, save_dir='', use_metric_cuhk03=False,
                   ranks=[1, 5, 10, 20], rerank=False):
-        batch_time = AverageMeter()
-
-        def _feature_extraction(data_loader):
-            f_, pids_, camids_ = [], [], []
-            for data in data_loader:
-                imgs, pids, camids, timeids = self.parse_data_for_eval(data)
-                if self.use_gpu:
-                    imgs = [im.cuda(non_blocking=True) for im in imgs]
-                end = time.time()
-                features = self.extract_features(imgs, timeids)
-                batch_time.update(time.time() - end)
-                f_.append(features.clone())             # stays on the device (reference: .cpu(), :368)
-                pids_.extend(np.asarray(pids).tolist())
-                camids_.extend(np.asarray(camids).tolist())
-            return torch.cat(f_, 0), np.asarray(pids_), np.asarray(camids_)
-
+        """descriptors -> distance matrix -> CMC / mAP, printed like engine.py:339-441; returns (rank-1, mAP)"""
+        clock = AverageMeter()
+        if ddp.world_size() > 1 and self.model is not None and hasattr(self.model, "_flat_buffers"):
+            ddp.sync_replicas(self.model, buffers_only=True)       # DataParallel evaluates with GPU 0's statistics
         print('Extracting features from query set ...')
-        qf, q_pids, q_camids = _feature_extraction(query_loader)
+        qf, q_pids, q_camids = self._descriptors(query_loader, clock)
         print('Done, obtained {}-by-{} matrix'.format(qf.size(0), qf.size(1)))
         print('Extracting features from gallery set ...')
-        gf, g_pids, g_camids = _feature_extraction(gallery_loader)
+        gf, g_pids, g_camids = self._descriptors(gallery_loader, clock)
         print('Done, obtained {}-by-{} matrix'.format(gf.size(0), gf.size(1)))
-        print('Speed: {:.4f} sec/batch'.format(batch_time.avg))
+        print('Speed: {:.4f} sec/batch'.format(clock.avg))
         if normalize_feature:
             print('Normalzing features with L2 norm ...')
-            qf = F.normalize(qf, p=2, dim=1)
-            gf = F.normalize(gf, p=2, dim=1)
+            qf, gf = F.normalize(qf, p=2, dim=1), F.normalize(gf, p=2, dim=1)
         print('Computing distance matrix with metric={} ...'.format(dist_metric))
-        if rerank:
-            # reference engine.py:402-406: re-rank with the query-query and gallery-gallery matrices, then evaluate
-            print('Applying person re-ranking ...')
-            from .rerank import re_ranking
-            distmat = compute_distance_matrix(qf, gf, dist_metric)
-            distmat_qq = compute_distance_matrix(qf, qf, dist_metric)
-            distmat_gg = compute_distance_matrix(gf, gf, dist_metric)
-            distmat = re_ranking(distmat, distmat_qq, distmat_gg)
-            print('Computing CMC and mAP for {}'.format(dataset_name))
-            cmc, mAP = evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, use_metric_cuhk03=use_metric_cuhk03)
-        elif ddp.world_size() > 1 and not use_metric_cuhk03:
-            # every rank holds the full feature sets; each ranks its slice of the queries (ieee_amd/dist.py)
+        sharded = ddp.world_size() > 1 and not use_metric_cuhk03 and not rerank
+        if sharded:     # each rank ranks its slice of the queries against the whole gallery (ieee_amd/dist.py)
             print('Computing CMC and mAP for {} (queries sharded over {} ranks)'.format(dataset_name, ddp.world_size()))
             cmc, mAP = ddp.sharded_evaluate_rank(qf, gf, q_pids, g_pids, q_camids, g_camids, metric=dist_metric)
         else:
             distmat = compute_distance_matrix(qf, gf, dist_metric)
+            if rerank:  # engine.py:402-406: k-reciprocal re-ranking with the query-query and gallery-gallery matrices
+                print('Applying person re-ranking ...')
+                from .rerank import re_ranking
+                distmat = re_ranking(distmat, compute_distance_matrix(qf, qf, dist_metric),
+                                     compute_distance_matrix(gf, gf, dist_metric))
             print('Computing CMC and mAP for {}'.format(dataset_name))
             cmc, mAP = evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, use_metric_cuhk03=use_metric_cuhk03)
         print('** Results **')
         print('mAP: {:.2%}'.format(mAP))
         print('CMC curve')
         for r in ranks:
-            if r - 1 < len(cmc):
-                print('Rank-{:<3}: {:.2%}'.format(r, cmc[r - 1]))
+            print('Rank-{:<3}: {:.2%}'.format(r, cmc[r - 1]))     # IndexError when r exceeds the curve, as in the reference
         print('\n')
         return cmc[0], mAP
 
+    # ---- small hooks the reference exposes ------------------------------------------------------------------------
     def compute_loss(self, criterion, outputs, targets):
         if isinstance(outputs, (tuple, list)):
             return DeepSupervision(criterion, outputs, targets)
@@ -275,24 +269,58 @@ class Engine(object):
         return data['img'], data['pid'], data['camid'], data['timeid']
 
     def two_stepped_transfer_learning(self, epoch, fixbase_epoch, open_layers, model=None):
-        """engine.py:507-529; the shipped config has fixbase_epoch=0, i.e. all layers open."""
+        """Freeze everything but `open_layers` for the first fixbase_epoch epochs, then train all (engine.py:507-529,
+        utils/torchtools.py:183-221).  The shipped configuration has fixbase_epoch = 0.  Frozen children stop
+        receiving optimizer updates; their BatchNorms keep running in batch mode inside the native forward (the
+        reference also puts them in eval() mode) -- said once when it happens."""
         model = self.model if model is None else model
         if model is None:
             return
-        if (epoch + 1) <= fixbase_epoch and open_layers is not None:
-            if isinstance(open_layers, str):
-                open_layers = [open_layers]
-            print('* Only train {} (epoch: {}/{})'.format(open_layers, epoch + 1, fixbase_epoch))
-            for name, module in model.named_children():
-                for p in module.parameters():
-                    p.requires_grad = name in open_layers
-        else:
-            for p in model.parameters():
-                p.requires_grad = True
+        freezing = (epoch + 1) <= fixbase_epoch and open_layers is not None
+        if freezing:
+            keep = [open_layers] if isinstance(open_layers, str) else list(open_layers)
+            for layer in keep:
+                assert hasattr(model, layer), \
+                    '"{}" is not an attribute of the model, please provide the correct name'.format(layer)
+            print('* Only train {} (epoch: {}/{})'.format(keep, epoch + 1, fixbase_epoch))
+            if not getattr(self, "_warned_fixbase", False) and _is_native(model):
+                print('  (note: frozen children keep batch-mode BatchNorm statistics in the native forward)')
+                self._warned_fixbase = True
+        for child_name, child in model.named_children():
+            flag = (child_name in keep) if freezing else True
+            for p in child.parameters():
+                p.requires_grad = flag
+
+    # ---- data parallel helpers ---------------------------------------------------------------------------------------
+    def _local_batch(self, data):
+        """(this rank's slice of the batch, rows of the GLOBAL batch)"""
+        world = ddp.world_size()
+        rows = int(data['pid'].shape[0])
+        if world == 1:
+            return data, rows
+        if self.dp_presharded:
+            return data, ddp.global_rows(rows)
+        k = int(getattr(self.datamanager, 'num_instances', 4))
+        return ddp.shard_batch(data, k), rows
+
+    def _sync_replicas_once(self):
+        if ddp.world_size() > 1 and not self._replicas_synced and hasattr(self.model, "_flat_params"):
+            ddp.sync_replicas(self.model, self.optimizer)
+        self._replicas_synced = True
 
 
 def _is_native(model):
     return hasattr(model, "native_net")
+
+
+def _chunks_short_of_identities(pids):
+    """True when `feat.chunk(n)` yields fewer than n = len(unique(pids)) pieces, i.e. when the reference's 3M loss dies
+    with `IndexError: tuple index out of range` in its first loop (multi_modal_margin_loss_new.py:24-33) BEFORE any
+    gradient exists.  Evaluated on the host so that the same error can be raised before this step touches the weights."""
+    rows = int(pids.numel())
+    n = int(torch.unique(pids).numel())
+    per = -(-rows // n)
+    return -(-rows // per) < n
 
 
 class _FusedStepMixin(object):
@@ -301,7 +329,18 @@ class _FusedStepMixin(object):
     def _fused_ok(self):
         return _is_native(self.model) and isinstance(self.optimizer, (FusedSGD, FusedAdam)) and self.use_gpu
 
-    def _fused_step(self, imgs, pids, weight_x, weight_m, margin, eps):
+    def _guard_chunks(self, pids, weight_m):
+        """the reference's IndexError, raised where the reference raises it: before backward / the optimizer"""
+        if weight_m <= 0:
+            return
+        key = (pids.data_ptr(), pids._version, tuple(pids.shape), pids.device)
+        if getattr(self, "_chunk_key", None) != key:       # a resident batch (bench.py) is checked once
+            self._chunk_bad = _chunks_short_of_identities(pids)
+            self._chunk_key = key
+        if self._chunk_bad:
+            raise IndexError('tuple index out of range')
+
+    def _fused_step(self, imgs, pids, weight_x, weight_m, margin, eps, total_rows=None):
         lib = _lib.require_gpu()
         m = self.model
         B, _, H, W = imgs[0].shape
@@ -318,9 +357,10 @@ class _FusedStepMixin(object):
                              torch.empty(B + 3, dtype=torch.float32, device=dev))
         dl, df, small, work, mwork = self._scratch
         head_loss, head_acc, out3 = small[:18], small[18:36], small[36:39]
+        ce_scale = float(weight_x) * ddp.ce_grad_scale(B, total_rows)
         _lib.check(lib.ieee_ce_ls_fwd_bwd(_lib.ptr(logits), _lib.ptr(pids), _lib.ptr(dl), _lib.ptr(head_loss),
-                                          _lib.ptr(head_acc), _lib.ptr(work), 18, B, C, float(eps),
-                                          float(weight_x) * ddp.ce_grad_scale(), _lib.stream()))
+                                          _lib.ptr(head_acc), _lib.ptr(work), 18, B, C, float(eps), ce_scale,
+                                          _lib.stream()))
         if weight_m > 0:
             _lib.check(lib.ieee_margin3m_fwd_bwd(_lib.ptr(feats), _lib.ptr(pids), _lib.ptr(df), _lib.ptr(out3),
                                                  _lib.ptr(mwork), B, feats.shape[2], float(margin), float(weight_m),
@@ -392,101 +432,99 @@ class _FusedStepMixin(object):
         aR, aN, aT = float(ha[0:6].mean()), float(ha[6:12].mean()), float(ha[12:18].mean())
         return lR, lN, lT, aR, aN, aT, float(v[36]), v[37], v[38]
 
+    def _generic_allreduce(self, params):
+        """autograd path under data parallelism: sum the parameter gradients across ranks (one collective per tensor;
+        the fused path is the fast one)"""
+        if ddp.world_size() == 1:
+            return
+        for p in params:
+            if p.grad is not None:
+                torch.distributed.all_reduce(p.grad, op=torch.distributed.ReduceOp.SUM)
+
+    def _to_device(self, imgs, pids):
+        if self.use_gpu:
+            imgs = [im.cuda(non_blocking=True) for im in imgs]
+            pids = pids.cuda()
+        return imgs, pids
+
 
 class Image3MEngine(_FusedStepMixin, Engine):
-    """CE (x18, label smoothed) + 3M margin loss engine, reference engine/image/margin.py:62-154."""
+    """Cross entropy over the 18 heads (label smoothed) + the 3M margin loss: engine/image/margin.py:62-154."""
 
     def __init__(self, datamanager, model, optimizer, margin=3, weight_m=1, weight_x=1, scheduler=None, use_gpu=True,
                  label_smooth=True):
         super(Image3MEngine, self).__init__(datamanager, use_gpu)
-        self.model = model
-        self.optimizer = optimizer
-        self.scheduler = scheduler
+        self.model, self.optimizer, self.scheduler = model, optimizer, scheduler
         self.register_model('model', model, optimizer, scheduler)
         assert weight_m >= 0 and weight_x >= 0
         assert weight_m + weight_x > 0
-        self.weight_m = weight_m
-        self.weight_x = weight_x
-        self.margin = margin
+        self.weight_m, self.weight_x, self.margin = weight_m, weight_x, margin
         self.criterion_m = multiModalMarginLossNew(margin=margin)
         self.criterion_x = CrossEntropyLoss(num_classes=self.datamanager.num_train_pids, use_gpu=self.use_gpu,
                                             label_smooth=label_smooth)
 
     def forward_backward(self, data):
+        self._sync_replicas_once()
+        data, total_rows = self._local_batch(data)
         imgs, pids, timeids = self.parse_data_for_train(data)
-        if self.use_gpu:
-            imgs = [im.cuda(non_blocking=True) for im in imgs]
-            pids = pids.cuda()
+        self._guard_chunks(pids, self.weight_m)
+        imgs, pids = self._to_device(imgs, pids)
         if self._fused_ok():
-            small, out3 = self._fused_step(imgs, pids, self.weight_x, self.weight_m, self.margin, self.criterion_x.eps)
-            lR, lN, lT, aR, aN, aT, lm, n_id, n_chunk = self._summary_from(small)
-            if self.weight_m > 0 and n_chunk < n_id:
-                raise IndexError('tuple index out of range')    # what chunk()/feat1[i] raises in the reference
+            small, out3 = self._fused_step(imgs, pids, self.weight_x, self.weight_m, self.margin, self.criterion_x.eps,
+                                           total_rows)
+            lR, lN, lT, aR, aN, aT, lm = self._summary_from(small)[:7]
             loss_x = lR + lN + lT
-            return {'loss': self.weight_m * lm + self.weight_x * loss_x, 'LossX': loss_x, 'LossM': out3[0].clone(),
-                    'accR': aR, 'lossR': lR, 'accN': aN, 'lossN': lN, 'accT': aT, 'lossT': lT}
-        # ---- generic path: same structure as the reference step (margin.py:102-152)
-        outputs_R, outputs_N, outputs_T, features_RGB, features_NI, features_TI = self.model(imgs)
-        loss = 0
-        loss_m = 0
+            values = (self.weight_m * lm + self.weight_x * loss_x, loss_x, out3[0].clone(), aR, lR, aN, lN, aT, lT)
+            return dict(zip(_SUMMARY_3M, values))
+        # ---- generic path: the reference's step (margin.py:102-152) over the autograd bridge
+        oR, oN, oT, fR, fN, fT = self.model(imgs)
+        scale = ddp.ce_grad_scale(int(pids.shape[0]), total_rows)
+        loss, loss_m = 0, 0
         if self.weight_m > 0:
-            loss_m = self.criterion_m(features_RGB, features_NI, features_TI, pids)
-            loss += self.weight_m * loss_m
+            loss_m = self.criterion_m(fR, fN, fT, pids)
+            loss = loss + self.weight_m * loss_m
         if self.weight_x > 0:
-            loss_R = self.compute_loss(self.criterion_x, outputs_R, pids)
-            loss_N = self.compute_loss(self.criterion_x, outputs_N, pids)
-            loss_T = self.compute_loss(self.criterion_x, outputs_T, pids)
-            loss_x = loss_R + loss_N + loss_T
-            loss += self.weight_x * loss_x
+            per_modality = [self.compute_loss(self.criterion_x, o, pids) for o in (oR, oN, oT)]
+            loss_x = per_modality[0] + per_modality[1] + per_modality[2]
+            loss = loss + (self.weight_x * scale) * loss_x
         self.optimizer.zero_grad()
         loss.backward()
-        if ddp.world_size() > 1:
-            raise RuntimeError("multi-GPU training uses the fused path (FusedSGD); see ieee_amd.dist")
+        self._generic_allreduce(self.model.parameters())
         self.optimizer.step()
-        acc_R = acc_N = acc_T = 0
-        for i in range(len(outputs_R)):
-            acc_R += accuracy(outputs_R[i], pids)[0]
-            acc_N += accuracy(outputs_N[i], pids)[0]
-            acc_T += accuracy(outputs_T[i], pids)[0]
-        acc_R /= len(outputs_R)
-        acc_N /= len(outputs_N)
-        acc_T /= len(outputs_T)
-        return {'loss': loss.item(), 'LossX': loss_x.item(), 'LossM': loss_m, 'accR': acc_R.item(),
-                'lossR': loss_R.item(), 'accN': acc_N.item(), 'lossN': loss_N.item(), 'accT': acc_T.item(),
-                'lossT': loss_T.item()}
+        acc = [sum(accuracy(h, pids)[0] for h in heads) / len(heads) for heads in (oR, oN, oT)]
+        shown = self.weight_m * loss_m + self.weight_x * loss_x          # the unscaled loss, as the reference logs it
+        values = (float(shown), loss_x.item(), loss_m, acc[0].item(), per_modality[0].item(), acc[1].item(),
+                  per_modality[1].item(), acc[2].item(), per_modality[2].item())
+        return dict(zip(_SUMMARY_3M, values))
 
 
 class MultiModalImageSoftmaxEngine(_FusedStepMixin, Engine):
-    """CE-only 3-modal engine (the "3M off" ablation), reference engine/image/softmax.py:11-132."""
+    """Cross entropy only (the "3M off" leg of the ablation): engine/image/softmax.py:11-132."""
 
     def __init__(self, datamanager, model, optimizer, scheduler=None, use_gpu=True, label_smooth=True):
         super(MultiModalImageSoftmaxEngine, self).__init__(datamanager, use_gpu)
-        self.model = model
-        self.optimizer = optimizer
-        self.scheduler = scheduler
+        self.model, self.optimizer, self.scheduler = model, optimizer, scheduler
         self.register_model('model', model, optimizer, scheduler)
         self.criterion = CrossEntropyLoss(num_classes=self.datamanager.num_train_pids, use_gpu=self.use_gpu,
                                           label_smooth=label_smooth)
 
     def forward_backward(self, data):
+        self._sync_replicas_once()
+        data, total_rows = self._local_batch(data)
         imgs, pids, timeids = self.parse_data_for_train(data)
-        if self.use_gpu:
-            imgs = [im.cuda(non_blocking=True) for im in imgs]
-            pids = pids.cuda()
+        imgs, pids = self._to_device(imgs, pids)
         if self._fused_ok():
-            small, _ = self._fused_step(imgs, pids, 1.0, 0.0, 0.0, self.criterion.eps)
+            small, _ = self._fused_step(imgs, pids, 1.0, 0.0, 0.0, self.criterion.eps, total_rows)
             lR, lN, lT, aR, aN, aT = self._summary_from(small)[:6]
-            return {'loss_all': lR + lN + lT, 'loss_R': lR, 'acc_R': aR, 'loss_N': lN, 'acc_N': aN, 'loss_T': lT,
-                    'acc_T': aT}
-        out = self.model(imgs)
-        outputs_R, outputs_N, outputs_T = out[0], out[1], out[2]
-        loss_R = self.compute_loss(self.criterion, outputs_R, pids)
-        loss_N = self.compute_loss(self.criterion, outputs_N, pids)
-        loss_T = self.compute_loss(self.criterion, outputs_T, pids)
-        loss = loss_R + loss_N + loss_T
-        self.optimizer.zero_grad()
-        loss.backward()
-        self.optimizer.step()
-        acc = [sum(accuracy(o, pids)[0] for o in oo) / len(oo) for oo in (outputs_R, outputs_N, outputs_T)]
-        return {'loss_all': loss.item(), 'loss_R': loss_R.item(), 'acc_R': acc[0].item(), 'loss_N': loss_N.item(),
-                'acc_N': acc[1].item(), 'loss_T': loss_T.item(), 'acc_T': acc[2].item()}
+        else:
+            heads = self.model(imgs)[:3]
+            per_modality = [self.compute_loss(self.criterion, o, pids) for o in heads]
+            loss = per_modality[0] + per_modality[1] + per_modality[2]
+            self.optimizer.zero_grad()
+            (loss * ddp.ce_grad_scale(int(pids.shape[0]), total_rows)).backward()
+            self._generic_allreduce(self.model.parameters())
+            self.optimizer.step()
+            lR, lN, lT = (v.item() for v in per_modality)
+            aR, aN, aT = (sum(accuracy(h, pids)[0] for h in o).item() / len(o) for o in heads)
+        return {'loss_all': lR + lN + lT, 'loss_R': lR, 'acc_R': aR, 'loss_N': lN, 'acc_N': aN, 'loss_T': lT,
+                'acc_T': aT}

@@ -212,7 +212,9 @@ class IEEE3modalPart(nn.Module):
     def part_runs(self):
         """trainable_runs() cut at the boundaries of the 5 staged-backward parts: part_runs()[p] = the element runs an
         optimizer may update as soon as part p of the backward (and its weight gradients) is done"""
-        key = (self.interaction, self.attention, self.using_REM)
+        # the runs depend on the ablation flags AND on which parameters are frozen (requires_grad, toggled by
+        # Engine.two_stepped_transfer_learning / open_specified_layers between epochs)
+        key = (self.interaction, self.attention, self.using_REM, tuple(p.requires_grad for _, p in self._param_items))
         if getattr(self, "_part_runs_key", None) != key:
             runs = self.trainable_runs()
             out = []

@@ -50,16 +50,40 @@ class FusedSGD(torch.optim.Optimizer):
         for p in self.model.parameters():
             p.grad = None
 
+    def flat_state(self):
+        """the flat state tensors (data-parallel replica synchronisation)"""
+        return [self.momentum_buffer()]
+
+    # Checkpoint interop with torch.optim.SGD (the reference's optimizer, optim/optimizer.py:130-138): state_dict()
+    # carries the momentum as per-parameter `momentum_buffer` entries -- views of the flat buffer, so the file stores
+    # it once -- exactly where torch.optim.SGD keeps its own, and load_state_dict() scatters such entries (from either
+    # implementation) back into the flat buffer.
+    def _publish_views(self):
+        buf = self.momentum_buffer()
+        for name, p in self.model._param_items:
+            off = self.model._offsets[name]
+            self.state[p]['momentum_buffer'] = buf[off:off + p.numel()].view(p.shape)
+
     def state_dict(self):
+        self._publish_views()
         d = super(FusedSGD, self).state_dict()
-        d['fused'] = {'momentum_buffer': self._buf}
+        d['fused'] = {'layout': 'per-parameter views of one flat buffer'}
         return d
 
     def load_state_dict(self, state_dict):
         fused = state_dict.get('fused')
         super(FusedSGD, self).load_state_dict({k: v for k, v in state_dict.items() if k != 'fused'})
-        if fused is not None and fused.get('momentum_buffer') is not None:
-            self.momentum_buffer().copy_(fused['momentum_buffer'])
+        buf = self.momentum_buffer()
+        if fused is not None and fused.get('momentum_buffer') is not None:        # files written by round-1 builds
+            buf.copy_(fused['momentum_buffer'])
+        else:
+            buf.zero_()
+            for name, p in self.model._param_items:
+                mb = self.state.get(p, {}).get('momentum_buffer')
+                if mb is not None:
+                    off = self.model._offsets[name]
+                    buf[off:off + p.numel()].copy_(mb.reshape(-1))
+        self._publish_views()
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -98,21 +122,53 @@ class FusedAdam(torch.optim.Optimizer):
         for p in self.model.parameters():
             p.grad = None
 
+    def flat_state(self):
+        return [t for t in self._buffers() if t is not None]
+
+    # same checkpoint interop as FusedSGD, with torch.optim.Adam's per-parameter keys (step, exp_avg, exp_avg_sq,
+    # max_exp_avg_sq)
+    _KEYS = ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq')
+
+    def _publish_views(self):
+        flats = self._buffers()
+        for name, p in self.model._param_items:
+            off, n = self.model._offsets[name], p.numel()
+            st = self.state[p]
+            st['step'] = torch.tensor(float(self._step))
+            for key, flat in zip(self._KEYS, flats):
+                if flat is not None:
+                    st[key] = flat[off:off + n].view(p.shape)
+
     def state_dict(self):
+        self._publish_views()
         d = super(FusedAdam, self).state_dict()
-        d['fused'] = {'step': self._step, 'exp_avg': self._m, 'exp_avg_sq': self._v, 'max_exp_avg_sq': self._vmax}
+        d['fused'] = {'layout': 'per-parameter views of flat buffers', 'step': self._step}
         return d
 
     def load_state_dict(self, state_dict):
         fused = state_dict.get('fused')
         super(FusedAdam, self).load_state_dict({k: v for k, v in state_dict.items() if k != 'fused'})
-        if fused is not None:
-            m, v, vmax = self._buffers()
+        flats = self._buffers()
+        if fused is not None and fused.get('exp_avg') is not None:                  # files written by round-1 builds
             self._step = int(fused['step'])
-            if fused['exp_avg'] is not None:
-                m.copy_(fused['exp_avg']); v.copy_(fused['exp_avg_sq'])
-                if vmax is not None and fused['max_exp_avg_sq'] is not None:
-                    vmax.copy_(fused['max_exp_avg_sq'])
+            flats[0].copy_(fused['exp_avg']); flats[1].copy_(fused['exp_avg_sq'])
+            if flats[2] is not None and fused.get('max_exp_avg_sq') is not None:
+                flats[2].copy_(fused['max_exp_avg_sq'])
+        else:
+            steps = []
+            for flat in flats:
+                if flat is not None:
+                    flat.zero_()
+            for name, p in self.model._param_items:
+                st = self.state.get(p, {})
+                off, n = self.model._offsets[name], p.numel()
+                if 'step' in st:
+                    steps.append(int(float(st['step'])))
+                for key, flat in zip(self._KEYS, flats):
+                    if flat is not None and st.get(key) is not None:
+                        flat[off:off + n].copy_(st[key].reshape(-1))
+            self._step = max(steps) if steps else (int(fused['step']) if fused and 'step' in fused else 0)
+        self._publish_views()
 
 
 def build_optimizer(model, optim='adam', lr=0.0003, weight_decay=5e-04, momentum=0.9, sgd_dampening=0,

@@ -7,10 +7,11 @@ IEEE3modalPart train / eval step in stock torch fp32 ops, arranged as the refere
   rem (closed form)             <- torchreid/models/ieee3modalPart.py:60-80
   cross_entropy_ls              <- torchreid/losses/cross_entropy_loss.py:36-50
   margin3m                      <- torchreid/losses/multi_modal_margin_loss_new.py:19-40
-  train_step                    <- torchreid/engine/image/margin.py:94-154 + optim/optimizer.py:130-138
+  train_step                    <- torchreid/engine/image/margin.py:94-154 (engine="margin") or
+                                   engine/image/softmax.py:81-132 (engine="softmax") + optim/optimizer.py:130-138
 
 Works on a plain dict name -> tensor with the reference's state_dict keys.  Pinned against the imported
-reference by tests/test_model_oracle.py (here) and tests/golden/model_golden.npz (everywhere).
+reference by tests/test_model_oracle.py (here) and tests/golden/model_golden.npz / model_golden_r2.npz (everywhere).
 """
 import torch
 import torch.nn.functional as F
@@ -140,15 +141,44 @@ def split_state(sd):
     return params, bufs
 
 
-def train_step(sd, xs, pids, num_classes, lr=1e-3, momentum=0.9, wd=5e-4, mom_state=None, margin=1.0, **flags):
+def softmax_losses(outputs, pids, num_classes):
+    """MultiModalImageSoftmaxEngine.forward_backward's loss and summary (engine/image/softmax.py:94-130)"""
+    oR, oN, oT = outputs[:3]
+    lR = sum(cross_entropy_ls(o, pids, num_classes) for o in oR)
+    lN = sum(cross_entropy_ls(o, pids, num_classes) for o in oN)
+    lT = sum(cross_entropy_ls(o, pids, num_classes) for o in oT)
+    acc = [sum(100.0 * (o.argmax(1) == pids).float().mean() for o in oo) / 6 for oo in (oR, oN, oT)]
+    loss = lR + lN + lT
+    return loss, dict(loss_all=loss, loss_R=lR, acc_R=acc[0], loss_N=lN, acc_N=acc[1], loss_T=lT, acc_T=acc[2])
+
+
+def calibrate_running_stats(sd, xs, **flags):
+    """running statistics := batch statistics of xs (one train-mode forward with momentum 1), in place; what
+    tests/golden/gen_model_golden_r2.py does to the reference model before its evaluation cases"""
+    global MOM
+    keep, MOM = MOM, 1.0
+    try:
+        with torch.no_grad():
+            forward(sd, xs, True, "margin", **flags)
+    finally:
+        MOM = keep
+    return sd
+
+
+def train_step(sd, xs, pids, num_classes, lr=1e-3, momentum=0.9, wd=5e-4, mom_state=None, margin=1.0, engine="margin",
+               **flags):
     """one engine step on CPU: returns (summary, grads, new_state, new_momentum).  SGD with nesterov
-    (hard-coded in the reference, optim/optimizer.py:137), dampening 0."""
+    (hard-coded in the reference, optim/optimizer.py:137), dampening 0.  engine = "margin" (Image3MEngine) or
+    "softmax" (MultiModalImageSoftmaxEngine: CE only, model built with loss='softmax')."""
     sd = {k: v.clone() for k, v in sd.items()}
     params, _ = split_state(sd)
     for p in params.values():
         p.requires_grad_(True)
-    out = forward(sd, xs, True, "margin", **flags)
-    loss, summary = losses(out, pids, num_classes, margin)
+    out = forward(sd, xs, True, engine, **flags)
+    if engine == "softmax":
+        loss, summary = softmax_losses(out, pids, num_classes)
+    else:
+        loss, summary = losses(out, pids, num_classes, margin)
     names = list(params)
     g = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
     grads = dict(zip(names, g))

@@ -1,0 +1,74 @@
+"""Summarise rocprofv3 --pmc passes (counter_collection.csv files) per kernel family into one JSON for profiles/.
+
+  python scripts/pmc_summary.py OUT.json DIR [DIR ...]      (every *_counter_collection.csv below the DIRs is read)
+
+Each pass was collected on its own (`rocprofv3 --pmc <counters> --output-format csv -d DIR -- python3 bench.py ...`, no
+trace domains beside it).  Per family: launches seen, the mean of every counter per launch, and the derived figures
+  hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024     gfx950: FETCH_SIZE counts 64 B per 128-B request on
+                                                                  wide coalesced reads (MI355X_MICROARCH.md, HBM)
+  l2_hit_rate          = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
+  mfma_busy            = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 4 SIMDs * 256 CUs)   share of MFMA-pipe cycles
+  wait_share           = SQ_WAIT_ANY / SQ_WAVE_CYCLES          wave-cycles parked in s_waitcnt / barriers
+  issue_stall_share    = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
+  active_share         = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+FAMILIES = (
+    ("conv_gather", "conv_gather_kernel"), ("conv_wgrad", "conv_wgrad_kernel"), ("wgrad_reduce", "wgrad_reduce_kernel"),
+    ("bn_apply", "bn_apply_kernel"), ("bn_bwd_apply", "bn_bwd_apply_kernel"), ("bn_bwd_reduce", "bn_bwd_reduce_kernel"),
+    ("bn_finalize", "finalize_kernel"), ("distmat", "distmat_kernel"), ("rank_query_fast", "rank_query_fast_kernel"),
+    ("sgd", "sgd_nesterov_kernel"), ("pack", "pack_all_kernel"), ("cim", "cim_"), ("sgemm", "sgemm_"),
+)
+
+
+def family(name):
+    for fam, key in FAMILIES:
+        if key in name:
+            return fam
+    return "other"
+
+
+def main():
+    out_path, dirs = sys.argv[1], sys.argv[2:]
+    sums = collections.defaultdict(lambda: collections.defaultdict(float))
+    counts = collections.defaultdict(lambda: collections.defaultdict(int))
+    for d in dirs:
+        for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            with open(path, newline="") as f:
+                for row in csv.DictReader(f):
+                    fam = family(row["Kernel_Name"])
+                    c = row["Counter_Name"]
+                    sums[fam][c] += float(row["Counter_Value"])
+                    counts[fam][c] += 1
+    res = {"_note": __doc__.split("\n\n")[1].replace("\n", " ") if False else
+           "rocprofv3 --pmc passes (one counter group per pass) summarised by scripts/pmc_summary.py; per-launch means"}
+    for fam in sorted(sums):
+        m = {c: sums[fam][c] / counts[fam][c] for c in sums[fam]}
+        e = {"launches": max(counts[fam].values()), "per_launch": m}
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            e["hbm_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
+        if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m and m["TCC_HIT_sum"] + m["TCC_MISS_sum"] > 0:
+            e["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+        if "SQ_WAVE_CYCLES" in m and m["SQ_WAVE_CYCLES"] > 0:
+            for key, c in (("wait_share", "SQ_WAIT_ANY"), ("issue_stall_share", "SQ_WAIT_INST_ANY"),
+                           ("active_share", "SQ_ACTIVE_INST_ANY"), ("lds_stall_share", "SQ_WAIT_INST_LDS")):
+                if c in m:
+                    e[key] = m[c] / m["SQ_WAVE_CYCLES"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE", 0) > 0:
+            e["mfma_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8.0 * 4 * 256)
+        if "SQ_LDS_BANK_CONFLICT" in m and m.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
+            e["lds_conflict_share"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
+        res[fam] = e
+    if len(sys.argv) > 1:
+        with open(out_path, "w") as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_launch"} for k, v in res.items() if k != "_note"}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -33,14 +33,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, B=16):
     from oracle import model as om
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
                       LOCAL_RANK=str(rank))
     w, r, _ = ddp.init_from_env(backend="gloo")
     assert (w, r) == (world, rank) and ddp.world_size() == world and ddp.rank() == rank
     torch.manual_seed(0)                      # same global batch on every rank
-    B, K, C, D = 16, 4, 11, 32
+    K, C, D = 4, 11, 32
     logits = torch.randn(6, B, C)
     feats = torch.nn.functional.normalize(torch.randn(3, B, D), dim=2)
     pids = torch.arange(B) // K
@@ -59,7 +59,9 @@ def _worker(rank, world, port, ret):
     ll = logits[:, a:b].clone().requires_grad_(True)
     fl = feats[:, a:b].clone().requires_grad_(True)
     lp = pids[a:b]
-    local = ddp.ce_grad_scale() * sum(om.cross_entropy_ls(ll[h], lp, C) for h in range(6)) \
+    # CE is a batch MEAN: each rank weighs its mean by B_local / B_global (uneven shards when identities % world != 0)
+    assert abs(ddp.ce_grad_scale(b - a) - (b - a) / B) < 1e-12 and ddp.global_rows(b - a) == B
+    local = ddp.ce_grad_scale(b - a, B) * sum(om.cross_entropy_ls(ll[h], lp, C) for h in range(6)) \
         + om.margin3m(fl[0], fl[1], fl[2], lp, 1.0)
     local.backward()
     flat = torch.zeros(6 * B * C + 3 * B * D)
@@ -79,12 +81,66 @@ def _worker(rank, world, port, ret):
     ret[rank] = 1
 
 
-def test_two_rank_gloo_allreduce_and_loss_scaling():
-    world = 2
+@pytest.mark.parametrize("world,B", [(2, 16), (3, 32)])      # (3, 32): 8 identities over 3 ranks = shards of 12, 12, 8 rows
+def test_gloo_allreduce_and_loss_scaling(world, B):
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
-        assert dict(ret) == {0: 1, 1: 1}
+        mp.spawn(_worker, args=(world, _free_port(), ret, B), nprocs=world, join=True)
+        assert dict(ret) == {r: 1 for r in range(world)}
+
+
+# ---- replica synchronisation and the sharded feature extraction of the evaluator
+class _FlatModel(object):
+    """the three flat buffers dist.sync_replicas works on (IEEE3modalPart keeps exactly these)"""
+
+    def __init__(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        self._flat_params = torch.randn(1000, generator=g)
+        self._flat_buffers = torch.randn(50, generator=g)
+        self._flat_counters = torch.randint(0, 9, (7,), generator=g)
+        self.invalidated = 0
+
+    def invalidate_eval_cache(self):
+        self.invalidated += 1
+
+
+class _FlatOpt(object):
+    def __init__(self, seed):
+        self.buf = torch.full((1000,), float(seed))
+
+    def flat_state(self):
+        return [self.buf]
+
+
+def _sync_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    ddp.init_from_env(backend="gloo")
+    ref = _FlatModel(100)                                  # what rank 0 holds
+    m, opt = _FlatModel(100 + rank), _FlatOpt(rank)        # every rank starts from its own draw
+    own_params = m._flat_params.clone()
+    ddp.sync_replicas(m, buffers_only=True)                # evaluation: rank 0's running statistics, parameters untouched
+    assert torch.equal(m._flat_buffers, ref._flat_buffers) and torch.equal(m._flat_counters, ref._flat_counters)
+    assert torch.equal(m._flat_params, own_params) and m.invalidated == 1
+    ddp.sync_replicas(m, opt)                              # first train step: everything, optimizer state included
+    assert torch.equal(m._flat_params, ref._flat_params) and torch.equal(opt.buf, torch.zeros(1000))
+    # sharded feature extraction: 5 loader batches of uneven size, rank r holds batches r, r + world, ...
+    rows = [4, 4, 3, 4, 1]
+    full = torch.arange(sum(rows) * 6, dtype=torch.float32).view(-1, 6)
+    starts = [sum(rows[:b]) for b in range(len(rows))]
+    local = {b: full[starts[b]:starts[b] + rows[b]].clone() for b in range(rank, len(rows), world)}
+    out = ddp.gather_feature_batches(local, rows, 6, torch.device("cpu"))
+    assert torch.equal(out, full)
+    dist.destroy_process_group()
+    ret[rank] = 1
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_replica_sync_and_sharded_feature_gather(world):
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_sync_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert dict(ret) == {r: 1 for r in range(world)}
 
 
 # ---- query-sharded evaluator (SURVEY.md §8e): host logic + the single 22-number all-reduce

@@ -22,6 +22,7 @@ def _free_port():
 
 class FakeDM(object):
     num_train_pids = C
+    num_instances = 4
     train_loader = []
     test_loader = {}
     sources = ["synthetic"]
@@ -51,9 +52,8 @@ def _worker(rank, world, port, out_path):
                       LOCAL_RANK=str(rank), IEEE_DIST_BACKEND="gloo", IEEE_FORCE_DEVICE="0")
     from ieee_amd import dist as ddp
     ddp.init_from_env()
-    eng, m = _build(7)
-    shard = ddp.shard_batch(_batch(16, 7), 4)
-    s = eng.forward_backward(shard)
+    eng, m = _build(7 + rank)             # every rank draws its own weights: the first step broadcasts rank 0's
+    s = eng.forward_backward(_batch(16, 7))   # the GLOBAL batch: the engine keeps this rank's identity-aligned half
     if rank == 0:
         torch.save({"grads": m._flat_grads.cpu(), "loss": s["loss"]}, out_path)
     torch.distributed.destroy_process_group()

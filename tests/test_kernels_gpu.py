@@ -128,15 +128,23 @@ def _cim_torch(F3, w, flags):
     return torch.stack(outs)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_cim_tail_chain_fwd_bwd_fp32(mode):
-    """ca_pool -> CA MLP (grouped GEMMs) -> cim_tail forward, and the full backward chain, vs autograd"""
+def test_cim_tail_chain_fwd_bwd(mode, dtype):
+    """ca_pool -> CA MLP (grouped GEMMs) -> cim_tail forward, and the full backward chain (cim_tail_bwd_datt,
+    cim_tail_bwd_g with its fused BN-backward sums, bn2d_bwd), vs autograd.  bf16: the conv outputs and the two
+    gradient maps are bf16 tensors (the storage of the speed mode), everything pooled / reduced stays fp32; the
+    reference is torch fp32 on the SAME bf16-rounded inputs, so what is measured is the kernels' own arithmetic and the
+    one bf16 rounding of each stored gradient element."""
     L, lib = _lib()
     from ieee_amd import _ops
     g = torch.Generator().manual_seed(mode)
     B, H, W, C, hid = 3, 16, 8, 256, 16
     P = H * W
-    w = {"y1": torch.randn(3, B, C, H, W, generator=g), "y2": torch.randn(3, B, C, H, W, generator=g),
+    bf = dtype == torch.bfloat16
+    dt = L.IEEE_BF16 if bf else L.IEEE_F32
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
+    w = {"y1": rnd(torch.randn(3, B, C, H, W, generator=g)), "y2": rnd(torch.randn(3, B, C, H, W, generator=g)),
          "g1": torch.rand(3, C, generator=g) + 0.5, "b1": torch.randn(3, C, generator=g) * 0.2,
          "g2": torch.rand(3, C, generator=g) + 0.5, "b2": torch.randn(3, C, generator=g) * 0.2,
          "w1": torch.randn(3, hid, C, 1, 1, generator=g) * 0.1, "w2": torch.randn(3, C, hid, 1, 1, generator=g) * 0.1}
@@ -147,14 +155,14 @@ def test_cim_tail_chain_fwd_bwd_fp32(mode):
     parts_ref.backward(dparts)
 
     dev = "cuda"
-    nhwc = lambda t: t.detach().permute(0, 1, 3, 4, 2).contiguous().to(dev)
+    nhwc = lambda t: t.detach().permute(0, 1, 3, 4, 2).contiguous().to(dev).to(dtype)
     y1, y2 = nhwc(w["y1"]), nhwc(w["y2"])
     st1, st2 = torch.empty(3, 4, C, device=dev), torch.empty(3, 4, C, device=dev)
-    npart = lib.ieee_bn_partial_floats(0, B * P, C)
+    npart = lib.ieee_bn_partial_floats(dt, B * P, C)
     part = torch.empty(3 * npart + 64, device=dev)
     for y, ga, be, st in ((y1, w["g1"], w["b1"], st1), (y2, w["g2"], w["b2"], st2)):
         gd, bd = ga.detach().to(dev), be.detach().to(dev)
-        L.check(lib.ieee_bn2d_fwd(L.ptr(y), None, None, 0, 3, B * P, C, B * P * C, L.ptr(gd), L.ptr(bd), C, None, None, 0,
+        L.check(lib.ieee_bn2d_fwd(L.ptr(y), None, None, dt, 3, B * P, C, B * P * C, L.ptr(gd), L.ptr(bd), C, None, None, 0,
                                   L.ptr(st), L.ptr(part), 0.1, 1e-5, 1, 1, 0, L.stream()))
     avgmax = torch.empty(3, 2 * B, C, device=dev)
     amax = torch.empty(3, B, C, device=dev, dtype=torch.int32)
@@ -167,7 +175,7 @@ def test_cim_tail_chain_fwd_bwd_fp32(mode):
         return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     if mode == 0:
         L.check(lib.ieee_ca_pool(L.ptr(y2), L.ptr(st2), L.ptr(avgmax), ctypes.c_void_p(avgmax.data_ptr() + B * C * 4),
-                                 2 * B * C, L.ptr(amax), 0, B, H, W, C, L.stream()))
+                                 2 * B * C, L.ptr(amax), dt, B, H, W, C, L.stream()))
         L.check(lib.ieee_sgemm_grouped(3, tab(list(avgmax)), tab(list(w1d)), tab(list(Hh)), None, 2 * B, hid, C, C, 1, C, 1,
                                        hid, 1.0, 1, 0, L.stream()))
         L.check(lib.ieee_ca_mix_fwd(L.ptr(Hh), L.ptr(Hs), B, hid, L.stream()))
@@ -175,16 +183,16 @@ def test_cim_tail_chain_fwd_bwd_fp32(mode):
                                        1.0, 0, 0, L.stream()))
         L.check(lib.ieee_sigmoid_fwd(L.ptr(att), att.numel(), L.stream()))
     Pp = torch.empty(3, B, 6, C, device=dev)
-    L.check(lib.ieee_cim_tail_fwd(L.ptr(y1), L.ptr(y2), L.ptr(st1), L.ptr(st2), L.ptr(att), L.ptr(Pp), 0, B, H, W, C, 6,
+    L.check(lib.ieee_cim_tail_fwd(L.ptr(y1), L.ptr(y2), L.ptr(st1), L.ptr(st2), L.ptr(att), L.ptr(Pp), dt, B, H, W, C, 6,
                                   mode, L.stream()))
-    torch.testing.assert_close(Pp.cpu(), parts_ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(Pp.cpu(), parts_ref.detach(), rtol=1e-4, atol=2e-5)        # inputs exact in both dtypes
     # ---- backward chain
     dP = dparts.to(dev)
     datt = torch.zeros(3, B, C, device=dev)
     davgmax = torch.zeros(3, 2 * B, C, device=dev)
     dw1, dw2 = torch.zeros_like(w1d), torch.zeros_like(w2d)
     if mode == 0:
-        L.check(lib.ieee_cim_tail_bwd_datt(L.ptr(dP), L.ptr(y2), L.ptr(st2), L.ptr(datt), 0, B, H, W, C, 6, L.stream()))
+        L.check(lib.ieee_cim_tail_bwd_datt(L.ptr(dP), L.ptr(y2), L.ptr(st2), L.ptr(datt), dt, B, H, W, C, 6, L.stream()))
         L.check(lib.ieee_sigmoid_bwd(L.ptr(datt), L.ptr(att), L.ptr(datt), datt.numel(), L.stream()))
         dHs, dH = torch.empty_like(Hs), torch.empty_like(Hh)
         L.check(lib.ieee_sgemm_grouped(3, tab(list(datt)), tab(list(Hs)), tab(list(dw2)), None, C, hid, B, 1, C, 1, hid, hid,
@@ -201,47 +209,58 @@ def test_cim_tail_chain_fwd_bwd_fp32(mode):
     bp1, bp2 = torch.zeros(3, 2, C, B, device=dev), torch.zeros(3, 2, C, B, device=dev)
     L.check(lib.ieee_cim_tail_bwd_g(L.ptr(dP), L.ptr(y1), L.ptr(y2), L.ptr(st1), L.ptr(st2), L.ptr(att), L.ptr(davgmax),
                                     ctypes.c_void_p(davgmax.data_ptr() + B * C * 4), 2 * B * C, L.ptr(amax), L.ptr(g1),
-                                    L.ptr(g2), 0, B, H, W, C, 6, mode, L.ptr(bp1), L.ptr(bp2), L.stream()))
-    for bp, gq, y in ((bp1, g1, y1), (bp2, g2, y2)):
-        torch.testing.assert_close(bp[:, 0].sum(-1), gq.view(3, -1, C).sum(1), rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(bp[:, 1].sum(-1), (gq * y).view(3, -1, C).sum(1), rtol=1e-4, atol=1e-4)
+                                    L.ptr(g2), dt, B, H, W, C, 6, mode, L.ptr(bp1), L.ptr(bp2), L.stream()))
+    for bp, gq, y in ((bp1, g1, y1), (bp2, g2, y2)):     # the fused sums are sums of the STORED (rounded) gradient
+        torch.testing.assert_close(bp[:, 0].sum(-1), gq.float().view(3, -1, C).sum(1), rtol=1e-4, atol=2e-4 if bf else 1e-4)
+        torch.testing.assert_close(bp[:, 1].sum(-1), (gq.float() * y.float()).view(3, -1, C).sum(1), rtol=1e-4,
+                                   atol=2e-4 if bf else 1e-4)
     coef = torch.empty(3, 3, C, device=dev)
     res = {}
     for name, gq, y, ga, st, bp in (("1", g1, y1, w["g1"], st1, bp1), ("2", g2, y2, w["g2"], st2, bp2)):
         gd = ga.detach().to(dev)
         dg, db = torch.zeros(3, C, device=dev), torch.zeros(3, C, device=dev)
-        L.check(lib.ieee_bn2d_bwd(L.ptr(gq), None, L.ptr(y), L.ptr(gq), None, 0, 3, B * P, C, B * P * C, L.ptr(gd), C,
+        L.check(lib.ieee_bn2d_bwd(L.ptr(gq), None, L.ptr(y), L.ptr(gq), None, dt, 3, B * P, C, B * P * C, L.ptr(gd), C,
                                   L.ptr(st), L.ptr(dg), L.ptr(db), C, L.ptr(bp), L.ptr(coef), 0, 0, B, L.stream()))
         res["dy" + name], res["dg" + name], res["db" + name] = gq, dg, db
-    back = lambda t: t.cpu().permute(0, 1, 4, 2, 3)
-    torch.testing.assert_close(back(res["dy1"]), w["y1"].grad, rtol=2e-3, atol=2e-5)
-    torch.testing.assert_close(back(res["dy2"]), w["y2"].grad, rtol=2e-3, atol=2e-5)
-    torch.testing.assert_close(res["dg1"].cpu(), w["g1"].grad, rtol=1e-3, atol=1e-4)
-    torch.testing.assert_close(res["db2"].cpu(), w["b2"].grad, rtol=1e-3, atol=1e-4)
-    if mode == 0:
+    back = lambda t: t.float().cpu().permute(0, 1, 4, 2, 3)
+    # bf16: g is rounded once when stored (2^-9 relative), dy once more, and dy = k1*g + k2*y + k3 cancels partly
+    tol_dy = dict(rtol=2e-2, atol=2e-3) if bf else dict(rtol=2e-3, atol=2e-5)
+    tol_p = dict(rtol=5e-3, atol=2e-3) if bf else dict(rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(back(res["dy1"]), w["y1"].grad, **tol_dy)
+    torch.testing.assert_close(back(res["dy2"]), w["y2"].grad, **tol_dy)
+    torch.testing.assert_close(res["dg1"].cpu(), w["g1"].grad, **tol_p)
+    torch.testing.assert_close(res["db2"].cpu(), w["b2"].grad, **tol_p)
+    if mode == 0:       # the attention branch only touches fp32 tensors
         torch.testing.assert_close(dw1.cpu().view_as(w["w1"]), w["w1"].grad, rtol=1e-3, atol=1e-5)
         torch.testing.assert_close(dw2.cpu().view_as(w["w2"]), w["w2"].grad, rtol=1e-3, atol=1e-5)
 
 
-def test_gpool_sum_others_and_combine():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gpool_sum_others_and_combine(dtype):
+    """global average pool + sum of the two other modalities (forward) and the three-way gradient combine (backward);
+    bf16: bf16 maps in / out, fp32 pooled vectors, checked against fp32 torch on the same rounded inputs (each stored
+    element rounded once)"""
     L, lib = _lib()
     g = torch.Generator().manual_seed(3)
     B, H, W, C = 2, 16, 8, 128
-    Fm = torch.randn(3, B, H * W, C, generator=g).cuda()
+    bf = dtype == torch.bfloat16
+    dt = L.IEEE_BF16 if bf else L.IEEE_F32
+    Fm = torch.randn(3, B, H * W, C, generator=g).cuda().to(dtype)
     S = torch.empty_like(Fm)
     Gp = torch.empty(3, B, C, device="cuda")
-    L.check(lib.ieee_gpool_sum_others(L.ptr(Fm), L.ptr(S), L.ptr(Gp), 0, B, H, W, C, L.stream()))
-    torch.testing.assert_close(Gp, Fm.mean(2), rtol=1e-5, atol=1e-6)
+    L.check(lib.ieee_gpool_sum_others(L.ptr(Fm), L.ptr(S), L.ptr(Gp), dt, B, H, W, C, L.stream()))
+    torch.testing.assert_close(Gp, Fm.float().mean(2), rtol=1e-5, atol=1e-6)
     for m in range(3):
         a, b = [k for k in range(3) if k != m]
-        torch.testing.assert_close(S[m], Fm[a] + Fm[b])
+        assert torch.equal(S[m], (Fm[a].float() + Fm[b].float()).to(dtype))           # one exact add, one rounding
     D1, DS = torch.randn_like(Fm), torch.randn_like(Fm)
     dG = torch.randn(3, B, C, device="cuda")
     dF = torch.empty_like(Fm)
-    L.check(lib.ieee_cim_bwd_combine(L.ptr(D1), L.ptr(DS), L.ptr(dG), L.ptr(dF), 0, B, H, W, C, 0, L.stream()))
+    L.check(lib.ieee_cim_bwd_combine(L.ptr(D1), L.ptr(DS), L.ptr(dG), L.ptr(dF), dt, B, H, W, C, 0, L.stream()))
     for m in range(3):
         a, b = [k for k in range(3) if k != m]
-        torch.testing.assert_close(dF[m], D1[m] + DS[a] + DS[b] + dG[m][:, None, :] / (H * W), rtol=1e-5, atol=1e-6)
+        ref = D1[m].float() + DS[a].float() + DS[b].float() + dG[m][:, None, :] / (H * W)
+        torch.testing.assert_close(dF[m].float(), ref, rtol=2 ** -8 if bf else 1e-5, atol=1e-6)
 
 
 def test_rowbn_rem_l2norm_fwd_bwd():

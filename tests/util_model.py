@@ -39,3 +39,46 @@ def compare_stats(mine, ref, names, rtol, what):
             bad.append((name, e_norm, e_samp, n_ref))
     assert not bad, "%s mismatch on %d/%d tensors, worst: %s" % (
         what, len(bad), len(names), sorted(bad, key=lambda b: -max(b[1], b[2]))[:8])
+
+
+# ---- round-2 evaluation / loop fixtures (tests/golden/gen_model_golden_r2.py uses the same definitions) ------------
+Q_PIDS = [0, 1, 2, 3, 0, 1, 2, 3]
+Q_CAMS = [0] * 8
+G_PIDS = [0, 0, 1, 1, 2, 2, 3, 3, 0, 1, 2, 3, 4, 4, 5, 5, 0, 1, 2, 3, 6, 6, 7, 7]
+G_CAMS = [1, 2, 1, 2, 1, 2, 1, 2, 0, 0, 0, 0, 1, 2, 1, 2, 3, 3, 3, 3, 1, 2, 1, 2]
+
+
+def id_images(pids, cams, seed):
+    return [torch.from_numpy(x) for x in detgen.generate_identity_images(pids, cams, seed, noise=0.5)]
+
+
+def id_loader(n, seed, pids, cams, bs=4):
+    """the reference's batch-dict format (data/datasets/dataset.py:344-351)"""
+    xs = id_images(pids, cams, seed)
+    return [{"img": [x[i:i + bs] for x in xs], "pid": torch.as_tensor(pids[i:i + bs]), "camid": torch.as_tensor(cams[i:i + bs]),
+             "impath": "", "timeid": torch.zeros(len(pids[i:i + bs]))} for i in range(0, n, bs)]
+
+
+def eval_loaders():
+    return {"query": id_loader(8, 11, Q_PIDS, Q_CAMS), "gallery": id_loader(24, 12, G_PIDS, G_CAMS)}
+
+
+def run2_train_loader():
+    out = []
+    for i in range(2):
+        pids = torch.full((4,), i, dtype=torch.long)
+        out.append({"img": id_images([i] * 4, [0, 1, 2, 3], 20 + i), "pid": pids, "camid": pids * 0, "impath": "",
+                    "timeid": pids * 0})
+    return out
+
+
+def calibrated_state(shapes, seed):
+    """generated weights with the running statistics calibrated on the gallery images by the ORACLE (one train-mode
+    forward with momentum 1), as gen_model_golden_r2.py does with the reference model"""
+    from oracle import model as om
+    sd = generated_state(shapes, seed)
+    om.calibrate_running_stats(sd, id_images(G_PIDS, G_CAMS, 12))
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros_like(sd[k])
+    return sd
