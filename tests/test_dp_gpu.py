@@ -122,3 +122,56 @@ def test_two_rank_sharded_evaluator_equals_single_device(tmp_path):
         got = torch.load(out + str(r))
         assert torch.equal(got["cmc"], torch.from_numpy(cmc))          # integer-grid features: no ties in rounding
         assert abs(got["mAP"] - m_ap) < 1e-12
+
+
+# ---- sharded evaluation end to end: every rank runs the forward for every second loader batch,
+# one all-gather completes the descriptors, the ranking is sharded by query; rank 1 starts with DIFFERENT running
+# statistics and must end up evaluating with rank 0's (what nn.DataParallel does)
+def _engine_eval_worker(rank, world, port, out_path):
+    import io
+    from contextlib import redirect_stdout
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), IEEE_DIST_BACKEND="gloo", IEEE_FORCE_DEVICE="0")
+    from ieee_amd import dist as ddp
+    from ieee_amd._spec import state_spec
+    from ieee_amd.engine import Image3MEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    from tests.util_model import calibrated_state, eval_loaders
+    ddp.init_from_env()
+    torch.set_num_threads(8)
+    state = calibrated_state({k: s for k, s, _ in state_spec(C)}, 8)
+    m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, compute_dtype=torch.float32)
+    m.load_state_dict(state)
+    if rank == 1:
+        with torch.no_grad():
+            m._flat_buffers.mul_(1.5)
+
+    class DM(FakeDM):
+        test_loader = {"synthetic": eval_loaders()}
+    eng = Image3MEngine(DM(), m, build_optimizer(m, optim="sgd", lr=1e-3), margin=1, use_gpu=True)
+    seen = []
+    extract = eng.extract_features
+
+    def counting(imgs, timeids):
+        seen.append(int(imgs[0].shape[0]))
+        return extract(imgs, timeids)
+    eng.extract_features = counting
+    with redirect_stdout(io.StringIO()) as buf:
+        m_ap = eng.test()
+    torch.save({"mAP": m_ap, "batches": len(seen), "printed": buf.getvalue()}, out_path + str(rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_sharded_engine_test_equals_reference(tmp_path, golden_dir):
+    import numpy as np
+    G = np.load(os.path.join(golden_dir, "model_golden_r2.npz"))
+    out = str(tmp_path / "evt.pt")
+    mp.spawn(_engine_eval_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = [torch.load(out + str(r)) for r in range(2)]
+    assert got[0]["batches"] == got[1]["batches"] == 4          # 2 + 6 loader batches, every second one per rank
+    for r in range(2):
+        assert abs(got[r]["mAP"] - float(G["evalpipe/mAP"])) < 1e-9
+        assert "queries sharded over 2 ranks" in got[r]["printed"]
+        ref = [l for l in str(G["evalpipe/printed"]).splitlines() if l.startswith(("mAP", "Rank-"))]
+        assert [l for l in got[r]["printed"].splitlines() if l.startswith(("mAP", "Rank-"))] == ref
