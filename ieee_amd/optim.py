@@ -29,6 +29,7 @@ class FusedSGD(torch.optim.Optimizer):
         m = self.model
         buf = self.momentum_buffer()
         m._native_epoch += 1                      # parameters change behind torch's version counters
+        self._opt_called = True                   # what torch's schedulers look at to order step() calls (step_part too)
         for a, b in runs:
             _lib.check(lib.ieee_sgd_nesterov_step(_lib.ptr(m._flat_params[a:b]), _lib.ptr(m._flat_grads[a:b]),
                                                   _lib.ptr(buf[a:b]), b - a, float(g['lr']), float(g['momentum']),
