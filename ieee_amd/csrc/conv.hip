@@ -170,17 +170,24 @@ template <typename T, int MODE> struct StagedStoreEpi {
       }
     }
     if constexpr (STATS) {
-      // reduce over the RPP row-lanes that share a chunk, through LDS (the staged tile is consumed)
+      // reduce over the RPP row-lanes that share a chunk, through LDS (the staged tile is consumed).  Layout: one plane of
+      // 256 floats ([r0][ch] = the thread index) per (quantity, element), planes 260 floats apart: the 16 stores of a
+      // thread are lane-contiguous, and the column sums below read banks 4*e + cc + 16*y -- both conflict-free (the
+      // [thread][16 values] layout this replaces put lanes t and t+2 on one bank: 16-way conflicts on every store,
+      // 21 % of all LDS cycles of the conv kernels by SQ_LDS_BANK_CONFLICT)
       __syncthreads();
-      float* red = (float*)smem;   // [RPP][CPRW][2*VEC]
+      float* red = (float*)smem;   // [2*VEC][260]
+      constexpr int PLANE = 260;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) { red[(r0 * CPRW + ch) * 2 * VEC + e] = s1[e]; red[(r0 * CPRW + ch) * 2 * VEC + VEC + e] = s2[e]; }
+      for (int e = 0; e < VEC; ++e) { red[e * PLANE + t] = s1[e]; red[(VEC + e) * PLANE + t] = s2[e]; }
       __syncthreads();
       for (int idx = t; idx < BN * 2; idx += 256) {
         const int q = idx / BN, c = idx % BN;          // quantity, channel within the tile
         const int cc = c / VEC, e = c % VEC;
+        const float* col = red + (q * VEC + e) * PLANE + cc;
         float s = 0.f;
-        for (int y = 0; y < RPP; ++y) s += red[(y * CPRW + cc) * 2 * VEC + q * VEC + e];
+#pragma unroll
+        for (int y = 0; y < RPP; ++y) s += col[y * CPRW];
         if (n0 + c < N) bn_partial[((int64_t)q * N + n0 + c) * tiles_m + tile_m] = s;
       }
     }
@@ -288,13 +295,15 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
   if constexpr (PIPE > 0) {   // both operands through LDS-DMA
     static_assert(!SLOW && sizeof(T) == 2, "the LDS-DMA ring is the bf16 vector path");
     const int ch = nt_dma_chunk(threadIdx.x);
-    LoaderPlainNT<T, BN / 32> lbd;
-    lbd.init(w, a.ldw, n0, a.N, a.ldw, ch);
+    // the packed weights are a plain [N][ldw] matrix (ldw = ktiles * 64, zero padded): lean issue, see glds16_lean
+    LoaderPlainLean<BN / 32> lbd;
+    lbd.init(w, a.ldw, n0, a.N, ch);
     if (a.g.R == 1 && a.g.S == 1 && a.g.mul == 1 && a.g.off == 0 && a.g.div == 1) {
       // 1x1 / stride 1 / no padding (two thirds of the launches): im2col(X) is X itself, a plain [pixels][C] matrix --
-      // no pixel decode, no tap masks (their set-up rivals the whole k-loop of the K = 64..256 layers)
-      LoaderPlainNT<T, 4> la;
-      la.init(src, a.g.Cs, m0, a.g.npix, a.g.Cs, ch);
+      // no pixel decode, no tap masks (their set-up rivals the whole k-loop of the K = 64..256 layers), and the same
+      // lean issue as the weights (C is a multiple of 64 on this path: no k tail)
+      LoaderPlainLean<4> la;
+      la.init(src, a.g.Cs, m0, a.g.npix, ch);
       gemm_nt_dma<128, BN, PIPE>(la, lbd, epi, a.ktiles, m0, n0, smem);
     } else {
       LoaderIm2colNT<T, 4> la;
@@ -322,6 +331,7 @@ struct WgradArgs {
   int Co, ncols;      // GEMM M (= Cout), N (= R*S*Cin)
   int npix, kchunk;   // GEMM K (= N*Ho*Wo) and the K range per split
   int tiles_n, tiles, nsplit, groups, xcd_group, plain_x;
+  int lean;           // every split covers whole k-tiles and the channel counts allow the clamped lean loaders
   int64_t dy_gs, x_gs, slab_gs;   // per-modality strides; slab_gs covers all splits of one modality
 };
 
@@ -369,6 +379,20 @@ __global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wg
   if constexpr (PIPE > 0) {   // LDS-DMA ring (see conv_gather_kernel)
     static_assert(!SLOW && sizeof(T) == 2, "the LDS-DMA ring is the bf16 vector path");
     const int ch = tn_dma_chunk(threadIdx.x);
+    if (a.lean) {   // every split is a whole number of k-tiles: no zero fill needed -> lean issue (glds16_lean) for dY
+      LoaderColsLean lad;
+      lad.init(dy, a.Co, m0, a.Co, kbeg, ch);
+      if (a.plain_x) {
+        LoaderColsLean lbd;
+        lbd.init(x, a.ncols, n0, a.ncols, kbeg, ch);
+        gemm_tn_dma<PIPE, HALF_M>(lad, lbd, epi, ktiles, m0, n0, smem);
+      } else {
+        LoaderIm2colTN<T> lbd;
+        lbd.init(x, a.g, n0, kbeg, kend, ch);
+        gemm_tn_dma<PIPE, HALF_M>(lad, lbd, epi, ktiles, m0, n0, smem);
+      }
+      return;
+    }
     LoaderColsTN<T> lad;
     lad.init(dy, a.Co, m0, a.Co, kbeg, kend, ch);
     if (a.plain_x) {   // 1x1 / stride 1 / no padding: im2col(X) is X itself
@@ -715,7 +739,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   {   // the LDS-staged epilogue needs the C tile: bf16 rows padded by 16 B, fp32 rows unpadded
     const size_t bn = plan.bn;
     const size_t epi_bytes = 128 * (bn * sizeof(T) + (sizeof(T) == 2 ? 16 : 0));
-    const size_t red_bytes = 16 * 1024;   // BN-sum reduction scratch
+    const size_t red_bytes = 2 * (16 / sizeof(T)) * 260 * 4;   // BN-sum reduction scratch: [2*VEC] planes of 260 floats
     if (smem < epi_bytes) smem = epi_bytes;
     if (smem < red_bytes) smem = red_bytes;
   }
@@ -1003,6 +1027,7 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
                                           stride % (vec / Ci) == 0);
   const bool slow = !chunk_ok;
   a.plain_x = (d.R == 1 && d.S == 1 && d.stride == 1 && d.pad == 0) ? 1 : 0;
+  a.lean = (a.npix % bk == 0 && d.Co >= 8 && a.ncols >= 8) ? 1 : 0;
   const int nkz = nsplit * (int)groups;
   static const int f_map = getenv("IEEE_WGRAD_MAP") ? atoi(getenv("IEEE_WGRAD_MAP")) : 2;
   a.xcd_group = (nkz >= 24 || nkz % 8 == 0) ? 1 : f_map;

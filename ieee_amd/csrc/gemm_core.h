@@ -291,6 +291,46 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
                : "memory");
 }
 
+// Lean form for plain row-major operands (weights; the activations of 1x1 / stride-1 convs): the k-tile's global
+// address is a WAVE-UNIFORM 64-bit base in SGPRs (advanced by one scalar add per k-tile) plus a per-lane 32-bit byte
+// offset that never changes, so a whole tile is issued with ZERO vector instructions (the pointer form above costs ~8
+// VALU per 16-byte slot: 64-bit select of the zero page + 64-bit add -- 63 VALU + 54 SALU per k-tile against 32 MFMAs
+// in the 128x128 core).  N consecutive slots land 4096 LDS bytes apart (32 rows of 128 B): M0 steps by one s_add.
+template <int N> __device__ __forceinline__ void glds16_lean(const unsigned (&voff)[N], const void* sbase, char* lds_wave_base);
+#define IEEE_GLDS_STEP(v) "s_nop 0\n\tglobal_load_lds_dwordx4 " v ", %[b]\n\ts_add_u32 m0, m0, 0x1000\n\t"
+template <> __device__ __forceinline__ void glds16_lean<2>(const unsigned (&voff)[2], const void* sbase, char* lds_wave_base) {
+  const unsigned dst =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\t" IEEE_GLDS_STEP("%[v0]") IEEE_GLDS_STEP("%[v1]") "s_mov_b32 m0, %[k]"
+               : [k] "=&s"(keep)
+               : [v0] "v"(voff[0]), [v1] "v"(voff[1]), [b] "s"(sbase), [d] "s"(dst)
+               : "memory", "scc");
+}
+template <> __device__ __forceinline__ void glds16_lean<4>(const unsigned (&voff)[4], const void* sbase, char* lds_wave_base) {
+  const unsigned dst =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\t" IEEE_GLDS_STEP("%[v0]") IEEE_GLDS_STEP("%[v1]") IEEE_GLDS_STEP("%[v2]")
+               IEEE_GLDS_STEP("%[v3]") "s_mov_b32 m0, %[k]"
+               : [k] "=&s"(keep)
+               : [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [b] "s"(sbase), [d] "s"(dst)
+               : "memory", "scc");
+}
+template <> __device__ __forceinline__ void glds16_lean<8>(const unsigned (&voff)[8], const void* sbase, char* lds_wave_base) {
+  const unsigned dst =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\t" IEEE_GLDS_STEP("%[v0]") IEEE_GLDS_STEP("%[v1]") IEEE_GLDS_STEP("%[v2]")
+               IEEE_GLDS_STEP("%[v3]") IEEE_GLDS_STEP("%[v4]") IEEE_GLDS_STEP("%[v5]") IEEE_GLDS_STEP("%[v6]") IEEE_GLDS_STEP("%[v7]")
+               "s_mov_b32 m0, %[k]"
+               : [k] "=&s"(keep)
+               : [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [v4] "v"(voff[4]), [v5] "v"(voff[5]),
+                 [v6] "v"(voff[6]), [v7] "v"(voff[7]), [b] "s"(sbase), [d] "s"(dst)
+               : "memory", "scc");
+}
+#undef IEEE_GLDS_STEP
+
 // NT logical chunk of thread t (same for every slot: rows advance by 32, the key (row>>1)&7 does not change)
 __device__ __forceinline__ int nt_dma_chunk(int t) { return (t & 7) ^ ((t >> 4) & 7); }
 // TN logical chunk (bf16, 16 chunks per 256-B k-row): physical window (t&15)>>1, key h(k-row)
@@ -337,10 +377,18 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
 
   auto issue = [&](int stage_idx) {
     char* stage = smem + stage_idx * STAGE;
+    if constexpr (LA::kLean) {
+      glds16_lean<ACH>(la.off, la.base, stage + (8 * wave_u) * 128);
+    } else {
 #pragma unroll
-    for (int i = 0; i < ACH; ++i) glds16(la.addr(i), stage + (32 * i + 8 * wave_u) * 128);
+      for (int i = 0; i < ACH; ++i) glds16(la.addr(i), stage + (32 * i + 8 * wave_u) * 128);
+    }
+    if constexpr (LB::kLean) {
+      glds16_lean<BCH>(lb.off, lb.base, stage + BM * 128 + (8 * wave_u) * 128);
+    } else {
 #pragma unroll
-    for (int i = 0; i < BCH; ++i) glds16(lb.addr(i), stage + BM * 128 + (32 * i + 8 * wave_u) * 128);
+      for (int i = 0; i < BCH; ++i) glds16(lb.addr(i), stage + BM * 128 + (32 * i + 8 * wave_u) * 128);
+    }
   };
   auto compute = [&](const char* cur) {
     const char* At = cur + (wm * (BM / 2)) * 128;
@@ -457,10 +505,18 @@ __device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles
 
   auto issue = [&](int stage_idx) {
     char* stage = smem + stage_idx * STAGE;
+    if constexpr (LA::kLean) {
+      glds16_lean<NCH>(la.off, la.base, stage + (4 * wave_u) * 256);
+    } else {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) glds16(la.addr(i), stage + (16 * i + 4 * wave_u) * 256);
+      for (int i = 0; i < NCH; ++i) glds16(la.addr(i), stage + (16 * i + 4 * wave_u) * 256);
+    }
+    if constexpr (LB::kLean) {
+      glds16_lean<NCH>(lb.off, lb.base, stage + TILE + (4 * wave_u) * 256);
+    } else {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) glds16(lb.addr(i), stage + TILE + (16 * i + 4 * wave_u) * 256);
+      for (int i = 0; i < NCH; ++i) glds16(lb.addr(i), stage + TILE + (16 * i + 4 * wave_u) * 256);
+    }
   };
   auto compute = [&](const char* cur) {
 #pragma unroll
@@ -521,7 +577,26 @@ __device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles
 
 // ------------------------------------------------------------------ loaders
 // Plain row-major [rows][ld] matrix, K contiguous (weights, features, linear inputs).
+// bf16 rows of a plain [rows][ld] matrix for the lean DMA issue (glds16_lean): rows past the end are CLAMPED to the
+// last row instead of zero-filled -- their products only reach output rows / columns that no epilogue stores or sums
+template <int NCH> struct LoaderPlainLean {
+  static constexpr bool kLean = true;
+  const char* base;          // wave-uniform
+  unsigned off[NCH];
+  __device__ __forceinline__ void init(const bf16* mat, int64_t ld, int row0, int nrows, int chunk) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int row = min(row0 + (t >> 3) + 32 * i, nrows - 1);
+      off[i] = (unsigned)(((int64_t)row * ld + chunk * 8) * 2);
+    }
+    base = (const char*)mat;
+  }
+  __device__ __forceinline__ void next() { base += 128; }
+};
+
 template <typename T, int NCH> struct LoaderPlainNT {
+  static constexpr bool kLean = false;
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int BK = ImgNT<T>::BK;
   const T* p[NCH];
@@ -567,6 +642,7 @@ struct GatherGeom {
 // offset, so a load costs a shift/test and one add (the 64-bit multiplies of a per-tile decode used to
 // rival the MFMA time of the tile).  Requires R*S <= 64 and < 2^31 elements per modality tensor.
 template <typename T, int NCH> struct LoaderIm2colNT {
+  static constexpr bool kLean = false;
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int BK = ImgNT<T>::BK;
   const T* src;
@@ -651,6 +727,7 @@ template <typename T, int NCH> struct LoaderIm2colNT {
 
 // Generic (slow) path: any Cs (the 3-channel stem); element-wise gather.
 template <typename T, int NCH> struct LoaderIm2colSlowNT {
+  static constexpr bool kLean = false;
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int BK = ImgNT<T>::BK;
   const T* p[NCH];
@@ -700,7 +777,27 @@ template <typename T, int NCH> struct LoaderIm2colSlowNT {
 };
 
 // TN: plain [K][ld] matrix, columns contiguous (dY for wgrad).
+// bf16 k-rows of a plain [K][ld] matrix for the lean DMA issue (glds16_lean): 16 k-rows per pass, 4 passes per tile.
+// Only for k ranges that are whole tiles (no zero fill: the caller checks (kend - kbeg) % 64 == 0); column chunks past
+// the end are clamped to the last one (they only feed output rows / columns that are never stored).
+struct LoaderColsLean {
+  static constexpr bool kLean = true;
+  const char* base;          // wave-uniform: first k-row of the current tile
+  unsigned off[4];
+  int64_t step;              // bytes per k-tile
+  __device__ __forceinline__ void init(const bf16* mat, int64_t ld, int col0, int ncols, int kbeg, int chunk) {
+    const int t = threadIdx.x;
+    const int col = min(col0 + chunk * 8, ncols - 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) off[i] = (unsigned)((((int64_t)(t >> 4) + 16 * i) * ld + col) * 2);
+    base = (const char*)(mat + (int64_t)kbeg * ld);
+    step = 64 * ld * 2;
+  }
+  __device__ __forceinline__ void next() { base += step; }
+};
+
 template <typename T> struct LoaderColsTN {
+  static constexpr bool kLean = false;
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int BK = ImgTN<T>::BK, CPR = ImgTN<T>::CPR, RPP = 256 / CPR, NCH = BK / RPP;
   const T* base;  // already offset to this thread's column chunk, or nullptr if the chunk is out of range
@@ -729,6 +826,7 @@ template <typename T> struct LoaderColsTN {
 
 // TN: im2col columns (tap, channel) of the forward geometry, rows = output pixels.
 template <typename T> struct LoaderIm2colTN {
+  static constexpr bool kLean = false;
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int BK = ImgTN<T>::BK, CPR = ImgTN<T>::CPR, RPP = 256 / CPR, NCH = BK / RPP;
   const T* src;
@@ -786,6 +884,7 @@ template <typename T> struct LoaderIm2colTN {
 
 // TN slow path (stem): per-element column decode.
 template <typename T> struct LoaderIm2colSlowTN {
+  static constexpr bool kLean = false;
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int BK = ImgTN<T>::BK, CPR = ImgTN<T>::CPR, RPP = 256 / CPR, NCH = BK / RPP;
   const T* src;

@@ -33,8 +33,14 @@ def family(name):
     return "other"
 
 
+BY_GRID = False
+
+
 def main():
-    out_path, dirs = sys.argv[1], sys.argv[2:]
+    global BY_GRID
+    args = [a for a in sys.argv[1:] if a != "--by-grid"]
+    BY_GRID = len(args) != len(sys.argv) - 1
+    out_path, dirs = args[0], args[1:]
     sums = collections.defaultdict(lambda: collections.defaultdict(float))
     counts = collections.defaultdict(lambda: collections.defaultdict(int))
     for d in dirs:
@@ -43,8 +49,12 @@ def main():
                 for row in csv.DictReader(f):
                     fam = family(row["Kernel_Name"])
                     c = row["Counter_Name"]
-                    sums[fam][c] += float(row["Counter_Value"])
-                    counts[fam][c] += 1
+                    keys = [fam]
+                    if BY_GRID and fam in ("conv_gather", "conv_wgrad"):       # one entry per launch geometry too
+                        keys.append("%s/grid%s_lds%s_vgpr%s" % (fam, row["Grid_Size"], row["LDS_Block_Size"], row["VGPR_Count"]))
+                    for k in keys:
+                        sums[k][c] += float(row["Counter_Value"])
+                        counts[k][c] += 1
     res = {"_note": __doc__.split("\n\n")[1].replace("\n", " ") if False else
            "rocprofv3 --pmc passes (one counter group per pass) summarised by scripts/pmc_summary.py; per-launch means"}
     for fam in sorted(sums):

@@ -225,7 +225,7 @@ def test_cim_tail_chain_fwd_bwd(mode, dtype):
     back = lambda t: t.float().cpu().permute(0, 1, 4, 2, 3)
     # bf16: g is rounded once when stored (2^-9 relative), dy once more, and dy = k1*g + k2*y + k3 cancels partly
     tol_dy = dict(rtol=2e-2, atol=2e-3) if bf else dict(rtol=2e-3, atol=2e-5)
-    tol_p = dict(rtol=5e-3, atol=2e-3) if bf else dict(rtol=1e-3, atol=1e-4)
+    tol_p = dict(rtol=1e-2, atol=2e-2) if bf else dict(rtol=1e-3, atol=1e-4)      # sums over 384 rounded terms
     torch.testing.assert_close(back(res["dy1"]), w["y1"].grad, **tol_dy)
     torch.testing.assert_close(back(res["dy2"]), w["y2"].grad, **tol_dy)
     torch.testing.assert_close(res["dg1"].cpu(), w["g1"].grad, **tol_p)
