@@ -426,42 +426,65 @@ __global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wg
 }
 
 // dW[z][co][ci][r][s] (OIHW fp32, the reference's parameter layout) = sum over splits of
-// slab[z][ks][co][(r*S+s)*Ci + ci]; deterministic (fixed summation order).  Threads walk the slab
-// order so the (dominant) slab reads are coalesced; for 3x3 / 7x7 the 4-byte writes scatter.
+// slab[z][ks][co][(r*S+s)*Ci + ci]; deterministic (fixed association).  The small-weight layers of layer1 / layer2 have
+// 75-150 splits and only 16 k-150 k outputs: one thread per output walking all its splits is a chain of 75+ dependent
+// round trips on 48 blocks (60 us for the 64->256 layer -- as long as its GEMM).  So the splits are spread over SL lanes:
+// block = (256 / SL) outputs x SL lanes; lane y adds splits y, y + SL, ... in order (independent loads, 4 in flight),
+// the lanes' sums are then added in lane order through LDS.  Threads walk the slab order, so the (dominant) slab
+// reads are coalesced; for 3x3 / 7x7 the 4-byte writes scatter.
+template <int VEC>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                            int splitk, int Co, int Ci, int RS, int64_t slab_gs,
-                                                           int64_t dw_gs, int accumulate, int vec4) {
+                                                           int64_t dw_gs, int accumulate, int sl_log2) {
+  __shared__ float part[256 * VEC];
   const int z = blockIdx.y;
+  const int SL = 1 << sl_log2, per = 256 >> sl_log2;
+  const int t = threadIdx.x, lane = t >> (8 - sl_log2), x = t & (per - 1);
   const int64_t total = (int64_t)Co * Ci * RS;
-  if (vec4) {   // 1x1 with 16-byte aligned operands: slab order == OIHW order -> 16-byte lanes (most of the slab bytes)
-    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i4 >= total) return;
-    const float* s = slab + z * slab_gs + i4;
-    float4 acc = *(const float4*)s;
-    for (int k = 1; k < splitk; ++k) {
-      const float4 v = *(const float4*)(s + k * total);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  const int64_t i = ((int64_t)blockIdx.x * per + x) * VEC;    // index in slab order [co][rs][ci]
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  if (i < total) {
+    const float* s = slab + z * slab_gs + i;
+#pragma unroll 4
+    for (int k = lane; k < splitk; k += SL) {
+      if constexpr (VEC == 4) {
+        const float4 v = *(const float4*)(s + (int64_t)k * total);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      } else {
+        acc[0] += s[(int64_t)k * total];
+      }
     }
-    float4* d = (float4*)(dw + z * dw_gs + i4);
-    if (accumulate) { const float4 o = *d; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
-    *d = acc;
-    return;
   }
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index in slab order [co][rs][ci]
+  if (SL > 1) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) part[(lane * per + x) * VEC + e] = acc[e];
+    __syncthreads();
+    if (lane != 0) return;
+    for (int y = 1; y < SL; ++y) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += part[(y * per + x) * VEC + e];
+    }
+  }
   if (i >= total) return;
-  const float* s = slab + z * slab_gs + i;
-  float acc = 0.f;
-  for (int k = 0; k < splitk; ++k) acc += s[k * total];
-  int64_t o = i;
-  if (RS > 1) {
-    const int ci = (int)(i % Ci);
-    const int64_t t = i / Ci;
-    const int rs = (int)(t % RS);
-    const int co = (int)(t / RS);
-    o = ((int64_t)co * Ci + ci) * RS + rs;
+  if constexpr (VEC == 4) {   // 1x1 with 16-byte aligned operands: slab order == OIHW order
+    float4* d = (float4*)(dw + z * dw_gs + i);
+    float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (accumulate) { const float4 p = *d; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    *d = o;
+  } else {
+    int64_t o = i;
+    if (RS > 1) {
+      const int ci = (int)(i % Ci);
+      const int64_t r = i / Ci;
+      const int rs = (int)(r % RS);
+      const int co = (int)(r / RS);
+      o = ((int64_t)co * Ci + ci) * RS + rs;
+    }
+    float* d = dw + z * dw_gs + o;
+    *d = accumulate ? (*d + acc[0]) : acc[0];
   }
-  float* d = dw + z * dw_gs + o;
-  *d = accumulate ? (*d + acc) : acc;
 }
 
 // Weight packing from the reference's fp32 OIHW parameters:
@@ -969,7 +992,7 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
 }
 
 // split-K heuristic shared by the workspace query and the launch
-static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups, int dtype) {
+static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups, int dtype, int64_t taps) {
   const int64_t tiles = ((Co + 127) / 128) * ((ncols + 127) / 128) * groups;
   const int64_t bk = elem_bk(dtype);
   // workgroups to aim at: 448 measured best at 4 workgroups/CU (256: -2.5 %, 640: -0.6 %, 1024: -3.5 %: slab
@@ -978,7 +1001,11 @@ static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups,
   static const int64_t f_target = getenv("IEEE_WGRAD_TARGET") ? atoll(getenv("IEEE_WGRAD_TARGET")) : 0;
   static const int64_t f_small = getenv("IEEE_WGRAD_TARGET_SMALL") ? atoll(getenv("IEEE_WGRAD_TARGET_SMALL")) : 448;
   const int64_t per_split_bytes = groups * Co * ncols * 4;
-  const int64_t target = f_target ? f_target : (per_split_bytes <= (1 << 20) ? f_small : 448);
+  // round 2 (parallel slab reduce): the small-weight layers WITH taps (layer1 3x3, the stem: X is re-read per tap from
+  // L2, few output tiles) gain 20-25 % from twice the workgroups; the 1x1 ones still lose (scripts/scan_wt.sh)
+  static const int64_t f_small_taps = getenv("IEEE_WGRAD_TARGET_SMALL_TAPS") ? atoll(getenv("IEEE_WGRAD_TARGET_SMALL_TAPS")) : 896;
+  const int64_t small = taps > 1 ? f_small_taps : f_small;
+  const int64_t target = f_target ? f_target : (per_split_bytes <= (1 << 20) ? small : 448);
   int64_t want = (target + tiles - 1) / tiles;               // aim at ~`target` workgroups per launch
   const int64_t maxsplit = (npix + 4 * bk - 1) / (4 * bk);   // at least 4 k-tiles per split
   if (want > maxsplit) want = maxsplit;
@@ -994,7 +1021,7 @@ extern "C" int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t 
 extern "C" int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, int64_t N, int64_t Ho, int64_t Wo,
                                                      int64_t Ci, int64_t Co, int64_t R, int64_t S) {
   const int64_t npix = N * Ho * Wo, ncols = R * S * Ci;
-  return (int64_t)wgrad_splitk(npix, Co, ncols, groups, dtype) * groups * Co * ncols * 4;
+  return (int64_t)wgrad_splitk(npix, Co, ncols, groups, dtype, R * S) * groups * Co * ncols * 4;
 }
 
 extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
@@ -1010,7 +1037,7 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   a.Co = d.Co;
   a.ncols = d.R * d.S * d.Ci;
   a.npix = a.g.npix;
-  const int splitk = wgrad_splitk(a.npix, d.Co, a.ncols, groups, dtype);
+  const int splitk = wgrad_splitk(a.npix, d.Co, a.ncols, groups, dtype, d.R * d.S);
   const int bk = elem_bk(dtype);
   a.kchunk = cdiv(cdiv(a.npix, splitk), bk) * bk;
   const int nsplit = cdiv(a.npix, a.kchunk);
@@ -1062,8 +1089,14 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   const int64_t total = (int64_t)d.Co * d.Ci * d.R * d.S;
   const bool vec4 = d.R * d.S == 1 && (total & 3) == 0 && (dw_gs & 3) == 0 && (a.slab_gs & 3) == 0 &&
                     ((uintptr_t)dw_oihw & 15) == 0 && ((uintptr_t)slab & 15) == 0;
-  dim3 rgrid(cdiv(vec4 ? total / 4 : total, 256), (unsigned)groups);
-  wgrad_reduce_kernel<<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs,
-                                             accumulate, vec4 ? 1 : 0);
+  // split lanes: enough blocks to fill the chip on the small-weight layers, no idle lanes on the few-split ones
+  const int64_t outs = vec4 ? total / 4 : total;
+  int sl_log2 = 0;
+  while (sl_log2 < 4 && (2 << sl_log2) <= nsplit && (outs << sl_log2) * groups < (int64_t)256 * 2048) ++sl_log2;
+  dim3 rgrid(cdiv(outs, 256 >> sl_log2), (unsigned)groups);
+  if (vec4)
+    wgrad_reduce_kernel<4><<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs, accumulate, sl_log2);
+  else
+    wgrad_reduce_kernel<1><<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs, accumulate, sl_log2);
   return launch_status("wgrad_reduce_kernel");
 }

@@ -17,4 +17,5 @@ top = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 for k, v in sorted(agg.items(), key=lambda kv: -sum(x[0] for x in kv[1]))[:top]:
     us = sum(x[0] for x in v)
     gf = sum(x[1] for x in v)
-    print('%-30s %-7s n=%2d %8.1f us %6.0f TF %5.1f%%' % (k[0], k[1], len(v), us, gf / us * 1e-3 * 1e3 * 1e3 / 1e3, 100 * us / tot))
+    # gflop / us = 1e9 flop / 1e-6 s = 1e15 flop/s -> x 1e3 for TFLOP/s
+    print('%-30s %-7s n=%2d %8.1f us %7.1f TFLOP/s %5.1f%%' % (k[0], k[1], len(v), us, gf / us * 1e3, 100 * us / tot))
