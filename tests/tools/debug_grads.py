@@ -1,5 +1,5 @@
 """diagnostic (not a test): per-parameter gradient error of the native backward against the golden
-gradient statistics captured from the reference.  python tests/debug_grads.py [train8|train16]"""
+gradient statistics captured from the reference.  python tests/tools/debug_grads.py [train8|train16]"""
 import sys
 
 import numpy as np

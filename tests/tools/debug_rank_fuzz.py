@@ -1,6 +1,6 @@
 """one-off differential fuzz of ieee_rank_market1501 (both kernel paths) against the oracle's C restatement:
 random sizes, identity / camera counts, tie densities, row strides.  Run by hand on a GPU box:
-    python tests/debug_rank_fuzz.py [cases] [seed]"""
+    python tests/tools/debug_rank_fuzz.py [cases] [seed]"""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 """diagnostic (not a test): per-stage max|diff| between the native executor's intermediates and the
-oracle on the CPU, to localise a parity failure.  python tests/debug_stages.py [B] [train|eval]"""
+oracle on the CPU, to localise a parity failure.  python tests/tools/debug_stages.py [B] [train|eval]"""
 import sys
 
 import torch
