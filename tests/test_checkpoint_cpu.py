@@ -105,3 +105,81 @@ def test_checkpoints_interoperate_with_the_reference_model(tmp_path):
     back = _model(seed=6)
     assert ckpt.resume_from_checkpoint(str(tmp_path / "ref.pth"), back) == 9
     assert torch.equal(back.backbone[1].layer2[0].conv2.weight, ours.backbone[1].layer2[0].conv2.weight * 0.5)
+
+
+def test_fused_optimizer_state_interops_with_torch_optim(tmp_path):
+    """the fused optimizers keep momentum / moments in flat buffers, but their state_dict() is what torch.optim.SGD / Adam
+    (the reference's optimizers, optim/optimizer.py:113-138) write and read: per-parameter momentum_buffer / exp_avg /
+    exp_avg_sq / step.  A checkpoint of either implementation resumes in the other without losing the state."""
+    from ieee_amd.optim import FusedAdam, FusedSGD
+    m = _model(seed=3)
+    params = list(m.parameters())
+    # fused SGD -> torch SGD (through a file, as resume_from_checkpoint does)
+    fs = FusedSGD(m, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    with torch.no_grad():
+        fs.momentum_buffer().copy_(torch.arange(m._flat_params.numel(), dtype=torch.float32) * 1e-6)
+    torch.save({"optimizer": fs.state_dict()}, str(tmp_path / "o.pt"))
+    sd = torch.load(str(tmp_path / "o.pt"), weights_only=False)["optimizer"]
+    ts = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    ts.load_state_dict(sd)
+    for name, p in m._param_items[:5] + m._param_items[-5:]:
+        off = m._offsets[name]
+        assert torch.equal(ts.state[p]["momentum_buffer"].flatten(), fs.momentum_buffer()[off:off + p.numel()])
+    # torch SGD -> fused SGD
+    for p in params:
+        ts.state[p]["momentum_buffer"] = torch.full_like(p, float(p.numel() % 13))
+    fs2 = FusedSGD(m, lr=1e-3)
+    fs2.load_state_dict(ts.state_dict())
+    for name, p in m._param_items:
+        off = m._offsets[name]
+        assert bool((fs2.momentum_buffer()[off:off + p.numel()] == float(p.numel() % 13)).all()), name
+    assert fs2.param_groups[0]["momentum"] == 0.9
+    # fused Adam <-> torch Adam (amsgrad: all three moment buffers and the step count)
+    fa = FusedAdam(m, lr=3e-4, amsgrad=True)
+    bufs = fa._buffers()
+    with torch.no_grad():
+        for k, b in enumerate(bufs):
+            b.fill_(0.25 * (k + 1))
+    fa._step = 7
+    ta = torch.optim.Adam(params, lr=3e-4, betas=(0.9, 0.99), weight_decay=5e-4, amsgrad=True)
+    ta.load_state_dict(fa.state_dict())
+    st = ta.state[params[10]]
+    assert float(st["step"]) == 7 and bool((st["exp_avg"] == 0.25).all()) and bool((st["exp_avg_sq"] == 0.5).all()) \
+        and bool((st["max_exp_avg_sq"] == 0.75).all())
+    for p in params:
+        ta.state[p]["step"] = torch.tensor(11.0)
+        ta.state[p]["exp_avg"] = torch.full_like(p, 2.0)
+    fa2 = FusedAdam(m, lr=3e-4, amsgrad=True)
+    fa2.load_state_dict(ta.state_dict())
+    assert fa2._step == 11 and bool((fa2._buffers()[0] == 2.0).all()) and bool((fa2._buffers()[1] == 0.5).all())
+
+
+def test_part_runs_follow_frozen_parameters():
+    """the staged optimizer update (FusedSGD.step_part) must see requires_grad changes made between epochs
+    (Engine.two_stepped_transfer_learning / open_specified_layers): the five parts together are always step()'s runs"""
+    m = _model(seed=4)
+
+    def flat(runs):
+        return sorted(runs)
+
+    def union(parts):
+        return flat([r for part in parts for r in part])
+
+    def merged(runs):          # adjacent runs cut at part boundaries are one run for step()
+        out = []
+        for a, b in flat(runs):
+            if out and out[-1][1] == a:
+                out[-1] = (out[-1][0], b)
+            else:
+                out.append((a, b))
+        return out
+    assert merged(union(m.part_runs())) == merged(m.trainable_runs())
+    for name, child in m.named_children():
+        for p in child.parameters():
+            p.requires_grad = name in ("classifier_R", "fc_T")
+    frozen = merged(union(m.part_runs()))
+    assert frozen == merged(m.trainable_runs()) and len(frozen) < 10
+    assert all(not r for r in m.part_runs()[1:])            # nothing trainable in the trunk parts
+    for p in m.parameters():
+        p.requires_grad = True
+    assert merged(union(m.part_runs())) == merged(m.trainable_runs()) and len(merged(m.trainable_runs())) >= 1
