@@ -62,7 +62,7 @@ class IEEE3modalPart(nn.Module):
     the reference hard-codes as attributes (:312-314) are constructor keywords here (default True)."""
 
     def __init__(self, num_classes, loss, block=None, parts=1, reduced_dim=512, cls_dim=128, nonlinear='relu',
-                 pretrained=True, interaction=True, attention=True, using_REM=True, compute_dtype=torch.bfloat16,
+                 pretrained=True, interaction=True, attention=True, using_REM=True, compute_dtype=None,
                  device=None, **kwargs):
         super(IEEE3modalPart, self).__init__()
         self.loss = loss
@@ -71,6 +71,15 @@ class IEEE3modalPart(nn.Module):
         self.interaction = interaction
         self.attention = attention
         self.using_REM = using_REM
+        if compute_dtype is None:
+            # bf16 storage / fp32 accumulate is the speed mode BASELINE config 2 names; the fp32 PARITY mode (exact fp32
+            # MFMA end to end: logits / features within 1e-3 of the reference's CPU path) is compute_dtype=torch.float32
+            # or IEEE_COMPUTE_DTYPE=fp32 for unchanged callers
+            import os
+            env = os.environ.get("IEEE_COMPUTE_DTYPE", "bf16").lower()
+            if env not in ("bf16", "fp32", "float32", "bfloat16"):
+                raise ValueError("IEEE_COMPUTE_DTYPE must be bf16 or fp32, got %r" % env)
+            compute_dtype = torch.float32 if env in ("fp32", "float32") else torch.bfloat16
         self.compute_dtype = compute_dtype
         self._nets = {}
         self._native_epoch = 0                   # bumped by every native writer of parameters / running statistics

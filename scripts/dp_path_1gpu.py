@@ -30,7 +30,7 @@ def build_engine_and_batch(B):
     return eng, make_batch(B, seed=0, device=dev)
 
 
-for forced in ("0", "1", "0", "1"):
+for forced in ("0", "1", "1", "0", "1", "0"):
     os.environ["IEEE_FORCE_DP_PATH"] = forced
     eng, batch = build_engine_and_batch(64)
     for _ in range(5):
