@@ -725,7 +725,8 @@ static GatherPlan plan_gather(int M, int N, int ktiles, int groups) {
   static const int f_maxwg = getenv("IEEE_GATHER_MAXWG") ? atoi(getenv("IEEE_GATHER_MAXWG")) : 1 << 30;
   static const int f_wide = getenv("IEEE_GATHER_WIDE") ? atoi(getenv("IEEE_GATHER_WIDE")) : 0;
   const int64_t wgs = (int64_t)cdiv(M, 128) * cdiv(N, 128) * groups;
-  if (N > 64 && wgs <= 512 && f_narrow != 0) p.bn = 64;
+  static const int64_t f_narrow_wg = getenv("IEEE_GATHER_NARROW_WG") ? atoll(getenv("IEEE_GATHER_NARROW_WG")) : 512;
+  if (N > 64 && wgs <= f_narrow_wg && f_narrow != 0) p.bn = 64;
   if (f_wide > 0 && N >= f_wide && N % 256 == 0) p.bn = 256;   // 128x256 tile: 25 % less L2 / LDS traffic per flop
   if (wgs <= f_maxwg) {   // tuning overrides apply to launches of at most IEEE_GATHER_MAXWG workgroups
     if (f_narrow == 1) p.bn = 64;
