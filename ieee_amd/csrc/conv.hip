@@ -109,64 +109,103 @@ template <typename T, int MODE> struct StagedStoreEpi {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     if (n < N) {
+      // The global operands of the epilogue (residual / skip gradient, y and the ReLU mask of the BatchNorm behind this
+      // dgrad) are fetched HP row passes at a time, all loads of a batch in flight before the first use: issued one pass
+      // at a time behind per-pass branches they cost a full memory round trip each (up to 24 per tile, the reason the
+      // block-input dgrads ran 1.5x longer than the forward convs of the same GEMM shape).  Rows past M read row M-1.
+      constexpr int NP = BM / RPP;
+      constexpr int HP = NP > 4 ? 4 : NP;
+      const bool has_add = addend != nullptr;
+      const bool has_mask = MODE == 2 && bmask != nullptr;
+      const bool has_fold = (MODE == 3) || (MODE == 2 && !has_mask && bstats != nullptr);
+      float sc[VEC], sh[VEC];   // this thread's channels never change over the passes
 #pragma unroll
-      for (int pss = 0; pss < BM / RPP; ++pss) {
-        const int r = r0 + RPP * pss;
-        const int m = m0 + r;
-        if (m >= M) continue;
-        uint4 v = *(const uint4*)(smem + r * ROWB + ch * 16);
-        T* o = out + (int64_t)m * ld + n;
-        if constexpr (MODE == 3) {
-          float f[VEC];
-          Vec16<T>::unpack(v, f);
+      for (int e = 0; e < VEC; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+      if constexpr (MODE == 2 || MODE == 3) {
+        if (has_fold) {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) f[e] = f[e] * bstats[2 * N + n + e] + bstats[3 * N + n + e];
-          if (addend != nullptr) {
-            float a[VEC];
-            Vec16<T>::unpack(*(const uint4*)(addend + (int64_t)m * ld + n), a);
+          for (int e = 0; e < VEC; ++e) { sc[e] = bstats[2 * N + n + e]; sh[e] = bstats[3 * N + n + e]; }
+        }
+      }
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) f[e] += a[e];
-          }
-          if (relu) {
+      for (int p0 = 0; p0 < NP; p0 += HP) {
+        uint4 va[HP], vy[HP], vk[HP];
+        int64_t off[HP];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) f[e] = fmaxf(f[e], 0.f);
-          }
-          v = Vec16<T>::pack(f);
-        } else if (addend != nullptr || STATS) {
-          float f[VEC];
-          Vec16<T>::unpack(v, f);
-          if (addend != nullptr) {
-            float a[VEC];
-            Vec16<T>::unpack(*(const uint4*)(addend + (int64_t)m * ld + n), a);
+        for (int h = 0; h < HP; ++h) {
+          const int m = m0 + r0 + RPP * (p0 + h);
+          off[h] = (int64_t)(m < M ? m : M - 1) * ld + n;
+          va[h] = vy[h] = vk[h] = make_uint4(0, 0, 0, 0);
+        }
+        if (has_add) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) f[e] += a[e];
-            v = Vec16<T>::pack(f);
-            if (STATS) Vec16<T>::unpack(v, f);
-          }
-          if constexpr (MODE == 1) {
+          for (int h = 0; h < HP; ++h) va[h] = *(const uint4*)(addend + off[h]);
+        }
+        if constexpr (MODE == 2) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
-          } else if constexpr (MODE == 2) {
-            float yv[VEC];
-            Vec16<T>::unpack(*(const uint4*)(by + (int64_t)m * ld + n), yv);
-            if (bmask != nullptr) {
-              float mk[VEC];
-              Vec16<T>::unpack(*(const uint4*)(bmask + (int64_t)m * ld + n), mk);
+          for (int h = 0; h < HP; ++h) vy[h] = *(const uint4*)(by + off[h]);
+          if (has_mask) {
 #pragma unroll
-              for (int e = 0; e < VEC; ++e) f[e] = mk[e] > 0.f ? f[e] : 0.f;
-              // the MASKED gradient g = dout * [out > 0] is what leaves the tile: the BatchNorm backward of that unit then
-              // reads g and y only (no second pass over the mask tensor, no separate g output) -- 12 instead of 20 bytes
-              // per element of the widest tensors of every block
-              v = Vec16<T>::pack(f);
-            } else if (bstats != nullptr) {
-#pragma unroll
-              for (int e = 0; e < VEC; ++e) f[e] = (yv[e] * bstats[2 * N + n + e] + bstats[3 * N + n + e]) > 0.f ? f[e] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) { s1[e] += f[e]; s2[e] += f[e] * yv[e]; }
+            for (int h = 0; h < HP; ++h) vk[h] = *(const uint4*)(bmask + off[h]);
           }
         }
-        *(uint4*)o = v;
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+          const int r = r0 + RPP * (p0 + h);
+          if (m0 + r >= M) continue;
+          uint4 v = *(const uint4*)(smem + r * ROWB + ch * 16);
+          if constexpr (MODE == 3) {
+            float f[VEC];
+            Vec16<T>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] = f[e] * sc[e] + sh[e];
+            if (has_add) {
+              float a[VEC];
+              Vec16<T>::unpack(va[h], a);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) f[e] += a[e];
+            }
+            if (relu) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) f[e] = fmaxf(f[e], 0.f);
+            }
+            v = Vec16<T>::pack(f);
+          } else if (has_add || STATS) {
+            float f[VEC];
+            Vec16<T>::unpack(v, f);
+            if (has_add) {
+              float a[VEC];
+              Vec16<T>::unpack(va[h], a);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) f[e] += a[e];
+              v = Vec16<T>::pack(f);
+              if (STATS) Vec16<T>::unpack(v, f);
+            }
+            if constexpr (MODE == 1) {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+            } else if constexpr (MODE == 2) {
+              float yv[VEC];
+              Vec16<T>::unpack(vy[h], yv);
+              if (has_mask) {
+                float mk[VEC];
+                Vec16<T>::unpack(vk[h], mk);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] = mk[e] > 0.f ? f[e] : 0.f;
+                // the MASKED gradient g = dout * [out > 0] is what leaves the tile: the BatchNorm backward of that unit
+                // then reads g and y only (no second pass over the mask tensor, no separate g output) -- 12 instead of
+                // 20 bytes per element of the widest tensors of every block
+                v = Vec16<T>::pack(f);
+              } else if (has_fold) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] = (yv[e] * sc[e] + sh[e]) > 0.f ? f[e] : 0.f;
+              }
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) { s1[e] += f[e]; s2[e] += f[e] * yv[e]; }
+            }
+          }
+          *(uint4*)(out + (int64_t)(m0 + r) * ld + n) = v;
+        }
       }
     }
     if constexpr (STATS) {
