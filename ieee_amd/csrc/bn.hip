@@ -176,9 +176,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ residual,
                                                        T* __restrict__ out, const float* __restrict__ stats,
                                                        int64_t stats_gs, int64_t total_chunks, int cprw, int C,
-                                                       int64_t gs, int relu) {
+                                                       int64_t gs, int relu, uint8_t* __restrict__ relu_bits) {
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
+  // relu_bits (16-bit dtype only, VEC == 8): one byte per 16-byte chunk, bit e = [stored out[e] > 0] -- the ReLU mask the
+  // block-input dgrad needs later, at 1/16 of the bytes of reading `out` again
+  uint8_t* bb = relu_bits ? relu_bits + z * (gs / 8) : nullptr;
   const bool pow2 = (cprw & (cprw - 1)) == 0;
   const float* sc = stats + z * stats_gs + 2 * C;
   const float* sh = sc + C;
@@ -197,7 +200,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
       if (relu) x = fmaxf(x, 0.f);
       v[e] = x;
     }
-    *(uint4*)(oo + i * VEC) = Vec16<T>::pack(v);
+    const uint4 pv = Vec16<T>::pack(v);
+    *(uint4*)(oo + i * VEC) = pv;
+    if constexpr (VEC == 8) {
+      if (bb) {
+        Vec16<T>::unpack(pv, v);   // the mask of the ROUNDED stored values, as a reader of `out` would see it
+        unsigned b = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
+        bb[i] = (uint8_t)b;
+      }
+    }
   }
 }
 
@@ -325,8 +338,10 @@ extern "C" int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C) {
 extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
                              int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
                              float* running_mean, float* running_var, int64_t buf_gs, float* stats, float* partial,
-                             float momentum, float eps, int training, int relu, int64_t stats_rblocks, void* stream) {
+                             float momentum, float eps, int training, int relu, int64_t stats_rblocks, void* relu_bits,
+                             void* stream) {
   IEEE_REQUIRE(y && gamma && beta && stats, "bn2d_fwd: null pointer");
+  IEEE_REQUIRE(!relu_bits || (dtype == IEEE_BF16 && out && act_gs % 8 == 0), "bn2d_fwd: relu_bits needs a bf16 output");
   IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_fwd: bad dtype");
   IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_fwd: C %ld not a multiple of %d", (long)C, vec_of(dtype));
   IEEE_REQUIRE(training || (running_mean && running_var), "bn2d_fwd: eval mode needs running stats");
@@ -351,10 +366,10 @@ extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int
   dim3 grid(ew_blocks(chunks), (unsigned)groups);
   if (dtype == IEEE_F32)
     bn_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)y, (const float*)residual, (float*)out, stats, 4 * C,
-                                                 chunks, g.cprw, (int)C, act_gs, relu);
+                                                 chunks, g.cprw, (int)C, act_gs, relu, nullptr);
   else
     bn_apply_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y, (const bf16*)residual, (bf16*)out, stats, 4 * C, chunks,
-                                                g.cprw, (int)C, act_gs, relu);
+                                                g.cprw, (int)C, act_gs, relu, (uint8_t*)relu_bits);
   return launch_status("bn_apply_kernel");
 }
 

@@ -81,6 +81,7 @@ template <typename T, int MODE> struct StagedStoreEpi {
   const T* by;
   const T* bmask;
   const float* bstats;
+  const uint8_t* bbits = nullptr;   // the mask as packed bits (one byte per 8 channels, ieee_bn2d_fwd relu_bits) instead of bmask
   template <int BM, int BN, int FM, int FN>
   __device__ __forceinline__ void finish(f32x4 (&acc)[FM][FN], char* smem, int m0, int n0) const {
     constexpr int VEC = 16 / sizeof(T);
@@ -116,7 +117,8 @@ template <typename T, int MODE> struct StagedStoreEpi {
       constexpr int NP = BM / RPP;
       constexpr int HP = NP > 4 ? 4 : NP;
       const bool has_add = addend != nullptr;
-      const bool has_mask = MODE == 2 && bmask != nullptr;
+      const bool has_bits = MODE == 2 && sizeof(T) == 2 && bbits != nullptr;
+      const bool has_mask = MODE == 2 && (bmask != nullptr || has_bits);
       const bool has_fold = (MODE == 3) || (MODE == 2 && !has_mask && bstats != nullptr);
       float sc[VEC], sh[VEC];   // this thread's channels never change over the passes
 #pragma unroll
@@ -130,12 +132,14 @@ template <typename T, int MODE> struct StagedStoreEpi {
 #pragma unroll
       for (int p0 = 0; p0 < NP; p0 += HP) {
         uint4 va[HP], vy[HP], vk[HP];
+        unsigned kb[HP];
         int64_t off[HP];
 #pragma unroll
         for (int h = 0; h < HP; ++h) {
           const int m = m0 + r0 + RPP * (p0 + h);
           off[h] = (int64_t)(m < M ? m : M - 1) * ld + n;
           va[h] = vy[h] = vk[h] = make_uint4(0, 0, 0, 0);
+          kb[h] = 0;
         }
         if (has_add) {
 #pragma unroll
@@ -144,7 +148,10 @@ template <typename T, int MODE> struct StagedStoreEpi {
         if constexpr (MODE == 2) {
 #pragma unroll
           for (int h = 0; h < HP; ++h) vy[h] = *(const uint4*)(by + off[h]);
-          if (has_mask) {
+          if (has_bits) {
+#pragma unroll
+            for (int h = 0; h < HP; ++h) kb[h] = bbits[off[h] >> 3];
+          } else if (has_mask) {
 #pragma unroll
             for (int h = 0; h < HP; ++h) vk[h] = *(const uint4*)(bmask + off[h]);
           }
@@ -188,10 +195,15 @@ template <typename T, int MODE> struct StagedStoreEpi {
               float yv[VEC];
               Vec16<T>::unpack(vy[h], yv);
               if (has_mask) {
-                float mk[VEC];
-                Vec16<T>::unpack(vk[h], mk);
+                if (has_bits) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) f[e] = mk[e] > 0.f ? f[e] : 0.f;
+                  for (int e = 0; e < VEC; ++e) f[e] = ((kb[h] >> e) & 1u) ? f[e] : 0.f;
+                } else {
+                  float mk[VEC];
+                  Vec16<T>::unpack(vk[h], mk);
+#pragma unroll
+                  for (int e = 0; e < VEC; ++e) f[e] = mk[e] > 0.f ? f[e] : 0.f;
+                }
                 // the MASKED gradient g = dout * [out > 0] is what leaves the tile: the BatchNorm backward of that unit
                 // then reads g and y only (no second pass over the mask tensor, no separate g output) -- 12 instead of
                 // 20 bytes per element of the widest tensors of every block
@@ -307,6 +319,7 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
   const float* stats;
   int64_t act_gs, stats_gs;
   int relu;                  // MODE 3 only
+  int mask_bits = 0;         // MODE 2: `mask` is the packed bit form (one byte per 8 channels)
 };
 
 // (forcing 4 waves per SIMD here spills 80 VGPRs and is 2.5x slower; the default allocation gives 3)
@@ -328,9 +341,12 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
   if (addend != nullptr) addend += z * a.dst_gs;
   StagedStoreEpi<T, MODE> epi{0, dst, addend, (MODE == 1 || MODE == 2) ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
                               MODE == 2 ? (const T*)bs.y + z * bs.act_gs : nullptr,
-                              (MODE == 2 && bs.mask) ? (const T*)bs.mask + z * bs.act_gs : nullptr,
+                              (MODE == 2 && bs.mask && !bs.mask_bits) ? (const T*)bs.mask + z * bs.act_gs : nullptr,
                               ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
   if constexpr (MODE == 3) epi.relu = bs.relu;
+  if constexpr (MODE == 2) {
+    if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
+  }
   if constexpr (PIPE > 0) {   // both operands through LDS-DMA
     static_assert(!SLOW && sizeof(T) == 2, "the LDS-DMA ring is the bf16 vector path");
     const int ch = nt_dma_chunk(threadIdx.x);
@@ -1008,8 +1024,9 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
                                  int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
                                  int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
                                  float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
-                                 void* stream) {
+                                 int bn_mask_bits, void* stream) {
   IEEE_REQUIRE(dy && w_packed_d && dx, "conv2d_dgrad: null pointer");
+  IEEE_REQUIRE(!bn_mask_bits || (bn_mask && dx_gs % 8 == 0 && Ci % 8 == 0), "conv2d_dgrad: bit mask needs Cin %% 8 == 0");
   IEEE_REQUIRE(!bn_partial || bn_y, "conv2d_dgrad: fused BN-backward sums need the BN input tensor");
   Dims d;
   IEEE_TRY(check_dims("conv2d_dgrad", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
@@ -1023,7 +1040,7 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
     return launch_gather<float>((const float*)dy, (const float*)w_packed_d, (float*)dx, (const float*)addend, g,
                                 g.npix, d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st);
   if (dtype == IEEE_BF16) {
-    BwdStats bs{bn_y, bn_mask, bn_stats, dx_gs, 4 * Ci, 0};
+    BwdStats bs{bn_y, bn_mask, bn_stats, dx_gs, 4 * Ci, 0, bn_mask_bits};
     return launch_gather<bf16>((const bf16*)dy, (const bf16*)w_packed_d, (bf16*)dx, (const bf16*)addend, g, g.npix,
                                d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st, bn_partial,
                                bn_partial ? &bs : nullptr);

@@ -30,6 +30,8 @@ struct ConvUnit {
   int Ci_src = 0, S_src = 0, R_src = 0;   // dims of the reference parameter when the unit runs zero-padded
   int s_w, s_g, s_b, s_rm, s_rv;   // slot ids of modality 0 (modality m = id + m)
   Tensor y, a, stats, wf, wd, dwpad;
+  Tensor abits;                    // bf16 block outputs: the ReLU mask of `a` as packed bits (bn_apply writes it, the next block's conv1 dgrad reads it)
+  bool want_bits = false;
   bool need_dgrad = true;
   int64_t M(int B) const { return (int64_t)B * Ho * Wo; }
 };
@@ -198,6 +200,10 @@ void Net::build() {
       blk.c3 = add_unit(p + "conv3", p + "bn3", planes[L], planes[L] * 4, 1, 1, 0, ho, wo);
       blk.ds = -1;
       if (b == 0) blk.ds = add_unit(p + "downsample.0", p + "downsample.1", inpl, planes[L] * 4, 1, st, 0, h, w);
+      // every block output but the last is the ReLU mask of the next block's input gradient (IEEE_RELU_BITS=0: read
+      // the activation itself for the mask, the round-1 form)
+      static const bool f_bits = !(getenv("IEEE_RELU_BITS") && atoi(getenv("IEEE_RELU_BITS")) == 0);
+      units[blk.c3].want_bits = f_bits && !(L == 3 && b == nblk[L] - 1);
       blocks.push_back(blk);
       inpl = planes[L] * 4;
       h = ho; w = wo;
@@ -251,6 +257,7 @@ void Net::plan() {
     const int64_t n = 3 * u.M(B) * u.Co;
     u.y = alloc(u.name + ".y", n, dt);
     u.a = alloc(u.name + ".a", n, dt);
+    if (u.want_bits && dt == IEEE_BF16) u.abits = alloc(u.name + ".abits", n / 8, 2 /*u8*/);
     u.stats = alloc(u.name + ".stats", (int64_t)3 * 4 * u.Co, IEEE_F32);
     u.wf = alloc("", 3 * u.Co * ieee_conv_packed_ld(dt, u.Ci, u.R, u.S), dt);
     if (u.need_dgrad) u.wd = alloc("", 3 * u.Ci * ieee_conv_packed_ld(dt, u.Co, u.R, u.S), dt);
@@ -380,12 +387,12 @@ struct Run {
     return ieee_conv2d_fwd(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
                            (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, fused_stats ? bnpart_cur : nullptr, st);
   }
-  int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training) {
+  int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training, void* relu_bits = nullptr) {
     const int64_t rb = (training && fused_stats) ? ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) : 0;
     fused_stats = false;
     return ieee_bn2d_fwd(P(u.y), residual, out, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b),
                          gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), bnpart_cur, n.bn_mom, n.bn_eps,
-                         training, relu, rb, st);
+                         training, relu, rb, relu_bits, st);
   }
   // inference: conv + BatchNorm(running statistics) (+ residual) (+ ReLU) in ONE launch; the raw conv output is never
   // written.  The tiny finalize launch turns the running statistics into this unit's scale / shift first.
@@ -395,7 +402,7 @@ struct Run {
     if (!eval_cached)
       IEEE_TRY(ieee_bn2d_fwd(P(u.y), nullptr, nullptr, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b),
                            gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), bnpart_cur, n.bn_mom, n.bn_eps,
-                           0, relu, 0, st));
+                           0, relu, 0, nullptr, st));
     prof_begin(0, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_fwd_bn_eval(in, P(u.wf), out, residual, F(u.stats), relu, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co,
@@ -537,8 +544,10 @@ struct Run {
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     return ieee_conv2d_dgrad(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
                              u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, fuse ? bnpart_cur : nullptr,
-                             fuse ? P(prev->y) : nullptr, (fuse && prev_mask_tensor) ? P(prev->a) : nullptr,
-                             (fuse && !prev_mask_tensor) ? F(prev->stats) : nullptr, st);
+                             fuse ? P(prev->y) : nullptr,
+                             (fuse && prev_mask_tensor) ? (prev->abits.numel ? P(prev->abits) : P(prev->a)) : nullptr,
+                             (fuse && !prev_mask_tensor) ? F(prev->stats) : nullptr,
+                             (fuse && prev_mask_tensor && prev->abits.numel) ? 1 : 0, st);
   }
   // grouped fp32 GEMM over the 3 modalities with uniform strides
   int gemm3(const float* A, int64_t a_gs, const float* Bm, int64_t b_gs, float* C, int64_t c_gs, const float* bias,
@@ -662,7 +671,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
       ++ds_slot;
     }
     IEEE_TRY(conv(c3, P(c2.a), ws_));
-    IEEE_TRY(bn(c3, identity, P(c3.a), 1, training));
+    IEEE_TRY(bn(c3, identity, P(c3.a), 1, training, (training && c3.abits.numel) ? P(c3.abits) : nullptr));
     x = P(c3.a);
   }
   const void* Fm = x;   // [3][B][16*8][2048]

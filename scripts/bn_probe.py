@@ -39,7 +39,7 @@ for M, C in shapes:
     st = L.stream()
     fwd = lambda r: L.check(lib.ieee_bn2d_fwd(L.ptr(y), L.ptr(res) if r else None, L.ptr(out), 1, G, M, C, M * C, L.ptr(gam),
                                               L.ptr(bet), C, L.ptr(rm), L.ptr(rv), C, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, 1,
-                                              RB, st))
+                                              RB, None, st))
     bwd = lambda m, go: L.check(lib.ieee_bn2d_bwd(L.ptr(dd), L.ptr(out) if m else None, L.ptr(y), L.ptr(dy),
                                                   L.ptr(gout) if go else None, 1, G, M, C, M * C, L.ptr(gam), C, L.ptr(stats),
                                                   L.ptr(dg), L.ptr(db), C, L.ptr(part), L.ptr(coef), 0, 0 if m else 1, RB, st))

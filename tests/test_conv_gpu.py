@@ -164,13 +164,20 @@ def test_fused_bn_partials_in_conv_epilogues():
     stats = torch.randn(G, 4, Ci, generator=g).cuda()
     addend = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
     dx_ref = _ops.conv2d_dgrad(dy, wpd, (H, W), Ci, 3, 3, 1, 1, addend=addend)
-    for mode in ("mask", "stats", "none"):
+    # the same mask as packed bits (bit e of byte k = element 8k + e), the form ieee_bn2d_fwd(relu_bits) writes
+    mbits = ((amask > 0).view(-1, 8).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
+    results = {}
+    for mode in ("mask", "bits", "stats", "none"):
         p2 = torch.zeros(G, 2, Ci, rb, device="cuda")
         dx = torch.empty_like(dx_ref)
+        mptr = L.ptr(amask) if mode == "mask" else (L.ptr(mbits) if mode == "bits" else None)
         L.check(lib.ieee_conv2d_dgrad(L.ptr(dy), L.ptr(wpd), L.ptr(dx), L.ptr(addend), L.IEEE_BF16, G, N, H, W, Ci, Co, 3, 3,
                                       1, 1, dy[0].numel(), wpd.stride(0), dx[0].numel(), L.ptr(p2), L.ptr(ypre),
-                                      L.ptr(amask) if mode == "mask" else None, L.ptr(stats) if mode == "stats" else None,
-                                      L.stream()))
+                                      mptr, L.ptr(stats) if mode == "stats" else None, int(mode == "bits"), L.stream()))
+        results[mode] = (dx, p2)
+        if mode == "bits":   # bit-identical to the mask-tensor form, stores and sums
+            assert torch.equal(dx, results["mask"][0]) and torch.equal(p2, results["mask"][1])
+            continue
         # mask-tensor mode stores the MASKED gradient g = (dgrad + addend) * [mask > 0] (what the BatchNorm backward of
         # the block output consumes); the other two modes store dgrad + addend unchanged
         if mode == "mask":
@@ -218,7 +225,7 @@ def test_conv_with_fused_eval_batchnorm(dtype, res, relu):
     part = torch.empty(64, device="cuda")
     gd, bd, rmd, rvd = gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda()
     L.check(lib.ieee_bn2d_fwd(L.ptr(dummy), None, None, dt, G, N * H * W, Co, N * H * W * Co, L.ptr(gd), L.ptr(bd), Co, L.ptr(rmd),
-                              L.ptr(rvd), Co, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 0, relu, 0, L.stream()))
+                              L.ptr(rvd), Co, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 0, relu, 0, None, L.stream()))
     out = torch.empty_like(dummy)
     L.check(lib.ieee_conv2d_fwd_bn_eval(L.ptr(xd), L.ptr(wp), L.ptr(out), L.ptr(rd) if res else None, L.ptr(stats), relu, dt, G, N,
                                         H, W, Ci, Co, 3, 3, 1, 1, xd[0].numel(), wp.stride(0), out[0].numel(), L.stream()))

@@ -57,8 +57,13 @@ def test_bn2d_fwd_bwd(dtype, G, M, C, residual, relu):
     dt = L.IEEE_BF16 if dtype == torch.bfloat16 else L.IEEE_F32
     npart = lib.ieee_bn_partial_floats(dt, M, C)
     part = torch.empty(G * npart + 64, device=dev)
+    bits = torch.zeros(G * M * C // 8, device=dev, dtype=torch.uint8) if dtype == torch.bfloat16 else None
     L.check(lib.ieee_bn2d_fwd(L.ptr(yd), L.ptr(resd), L.ptr(out), dt, G, M, C, M * C, L.ptr(gd), L.ptr(bd), C,
-                              L.ptr(rmd), L.ptr(rvd), C, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, int(relu), 0, L.stream()))
+                              L.ptr(rmd), L.ptr(rvd), C, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, int(relu), 0, L.ptr(bits),
+                              L.stream()))
+    if bits is not None:   # relu_bits: bit e of byte k = [stored out[8k + e] > 0]
+        want_bits = ((out.view(-1, 8) > 0).to(torch.int32) << torch.arange(8, device=dev, dtype=torch.int32)).sum(1)
+        assert torch.equal(bits.to(torch.int32), want_bits)
     tol = dict(rtol=2e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(out.float().cpu(), out_ref.detach(), **tol)
     torch.testing.assert_close(rmd.cpu(), rmr, rtol=1e-4, atol=1e-5)
@@ -163,7 +168,7 @@ def test_cim_tail_chain_fwd_bwd(mode, dtype):
     for y, ga, be, st in ((y1, w["g1"], w["b1"], st1), (y2, w["g2"], w["b2"], st2)):
         gd, bd = ga.detach().to(dev), be.detach().to(dev)
         L.check(lib.ieee_bn2d_fwd(L.ptr(y), None, None, dt, 3, B * P, C, B * P * C, L.ptr(gd), L.ptr(bd), C, None, None, 0,
-                                  L.ptr(st), L.ptr(part), 0.1, 1e-5, 1, 1, 0, L.stream()))
+                                  L.ptr(st), L.ptr(part), 0.1, 1e-5, 1, 1, 0, None, L.stream()))
     avgmax = torch.empty(3, 2 * B, C, device=dev)
     amax = torch.empty(3, B, C, device=dev, dtype=torch.int32)
     att = torch.zeros(3, B, C, device=dev)
