@@ -542,6 +542,40 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The same reduction for the few-split layers with taps (3x3 of layer2-4): one block per (output channel, 128 input
+// channels).  The slab rows [rs][ci] are read as float4 along ci, turned through LDS, and the [ci][rs] run of the OIHW
+// gradient -- contiguous for a fixed output channel -- leaves as coalesced stores (the element-wise form above scatters
+// 4-byte stores RS floats apart: 70 us for the 512x512x3x3 gradients, 3x what their bytes need).  Splits are added in order.
+constexpr int RT_CIB = 128;
+__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                int splitk, int Co, int Ci, int RS, int64_t slab_gs,
+                                                                int64_t dw_gs, int accumulate) {
+  extern __shared__ float tile[];   // [RT_CIB][RS]
+  const int z = blockIdx.y;
+  const int cibs = (Ci + RT_CIB - 1) / RT_CIB;
+  const int co = blockIdx.x / cibs, ci0 = (blockIdx.x % cibs) * RT_CIB;
+  const int nci = min(RT_CIB, Ci - ci0);
+  const int t = threadIdx.x;
+  const int64_t total = (int64_t)Co * Ci * RS;
+  const float* s = slab + z * slab_gs + ((int64_t)co * RS) * Ci + ci0;
+  const int q = nci >> 2;   // float4 per tap row (Ci % 4 == 0)
+  for (int idx = t; idx < RS * q; idx += 256) {
+    const int rs = idx / q, c4 = idx - rs * q;
+    const float* src = s + (int64_t)rs * Ci + c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int k = 0; k < splitk; ++k) {
+      const float4 v = *(const float4*)(src + (int64_t)k * total);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* d = tile + (c4 * 4) * RS + rs;
+    d[0] = acc.x; d[RS] = acc.y; d[2 * RS] = acc.z; d[3 * RS] = acc.w;
+  }
+  __syncthreads();
+  float* d = dw + z * dw_gs + ((int64_t)co * Ci + ci0) * RS;
+  for (int j = t; j < nci * RS; j += 256) d[j] = accumulate ? (d[j] + tile[j]) : tile[j];
+}
+
 // Weight packing from the reference's fp32 OIHW parameters:
 //  mode 0 (forward): dst[co][(r*S+s)*Ci + ci]  row length ld (zero padded)
 //  mode 1 (dgrad)  : dst[ci][(r*S+s)*Co + co]  row length ld
@@ -1151,6 +1185,14 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   int sl_log2 = 0;
   while (sl_log2 < 4 && (2 << sl_log2) <= nsplit && (outs << sl_log2) * groups < (int64_t)256 * 2048) ++sl_log2;
   dim3 rgrid(cdiv(outs, 256 >> sl_log2), (unsigned)groups);
+  static const int f_taps = getenv("IEEE_WGRAD_REDUCE_TAPS") ? atoi(getenv("IEEE_WGRAD_REDUCE_TAPS")) : 16;
+  if (d.R * d.S > 1 && nsplit <= f_taps && d.Ci % 4 == 0 && (a.slab_gs & 3) == 0 && ((uintptr_t)slab & 15) == 0) {
+    const int RS = d.R * d.S;
+    dim3 tgrid((unsigned)(d.Co * cdiv(d.Ci, RT_CIB)), (unsigned)groups);
+    wgrad_reduce_taps_kernel<<<tgrid, 256, (size_t)RT_CIB * RS * sizeof(float), st>>>(slab, dw_oihw, nsplit, d.Co, d.Ci, RS, a.slab_gs,
+                                                                                    dw_gs, accumulate);
+    return launch_status("wgrad_reduce_taps_kernel");
+  }
   if (vec4)
     wgrad_reduce_kernel<4><<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs, accumulate, sl_log2);
   else
