@@ -1,0 +1,2 @@
+run() { env $1 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-distmat --no-fp32 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value'],1), round(d['ms_per_step'],3))"; }
+for i in 1 2 3; do for v in 8192 16384 32768 1000000; do run IEEE_EW_BLOCKS=$v; done; done
