@@ -5,6 +5,8 @@
 // All maps are NHWC with a leading modality axis [3][B][H*W][C]; everything here is HBM-bound
 // streaming with 16-byte lanes; per-(b,c) reductions over the 128 positions are done by `ty` row
 // lanes of a block and finished through LDS.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ieee {
@@ -613,8 +615,9 @@ __global__ __launch_bounds__(256) void cim_bwd_combine_kernel(const T* __restric
 }
 
 static int ew_blocks2(int64_t n) {
+  static const int64_t cap = getenv("IEEE_CIM_EW_BLOCKS") ? atoll(getenv("IEEE_CIM_EW_BLOCKS")) : 2048;
   int64_t b = (n + 255) / 256;
-  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 }  // namespace ieee

@@ -611,8 +611,9 @@ __global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restri
 }
 
 static int ewb(int64_t n) {
+  static const int64_t cap = getenv("IEEE_HEAD_EW_BLOCKS") ? atoll(getenv("IEEE_HEAD_EW_BLOCKS")) : 2048;
   int64_t b = (n + 255) / 256;
-  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 }  // namespace ieee
