@@ -27,7 +27,7 @@ from torch.nn import functional as F
 from . import _lib, dist as ddp
 from .checkpoint import save_checkpoint
 from .losses import CrossEntropyLoss, DeepSupervision, multiModalMarginLossNew
-from .meters import AverageMeter, MetricMeter
+from .meters import AverageMeter, DeferredSummary, MetricMeter
 from .metrics import accuracy, compute_distance_matrix, evaluate_rank
 from .optim import FusedAdam, FusedSGD
 
@@ -147,6 +147,8 @@ class Engine(object):
         self.two_stepped_transfer_learning(self.epoch, fixbase_epoch, open_layers)
         self.num_batches = len(self.train_loader)
         mark = time.time()
+        # the per-batch numbers are read back when the log is printed (or written), not inside every step
+        self.defer_summary = os.environ.get("IEEE_DEFER_SUMMARY", "1") != "0"
         for self.batch_idx, data in enumerate(self.train_loader):
             t_data.update(time.time() - mark)
             log.update(self.forward_backward(data))
@@ -163,6 +165,8 @@ class Engine(object):
                     self.writer.add_scalar('Train/' + key, meter.avg, step)
                 self.writer.add_scalar('Train/lr', self.get_current_lr(), step)
             mark = time.time()
+        self.defer_summary = False
+        str(log)                                 # settle what is still pending before the epoch ends
         self.update_lr()
 
     def forward_backward(self, data):
@@ -419,18 +423,41 @@ class _FusedStepMixin(object):
         self.optimizer.step()
         return small, out3
 
-    def _summary_from(self, small):
-        # the step's single device->host read-back, into a pinned buffer (a pageable .cpu() adds ~50 us of staging)
-        host = getattr(self, "_small_host", None)
-        if host is None or host.numel() != small.numel():
-            host = self._small_host = torch.empty(small.numel(), dtype=small.dtype, pin_memory=True)
+    _RING = 4                            # pinned read-back buffers: the host runs at most _RING - 1 steps ahead
+
+    def _summary_from(self, small, finish, keys):
+        """The step's single device->host read-back (39 floats into a pinned buffer, enqueued on the step's stream behind
+        its last kernel; a pageable .cpu() adds ~50 us of staging) and `finish(numbers)` -> the loss_summary values.
+        Eager (default, the reference's behaviour): wait for it and return a plain dict.  `self.defer_summary`: return a
+        DeferredSummary that waits when first looked at, so the host can enqueue the next step while this one runs (the
+        end-of-step bubble -- synchronise, read, re-launch -- was ~0.2 ms of a 16.5 ms step)."""
+        ring = getattr(self, "_small_ring", None)
+        if ring is None or ring[0][0].numel() != small.numel():
+            ring = self._small_ring = [[torch.empty(small.numel(), dtype=small.dtype, pin_memory=True), None]
+                                       for _ in range(self._RING)]
+            self._ring_at = 0
+        slot = ring[self._ring_at]
+        self._ring_at = (self._ring_at + 1) % self._RING
+        if slot[1] is not None:          # a summary nobody has looked at still owns this buffer: settle it first
+            slot[1].resolve()
+        host = slot[0]
         host.copy_(small, non_blocking=True)
-        torch.cuda.current_stream(small.device).synchronize()
-        v = host.numpy().copy()
-        hl, ha = v[:18], v[18:36]
-        lR, lN, lT = float(hl[0:6].sum()), float(hl[6:12].sum()), float(hl[12:18].sum())
-        aR, aN, aT = float(ha[0:6].mean()), float(ha[6:12].mean()), float(ha[12:18].mean())
-        return lR, lN, lT, aR, aN, aT, float(v[36]), v[37], v[38]
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(small.device))
+
+        def read():
+            done.synchronize()
+            slot[1] = None
+            v = host.numpy().copy()
+            hl, ha = v[:18], v[18:36]
+            lR, lN, lT = float(hl[0:6].sum()), float(hl[6:12].sum()), float(hl[12:18].sum())
+            aR, aN, aT = float(ha[0:6].mean()), float(ha[6:12].mean()), float(ha[12:18].mean())
+            return dict(zip(keys, finish(lR, lN, lT, aR, aN, aT, float(v[36]))))
+
+        if not getattr(self, "defer_summary", False):
+            return read()
+        slot[1] = DeferredSummary(keys, read)
+        return slot[1]
 
     def _generic_allreduce(self, params):
         """autograd path under data parallelism: sum the parameter gradients across ranks (one collective per tensor;
@@ -472,10 +499,13 @@ class Image3MEngine(_FusedStepMixin, Engine):
         if self._fused_ok():
             small, out3 = self._fused_step(imgs, pids, self.weight_x, self.weight_m, self.margin, self.criterion_x.eps,
                                            total_rows)
-            lR, lN, lT, aR, aN, aT, lm = self._summary_from(small)[:7]
-            loss_x = lR + lN + lT
-            values = (self.weight_m * lm + self.weight_x * loss_x, loss_x, out3[0].clone(), aR, lR, aN, lN, aT, lT)
-            return dict(zip(_SUMMARY_3M, values))
+            loss_m = out3[0].clone()     # 'LossM' stays a 0-d device tensor like the reference's (margin.py:145)
+
+            def finish(lR, lN, lT, aR, aN, aT, lm):
+                loss_x = lR + lN + lT
+                return (self.weight_m * lm + self.weight_x * loss_x, loss_x, loss_m, aR, lR, aN, lN, aT, lT)
+
+            return self._summary_from(small, finish, _SUMMARY_3M)
         # ---- generic path: the reference's step (margin.py:102-152) over the autograd bridge
         oR, oN, oT, fR, fN, fT = self.model(imgs)
         scale = ddp.ce_grad_scale(int(pids.shape[0]), total_rows)
@@ -515,7 +545,8 @@ class MultiModalImageSoftmaxEngine(_FusedStepMixin, Engine):
         imgs, pids = self._to_device(imgs, pids)
         if self._fused_ok():
             small, _ = self._fused_step(imgs, pids, 1.0, 0.0, 0.0, self.criterion.eps, total_rows)
-            lR, lN, lT, aR, aN, aT = self._summary_from(small)[:6]
+            return self._summary_from(small, lambda lR, lN, lT, aR, aN, aT, lm: (lR + lN + lT, lR, aR, lN, aN, lT, aT),
+                                      ('loss_all', 'loss_R', 'acc_R', 'loss_N', 'acc_N', 'loss_T', 'acc_T'))
         else:
             heads = self.model(imgs)[:3]
             per_modality = [self.compute_loss(self.criterion, o, pids) for o in heads]

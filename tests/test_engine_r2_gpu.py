@@ -105,6 +105,27 @@ def test_softmax_engine_step_matches_reference(G):
     compare_stats([stats(sd[n]) for n in bnames], G["softmax8/post_buffer_stats"], bnames, 1e-3, "running stats")
 
 
+@pytest.mark.parametrize("kind", ["margin", "softmax"])
+def test_deferred_summary_equals_the_eager_one(kind):
+    """`engine.defer_summary`: forward_backward returns before the device is done and the numbers arrive on first look;
+    five steps queued back to back (more than the ring of pinned read-back buffers) give, step for step, the values of
+    five eager steps from the same start (fp32 parity mode; both runs are the same kernels in the same order)"""
+    from ieee_amd.meters import DeferredSummary
+    state = generated_state(shapes(171), 9)
+    runs = []
+    for defer in (False, True):
+        m = build(171, "margin" if kind == "margin" else "softmax", state).train()
+        eng = engine_for(m, kind)
+        eng.defer_summary = defer
+        got = [eng.forward_backward(batch(8, 9)) for _ in range(5)]
+        assert all(isinstance(s, DeferredSummary) == defer for s in got)
+        if defer:
+            assert not got[-1].resolved and got[0].resolved     # the ring settled the oldest ones when it wrapped
+        runs.append([[float(v) for v in s.values()] for s in got])
+        assert tuple(got[0]) == (KEYS_SM if kind == "softmax" else tuple(got[0].keys()))
+    np.testing.assert_array_equal(np.array(runs[0]), np.array(runs[1]))
+
+
 @pytest.mark.parametrize("tag,flags", [("c750_train8", {}), ("c750_train8_noatt", dict(attention=False)),
                                        ("c750_train8_nocim", dict(interaction=False)), ("c750_train8_norem", dict(using_REM=False))])
 def test_750_classes_fp32_match_reference(G, tag, flags):
