@@ -308,7 +308,8 @@ def main():
         "config": {"workload": "IEEE3modalPart train step, RGBNT201-shaped 256x128 triples, batch %d per GPU, "
                                "171 classes, full CIM+REM+3M, SGD-nesterov" % B,
                    "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "loss_last_step": float(summary["loss"])},
+                   "loss_last_step": float(summary["loss"]),
+                   "summary_readback": "on first look (engine.defer_summary)" if engine.defer_summary else "inside every step"},
         "roofline": roofline,
     }
     if rank == 0:
