@@ -7,6 +7,8 @@
 // lanes of a block and finished through LDS.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace ieee {
@@ -234,6 +236,52 @@ __device__ __forceinline__ void reduce_over_ty(float* acc, int tx, int ty, int t
   }
 }
 
+// Row blocks.  The three kernels below that deal with the `parts` overlapping row bins give each row lane `ty` of a block
+// a run of consecutive map rows [r0, r1) instead of every ty-th position: such a run meets at most MAXS bins
+// (first .. first + MAXS - 1; 2 for the 16-row / 6-part map), so a thread keeps MAXS x VEC bin values in registers instead
+// of 8 x VEC, and the which-bins-hold-this-row decision is taken once per row, not once per position.  (With 64
+// accumulators plus 64 pre-scaled pooled gradients per thread the first form of these kernels needed 150-300 VGPRs --
+// one to three waves per SIMD, scratch spills in the forward -- and ran at 1.9 TB/s; the plain pools next to them, same
+// geometry without the bins, at 4.4-5.3.)  MAXS is a template parameter (2 or 4) the launchers pick from the geometry.
+// VEC consecutive fp32 / int32 values as 16-byte loads (the operands are 16-byte aligned: checked by the launchers).
+// Element-wise loads behind the mode tests compiled to one 4-byte load and one wait per element.
+template <int VEC, typename S> __device__ __forceinline__ void load_vec(const S* __restrict__ p, S (&d)[VEC]) {
+  static_assert(sizeof(S) == 4 && VEC % 4 == 0, "16-byte pieces of 4-byte values");
+#pragma unroll
+  for (int q = 0; q < VEC / 4; ++q) {
+    const uint4 v = *(const uint4*)(p + 4 * q);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[4 * q + e] = __builtin_bit_cast(S, w[e]);
+  }
+}
+
+constexpr int MAXS_MAX = 4;
+struct RowBlock { int r0, r1, first; };
+__host__ __device__ inline int rb_bin_start(int i, int H, int parts) { return (i * H) / parts; }
+__host__ __device__ inline int rb_bin_end(int i, int H, int parts) { return ((i + 1) * H + parts - 1) / parts; }
+__host__ __device__ inline RowBlock row_block(int ty, int tyn, int H, int parts) {
+  const int rpt = (H + tyn - 1) / tyn;
+  RowBlock rb;
+  rb.r0 = ty * rpt < H ? ty * rpt : H;
+  rb.r1 = rb.r0 + rpt < H ? rb.r0 + rpt : H;
+  rb.first = 0;
+  while (rb.first < parts && rb_bin_end(rb.first, H, parts) <= rb.r0) ++rb.first;
+  return rb;
+}
+// largest number of bins any row block meets (host side, for the launch check)
+static int row_block_bins(int tyn, int H, int parts) {
+  int worst = 0;
+  for (int ty = 0; ty < tyn; ++ty) {
+    const RowBlock rb = row_block(ty, tyn, H, parts);
+    int last = rb.first - 1;
+    for (int i = rb.first; i < parts; ++i)
+      if (rb_bin_start(i, H, parts) < rb.r1 && rb_bin_end(i, H, parts) > rb.r0) last = i;
+    if (rb.r1 > rb.r0 && last - rb.first + 1 > worst) worst = last - rb.first + 1;
+  }
+  return worst;
+}
+
 // K1: S_m = F_a + F_b (a,b = the other two modalities) and G_m = mean over positions of F_m
 template <typename T>
 __global__ __launch_bounds__(256) void gpool_sum_others_kernel(const T* __restrict__ F, T* __restrict__ S,
@@ -334,70 +382,92 @@ __global__ __launch_bounds__(256) void ca_pool_kernel(const T* __restrict__ y2, 
 
 // K5: out = act1(y1) + act2(y2)*(1+att), pooled into `parts` overlapping row bins -> Pp [3][B][parts][C] fp32
 //   mode 0: full CIM (act = relu(bn)), mode 1: attention off (att ignored), mode 2: interaction off (out = y1 raw)
-template <typename T>
+template <typename T, int MAXS>
 __global__ __launch_bounds__(256) void cim_tail_kernel(const T* __restrict__ y1, const T* __restrict__ y2,
                                                        const float* __restrict__ st1, const float* __restrict__ st2,
                                                        const float* __restrict__ att, float* __restrict__ Pp,
                                                        PosGeom g, int64_t gs, int H, int parts, int mode) {
   constexpr int VEC = 16 / sizeof(T);
-  constexpr int MAXP = 8;
-  __shared__ float red[RED_Q * 256];
+  __shared__ float part[256 * MAXS * VEC];   // [ty][MAXS][tx * VEC]
   const int z = blockIdx.y;
   const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
   const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
   const int c0 = (cb * g.tx + tx) * VEC;
   float sc1[VEC], sh1[VEC], sc2[VEC], sh2[VEC], at[VEC];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    sc1[e] = 1.f; sh1[e] = 0.f; sc2[e] = 0.f; sh2[e] = 0.f; at[e] = 0.f;
-    if (mode != 2) {
-      sc1[e] = st1[(int64_t)z * 4 * g.C + 2 * g.C + c0 + e];
-      sh1[e] = st1[(int64_t)z * 4 * g.C + 3 * g.C + c0 + e];
-      sc2[e] = st2[(int64_t)z * 4 * g.C + 2 * g.C + c0 + e];
-      sh2[e] = st2[(int64_t)z * 4 * g.C + 3 * g.C + c0 + e];
-    }
-    if (mode == 0) at[e] = att[((int64_t)z * g.B + b) * g.C + c0 + e];
+  for (int e = 0; e < VEC; ++e) { sc1[e] = 1.f; sh1[e] = 0.f; sc2[e] = 0.f; sh2[e] = 0.f; at[e] = 0.f; }
+  if (mode != 2) {
+    load_vec<VEC>(st1 + (int64_t)z * 4 * g.C + 2 * g.C + c0, sc1);
+    load_vec<VEC>(st1 + (int64_t)z * 4 * g.C + 3 * g.C + c0, sh1);
+    load_vec<VEC>(st2 + (int64_t)z * 4 * g.C + 2 * g.C + c0, sc2);
+    load_vec<VEC>(st2 + (int64_t)z * 4 * g.C + 3 * g.C + c0, sh2);
   }
-  float acc[MAXP * VEC];
+  if (mode == 0) load_vec<VEC>(att + ((int64_t)z * g.B + b) * g.C + c0, at);
+  const RowBlock rb = row_block(ty, g.ty, H, parts);
+  float acc[MAXS * VEC];
 #pragma unroll
-  for (int e = 0; e < MAXP * VEC; ++e) acc[e] = 0.f;
-  int bs[MAXP], be[MAXP];   // row bins, computed once (empty beyond `parts`)
+  for (int e = 0; e < MAXS * VEC; ++e) acc[e] = 0.f;
+  for (int h = rb.r0; h < rb.r1; ++h) {
+    float row[VEC];
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    bs[i] = i < parts ? bin_start(i, H, parts) : 0;
-    be[i] = i < parts ? bin_end(i, H, parts) : 0;
-  }
-#pragma unroll 4
-  for (int p = ty; p < g.P; p += g.ty) {
-    const int h = p / g.W;
-    const int64_t off = z * gs + ((int64_t)b * g.P + p) * g.C + c0;
-    float v1[VEC], v2[VEC], o[VEC];
-    Vec16<T>::unpack(*(const uint4*)(y1 + off), v1);
-    if (mode != 2) {
-      Vec16<T>::unpack(*(const uint4*)(y2 + off), v2);
+    for (int e = 0; e < VEC; ++e) row[e] = 0.f;
+    const int64_t off0 = z * gs + ((int64_t)b * g.P + h * g.W) * g.C + c0;
+    // the loads of WB positions are issued together (clamped past the row end), then consumed: left to the unroller the
+    // two loads of a position were waited for before the next position's were issued
+    constexpr int WB = 4;
+    for (int w0 = 0; w0 < g.W; w0 += WB) {
+      uint4 r1[WB], r2[WB];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        o[e] = fmaxf(v1[e] * sc1[e] + sh1[e], 0.f) + fmaxf(v2[e] * sc2[e] + sh2[e], 0.f) * (1.f + at[e]);
-    } else {
+      for (int k = 0; k < WB; ++k) {
+        const int64_t o = off0 + (int64_t)min(w0 + k, g.W - 1) * g.C;
+        r1[k] = *(const uint4*)(y1 + o);
+        r2[k] = mode != 2 ? *(const uint4*)(y2 + o) : make_uint4(0, 0, 0, 0);
+      }
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) o[e] = v1[e];
+      for (int k = 0; k < WB; ++k) {
+        if (w0 + k >= g.W) break;
+        float v1[VEC], v2[VEC];
+        Vec16<T>::unpack(r1[k], v1);
+        Vec16<T>::unpack(r2[k], v2);
+        if (mode != 2) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            row[e] += fmaxf(v1[e] * sc1[e] + sh1[e], 0.f) + fmaxf(v2[e] * sc2[e] + sh2[e], 0.f) * (1.f + at[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) row[e] += v1[e];
+        }
+      }
     }
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-      if (h >= bs[i] && h < be[i]) {
+    for (int k = 0; k < MAXS; ++k) {
+      const int i = rb.first + k;
+      if (i < parts && h >= rb_bin_start(i, H, parts) && h < rb_bin_end(i, H, parts)) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[i * VEC + e] += o[e];
+        for (int e = 0; e < VEC; ++e) acc[k * VEC + e] += row[e];
       }
     }
   }
-  reduce_over_ty<MAXP * VEC>(acc, tx, ty, g.tx, g.ty, red);
-  if (ty == 0) {
-    for (int i = 0; i < parts; ++i) {
-      const float inv = 1.0f / ((bin_end(i, H, parts) - bin_start(i, H, parts)) * g.W);
+  // every row lane leaves its MAXS bin sums in LDS; bin i of a channel is then the sum, in lane order, of the slots that
+  // stand for bin i (slots of bins a lane's rows do not meet hold 0)
+  const int txw = g.tx * VEC, txw_log2 = __ffs(txw) - 1;   // a power of two
+  __shared__ int firsts[256];
+  __shared__ float invs[8];
+  if (t < g.ty) firsts[t] = row_block(t, g.ty, H, parts).first;   // (integer divisions: once per lane / bin, not per output)
+  if (t < parts) invs[t] = 1.0f / ((rb_bin_end(t, H, parts) - rb_bin_start(t, H, parts)) * g.W);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        Pp[(((int64_t)z * g.B + b) * parts + i) * g.C + c0 + e] = acc[i * VEC + e] * inv;
+  for (int k = 0; k < MAXS; ++k)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) part[(ty * MAXS + k) * txw + tx * VEC + e] = acc[k * VEC + e];
+  __syncthreads();
+  for (int idx = t; idx < parts * txw; idx += 256) {
+    const int i = idx >> txw_log2, c = idx & (txw - 1);
+    float sum = 0.f;
+    for (int y = 0; y < g.ty; ++y) {
+      const int k = i - firsts[y];
+      if (k >= 0 && k < MAXS) sum += part[(y * MAXS + k) * txw + c];
     }
+    Pp[(((int64_t)z * g.B + b) * parts + i) * g.C + cb * txw + c] = sum * invs[i];
   }
 }
 
@@ -415,7 +485,7 @@ __device__ __forceinline__ void dout_at(const float* dP, int64_t base, int C, in
 }
 
 // backward part 1: d_att[b,c] = sum_pos d_out * rest
-template <typename T>
+template <typename T, int MAXS>
 __global__ __launch_bounds__(256) void cim_bwd_datt_kernel(const float* __restrict__ dP, const T* __restrict__ y2,
                                                            const float* __restrict__ st2, float* __restrict__ datt,
                                                            PosGeom g, int64_t gs, int H, int parts) {
@@ -428,39 +498,53 @@ __global__ __launch_bounds__(256) void cim_bwd_datt_kernel(const float* __restri
   const float* sc = st2 + (int64_t)z * 4 * g.C + 2 * g.C;
   const float* sh = sc + g.C;
   const int64_t pbase = ((int64_t)z * g.B + b) * parts * g.C;
-  // the pooled gradients of this thread's channels, pre-scaled by their bin size, and the BN coefficients: loaded
-  // once (as in cim_bwd_g_kernel) instead of per position
-  constexpr int MAXP = 8;
-  float dps[MAXP][VEC], scv[VEC], shv[VEC];
-  int bs[MAXP], be[MAXP];
+  // the pooled gradients of this thread's channels for the bins its rows meet, pre-scaled by their bin size, and the
+  // BN coefficients: loaded once instead of per position
+  const RowBlock rb = row_block(ty, g.ty, H, parts);
+  float dps[MAXS][VEC], scv[VEC], shv[VEC];
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    bs[i] = i < parts ? bin_start(i, H, parts) : 0;
-    be[i] = i < parts ? bin_end(i, H, parts) : 0;
-    const float inv = i < parts ? 1.0f / ((be[i] - bs[i]) * g.W) : 0.f;
+  for (int k = 0; k < MAXS; ++k) {
+    const int i = rb.first + k;
+    const bool on = i < parts && rb.r1 > rb.r0;
+    const float inv = on ? 1.0f / ((rb_bin_end(i, H, parts) - rb_bin_start(i, H, parts)) * g.W) : 0.f;
+    load_vec<VEC>(dP + pbase + (int64_t)(on ? i : 0) * g.C + c0, dps[k]);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) dps[i][e] = i < parts ? dP[pbase + (int64_t)i * g.C + c0 + e] * inv : 0.f;
+    for (int e = 0; e < VEC; ++e) dps[k][e] = on ? dps[k][e] * inv : 0.f;
   }
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) { scv[e] = sc[c0 + e]; shv[e] = sh[c0 + e]; }
+  load_vec<VEC>(sc + c0, scv);
+  load_vec<VEC>(sh + c0, shv);
   float acc[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-#pragma unroll 4
-  for (int p = ty; p < g.P; p += g.ty) {
-    const int h = p / g.W;
-    float d[VEC], v[VEC];
+  for (int h = rb.r0; h < rb.r1; ++h) {
+    float d[VEC], row[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) d[e] = 0.f;
+    for (int e = 0; e < VEC; ++e) { d[e] = 0.f; row[e] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i)
-      if (h >= bs[i] && h < be[i]) {
+    for (int k = 0; k < MAXS; ++k) {
+      const int i = rb.first + k;
+      if (i < parts && h >= rb_bin_start(i, H, parts) && h < rb_bin_end(i, H, parts)) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) d[e] += dps[i][e];
+        for (int e = 0; e < VEC; ++e) d[e] += dps[k][e];
       }
-    Vec16<T>::unpack(*(const uint4*)(y2 + z * gs + ((int64_t)b * g.P + p) * g.C + c0), v);
+    }
+    constexpr int WB = 8;   // loads of WB positions in flight together (clamped past the row end)
+    const int64_t off0 = z * gs + ((int64_t)b * g.P + h * g.W) * g.C + c0;
+    for (int w0 = 0; w0 < g.W; w0 += WB) {
+      uint4 r[WB];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] += d[e] * fmaxf(v[e] * scv[e] + shv[e], 0.f);
+      for (int k = 0; k < WB; ++k) r[k] = *(const uint4*)(y2 + off0 + (int64_t)min(w0 + k, g.W - 1) * g.C);
+#pragma unroll
+      for (int k = 0; k < WB; ++k) {
+        if (w0 + k >= g.W) break;
+        float v[VEC];
+        Vec16<T>::unpack(r[k], v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) row[e] += fmaxf(v[e] * scv[e] + shv[e], 0.f);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] += d[e] * row[e];   // d is the same for every position of a row
   }
   reduce_over_ty<VEC>(acc, tx, ty, g.tx, g.ty, red);
   if (ty == 0) {
@@ -473,7 +557,7 @@ __global__ __launch_bounds__(256) void cim_bwd_datt_kernel(const float* __restri
 //   mode 2 (interaction off): g1 = d_out (gradient straight to the trunk output), no g2.
 // One block per (sample, channel block): the per-(b,c) operands (6 pooled gradients pre-scaled by their
 // bin size, attention, BN scale/shift) are loaded once and the block then streams its 128 positions.
-template <typename T>
+template <typename T, int MAXS>
 __global__ __launch_bounds__(256) void cim_bwd_g_kernel(const float* __restrict__ dP, const T* __restrict__ y1,
                                                         const T* __restrict__ y2, const float* __restrict__ st1,
                                                         const float* __restrict__ st2, const float* __restrict__ att,
@@ -483,103 +567,117 @@ __global__ __launch_bounds__(256) void cim_bwd_g_kernel(const float* __restrict_
                                                         int mode, int64_t pool_gs, float* __restrict__ bnp1,
                                                         float* __restrict__ bnp2) {
   constexpr int VEC = 16 / sizeof(T);
-  constexpr int MAXP = 8;
   __shared__ float red[RED_Q * 256];
   const int z = blockIdx.y;
   const int t = threadIdx.x, tx = t % g.tx, ty = t / g.tx;
   const int b = blockIdx.x / g.cblocks, cb = blockIdx.x % g.cblocks;
   const int c0 = (cb * g.tx + tx) * VEC;
-  float dps[MAXP][VEC];
-  int bs[MAXP], be[MAXP];
+  const RowBlock rb = row_block(ty, g.ty, H, parts);
+  float dps[MAXS][VEC];
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    bs[i] = i < parts ? bin_start(i, H, parts) : 0;
-    be[i] = i < parts ? bin_end(i, H, parts) : 0;
-    const float inv = i < parts ? 1.0f / ((be[i] - bs[i]) * g.W) : 0.f;
+  for (int k = 0; k < MAXS; ++k) {
+    const int i = rb.first + k;
+    const bool on = i < parts && rb.r1 > rb.r0;
+    const float inv = on ? 1.0f / ((rb_bin_end(i, H, parts) - rb_bin_start(i, H, parts)) * g.W) : 0.f;
+    load_vec<VEC>(dP + (((int64_t)z * g.B + b) * parts + (on ? i : 0)) * g.C + c0, dps[k]);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e)
-      dps[i][e] = i < parts ? dP[(((int64_t)z * g.B + b) * parts + i) * g.C + c0 + e] * inv : 0.f;
-  }
-  float sc1[VEC], sh1[VEC], sc2[VEC], sh2[VEC], a1[VEC], dav[VEC], dmx[VEC];
-  int am[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    sc1[e] = sh1[e] = sc2[e] = sh2[e] = 0.f; a1[e] = 1.f; dav[e] = dmx[e] = 0.f; am[e] = -1;
-    if (mode != 2) {
-      sc1[e] = st1[(int64_t)z * 4 * g.C + 2 * g.C + c0 + e];
-      sh1[e] = st1[(int64_t)z * 4 * g.C + 3 * g.C + c0 + e];
-      sc2[e] = st2[(int64_t)z * 4 * g.C + 2 * g.C + c0 + e];
-      sh2[e] = st2[(int64_t)z * 4 * g.C + 3 * g.C + c0 + e];
-    }
-    if (mode == 0) {
-      const int64_t bc = ((int64_t)z * g.B + b) * g.C + c0 + e;
-      const int64_t pc = z * pool_gs + (int64_t)b * g.C + c0 + e;
-      a1[e] = 1.f + att[bc];
-      dav[e] = davg[pc] * (1.0f / g.P);
-      dmx[e] = dmax[pc];
-      am[e] = amax[bc];
-    }
+    for (int e = 0; e < VEC; ++e) dps[k][e] = on ? dps[k][e] * inv : 0.f;
   }
   // BN-backward sums of convOne / convAvgRest (sum g, sum g*y over this sample's positions, of the ROUNDED g
   // that is stored), emitted per sample so that bn2d_bwd(stats_rblocks = B) needs no reduction pass
-  float bsum[4 * VEC];
+  // Two passes over this thread's rows, one per gradient map: each keeps only its own per-channel operands in
+  // registers (2 x VEC for g1, 6 x VEC for g2) -- together with the row-block form 300 -> ~130 VGPRs
+  auto run = [&](auto PASS) {
+    constexpr int pass = decltype(PASS)::value;
+    float sc[VEC], sh[VEC], a1[VEC], dav[VEC], dmx[VEC];
+    int am[VEC];
+    const float* stp = pass == 0 ? st1 : st2;
 #pragma unroll
-  for (int e = 0; e < 4 * VEC; ++e) bsum[e] = 0.f;
-#pragma unroll 4
-  for (int p = ty; p < g.P; p += g.ty) {
-    const int h = p / g.W;
-    float d[VEC];
+    for (int e = 0; e < VEC; ++e) { sc[e] = sh[e] = 0.f; a1[e] = 1.f; dav[e] = dmx[e] = 0.f; am[e] = -1; }
+    if (mode != 2) {
+      load_vec<VEC>(stp + (int64_t)z * 4 * g.C + 2 * g.C + c0, sc);
+      load_vec<VEC>(stp + (int64_t)z * 4 * g.C + 3 * g.C + c0, sh);
+    }
+    if (mode == 0 && pass == 1) {
+      const int64_t bc = ((int64_t)z * g.B + b) * g.C + c0;
+      const int64_t pc = z * pool_gs + (int64_t)b * g.C + c0;
+      load_vec<VEC>(att + bc, a1);
+      load_vec<VEC>(davg + pc, dav);
+      load_vec<VEC>(dmax + pc, dmx);
+      load_vec<VEC>(amax + bc, am);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) d[e] = 0.f;
+      for (int e = 0; e < VEC; ++e) { a1[e] += 1.f; dav[e] *= 1.0f / g.P; }
+    }
+    const T* yy = pass == 0 ? y1 : y2;
+    T* gg = pass == 0 ? g1 : g2;
+    float bsum[2 * VEC];
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i)
-      if (h >= bs[i] && h < be[i]) {
+    for (int e = 0; e < 2 * VEC; ++e) bsum[e] = 0.f;
+    for (int h = rb.r0; h < rb.r1; ++h) {
+      float d[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) d[e] += dps[i][e];
+      for (int e = 0; e < VEC; ++e) d[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXS; ++k) {
+        const int i = rb.first + k;
+        if (i < parts && h >= rb_bin_start(i, H, parts) && h < rb_bin_end(i, H, parts)) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) d[e] += dps[k][e];
+        }
       }
-    const int64_t off = z * gs + ((int64_t)b * g.P + p) * g.C + c0;
-    if (mode == 2) {
-      *(uint4*)(g1 + off) = Vec16<T>::pack(d);
-      continue;
-    }
-    float v1[VEC], v2[VEC], o1[VEC], o2[VEC];
-    Vec16<T>::unpack(*(const uint4*)(y1 + off), v1);
-    Vec16<T>::unpack(*(const uint4*)(y2 + off), v2);
+      if (mode == 2) {
+        const uint4 q = Vec16<T>::pack(d);
+        for (int w = 0; w < g.W; ++w) *(uint4*)(g1 + z * gs + ((int64_t)b * g.P + h * g.W + w) * g.C + c0) = q;
+        continue;
+      }
+      constexpr int WB = 8;   // loads of WB positions in flight together (clamped past the row end)
+      const int64_t off0 = z * gs + ((int64_t)b * g.P + h * g.W) * g.C + c0;
+      for (int w0 = 0; w0 < g.W; w0 += WB) {
+        uint4 r[WB];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const bool on1 = v1[e] * sc1[e] + sh1[e] > 0.f;
-      const bool on2 = v2[e] * sc2[e] + sh2[e] > 0.f;
-      float t2 = d[e] * a1[e] + dav[e];
-      if (am[e] == p) t2 += dmx[e];
-      o1[e] = on1 ? d[e] : 0.f;
-      o2[e] = on2 ? t2 : 0.f;
-    }
-    const uint4 q1 = Vec16<T>::pack(o1), q2 = Vec16<T>::pack(o2);
-    *(uint4*)(g1 + off) = q1;
-    *(uint4*)(g2 + off) = q2;
-    if (bnp1 != nullptr) {
-      Vec16<T>::unpack(q1, o1);
-      Vec16<T>::unpack(q2, o2);
+        for (int k = 0; k < WB; ++k) r[k] = *(const uint4*)(yy + off0 + (int64_t)min(w0 + k, g.W - 1) * g.C);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        bsum[e] += o1[e]; bsum[VEC + e] += o1[e] * v1[e];
-        bsum[2 * VEC + e] += o2[e]; bsum[3 * VEC + e] += o2[e] * v2[e];
+        for (int k = 0; k < WB; ++k) {
+          if (w0 + k >= g.W) break;
+          const int p = h * g.W + w0 + k;
+          float v[VEC], o[VEC];
+          Vec16<T>::unpack(r[k], v);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const bool on = v[e] * sc[e] + sh[e] > 0.f;
+            float tv = d[e];
+            if (pass == 1) {
+              tv = d[e] * a1[e] + dav[e];
+              if (am[e] == p) tv += dmx[e];
+            }
+            o[e] = on ? tv : 0.f;
+          }
+          const uint4 q = Vec16<T>::pack(o);
+          *(uint4*)(gg + off0 + (int64_t)(w0 + k) * g.C) = q;
+          Vec16<T>::unpack(q, o);          // (summed whether or not the sums are asked for: no branch inside the loop)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            bsum[e] += o[e];
+            bsum[VEC + e] += o[e] * v[e];
+          }
+        }
       }
     }
-  }
-  if (bnp1 != nullptr && mode != 2) {   // partial layout [z][2][C][B] (sample index innermost, see StagedStoreEpi)
-    reduce_over_ty<4 * VEC>(bsum, tx, ty, g.tx, g.ty, red);
-    if (ty == 0) {
+    if (bnp1 != nullptr && mode != 2) {   // partial layout [z][2][C][B] (sample index innermost, see StagedStoreEpi)
+      reduce_over_ty<2 * VEC>(bsum, tx, ty, g.tx, g.ty, red);
+      if (ty == 0) {
+        float* bnp = pass == 0 ? bnp1 : bnp2;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const int64_t o = ((int64_t)z * 2 * g.C + c0 + e) * g.B + b;
-        bnp1[o] = bsum[e];
-        bnp1[o + (int64_t)g.C * g.B] = bsum[VEC + e];
-        bnp2[o] = bsum[2 * VEC + e];
-        bnp2[o + (int64_t)g.C * g.B] = bsum[3 * VEC + e];
+        for (int e = 0; e < VEC; ++e) {
+          const int64_t o = ((int64_t)z * 2 * g.C + c0 + e) * g.B + b;
+          bnp[o] = bsum[e];
+          bnp[o + (int64_t)g.C * g.B] = bsum[VEC + e];
+        }
       }
     }
-  }
+  };
+  run(std::integral_constant<int, 0>());
+  if (mode != 2) run(std::integral_constant<int, 1>());
 }
 
 // gradient w.r.t. the trunk output: dF_m = D1_m + DS_a + DS_b + dG_m/P  (a,b = other modalities)
@@ -707,11 +805,16 @@ extern "C" int ieee_cim_tail_fwd(const void* y1, const void* y2, const float* st
   IEEE_REQUIRE(parts >= 1 && parts <= 8, "cim_tail_fwd: parts must be in [1,8]");
   IEEE_REQUIRE(mode == 2 || (y2 && stats1 && stats2), "cim_tail_fwd: missing CIM operands");
   IEEE_REQUIRE(mode != 0 || att, "cim_tail_fwd: attention weights missing");
+  IEEE_REQUIRE((((uintptr_t)stats1 | (uintptr_t)stats2 | (uintptr_t)att | (uintptr_t)parts_out) & 15) == 0, "cim_tail_fwd: the fp32 / int32 operands must be 16-byte aligned");
   const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
+  IEEE_REQUIRE(row_block_bins(g.ty, (int)H, (int)parts) <= MAXS_MAX, "cim_tail_fwd: a row block of this %ld-row / %ld-part map meets more than %d bins", (long)H, (long)parts, MAXS_MAX);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(B * g.cblocks), 3);
-  DISPATCH_T(dtype, (cim_tail_kernel<float><<<grid, 256, 0, st>>>((const float*)y1, (const float*)y2, stats1, stats2, att, parts_out, g, B * H * W * C, (int)H, (int)parts, mode)),
-             (cim_tail_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y1, (const bf16*)y2, stats1, stats2, att, parts_out, g, B * H * W * C, (int)H, (int)parts, mode)));
+  if (row_block_bins(g.ty, (int)H, (int)parts) <= 2) {
+    DISPATCH_T(dtype, (cim_tail_kernel<float, 2><<<grid, 256, 0, st>>>((const float*)y1, (const float*)y2, stats1, stats2, att, parts_out, g, B * H * W * C, (int)H, (int)parts, mode)), (cim_tail_kernel<bf16, 2><<<grid, 256, 0, st>>>((const bf16*)y1, (const bf16*)y2, stats1, stats2, att, parts_out, g, B * H * W * C, (int)H, (int)parts, mode)));
+  } else {
+    DISPATCH_T(dtype, (cim_tail_kernel<float, 4><<<grid, 256, 0, st>>>((const float*)y1, (const float*)y2, stats1, stats2, att, parts_out, g, B * H * W * C, (int)H, (int)parts, mode)), (cim_tail_kernel<bf16, 4><<<grid, 256, 0, st>>>((const bf16*)y1, (const bf16*)y2, stats1, stats2, att, parts_out, g, B * H * W * C, (int)H, (int)parts, mode)));
+  }
   return launch_status("cim_tail_kernel");
 }
 
@@ -719,11 +822,16 @@ extern "C" int ieee_cim_tail_bwd_datt(const float* dparts, const void* y2, const
                                       int64_t B, int64_t H, int64_t W, int64_t C, int64_t parts, void* stream) {
   IEEE_REQUIRE(dparts && y2 && stats2 && datt, "cim_tail_bwd_datt: null pointer");
   IEEE_REQUIRE(parts >= 1 && parts <= 8, "cim_tail_bwd_datt: parts must be in [1,8]");
+  IEEE_REQUIRE((((uintptr_t)dparts | (uintptr_t)stats2 | (uintptr_t)datt) & 15) == 0, "cim_tail_bwd_datt: the fp32 / int32 operands must be 16-byte aligned");
   const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
+  IEEE_REQUIRE(row_block_bins(g.ty, (int)H, (int)parts) <= MAXS_MAX, "cim_tail_bwd_datt: a row block of this %ld-row / %ld-part map meets more than %d bins", (long)H, (long)parts, MAXS_MAX);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(B * g.cblocks), 3);
-  DISPATCH_T(dtype, (cim_bwd_datt_kernel<float><<<grid, 256, 0, st>>>(dparts, (const float*)y2, stats2, datt, g, B * H * W * C, (int)H, (int)parts)),
-             (cim_bwd_datt_kernel<bf16><<<grid, 256, 0, st>>>(dparts, (const bf16*)y2, stats2, datt, g, B * H * W * C, (int)H, (int)parts)));
+  if (row_block_bins(g.ty, (int)H, (int)parts) <= 2) {
+    DISPATCH_T(dtype, (cim_bwd_datt_kernel<float, 2><<<grid, 256, 0, st>>>(dparts, (const float*)y2, stats2, datt, g, B * H * W * C, (int)H, (int)parts)), (cim_bwd_datt_kernel<bf16, 2><<<grid, 256, 0, st>>>(dparts, (const bf16*)y2, stats2, datt, g, B * H * W * C, (int)H, (int)parts)));
+  } else {
+    DISPATCH_T(dtype, (cim_bwd_datt_kernel<float, 4><<<grid, 256, 0, st>>>(dparts, (const float*)y2, stats2, datt, g, B * H * W * C, (int)H, (int)parts)), (cim_bwd_datt_kernel<bf16, 4><<<grid, 256, 0, st>>>(dparts, (const bf16*)y2, stats2, datt, g, B * H * W * C, (int)H, (int)parts)));
+  }
   return launch_status("cim_bwd_datt_kernel");
 }
 
@@ -737,11 +845,16 @@ extern "C" int ieee_cim_tail_bwd_g(const float* dparts, const void* y1, const vo
   IEEE_REQUIRE((bn_partial1 == nullptr) == (bn_partial2 == nullptr), "cim_tail_bwd_g: give both BN partial buffers or none");
   IEEE_REQUIRE(mode == 2 || (y1 && y2 && stats1 && stats2 && g2), "cim_tail_bwd_g: missing CIM operands");
   IEEE_REQUIRE(mode != 0 || (att && davg && dmax && argmax), "cim_tail_bwd_g: missing attention operands");
+  IEEE_REQUIRE((((uintptr_t)dparts | (uintptr_t)stats1 | (uintptr_t)stats2 | (uintptr_t)att | (uintptr_t)davg | (uintptr_t)dmax | (uintptr_t)argmax) & 15) == 0 && (pool_gs & 3) == 0, "cim_tail_bwd_g: the fp32 / int32 operands must be 16-byte aligned");
   const PosGeom g = pos_geom((int)B, (int)H, (int)W, (int)C, vecw(dtype));
+  IEEE_REQUIRE(row_block_bins(g.ty, (int)H, (int)parts) <= MAXS_MAX, "cim_tail_bwd_g: a row block of this %ld-row / %ld-part map meets more than %d bins", (long)H, (long)parts, MAXS_MAX);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(B * g.cblocks), 3);
-  DISPATCH_T(dtype, (cim_bwd_g_kernel<float><<<grid, 256, 0, st>>>(dparts, (const float*)y1, (const float*)y2, stats1, stats2, att, davg, dmax, argmax, (float*)g1, (float*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs, bn_partial1, bn_partial2)),
-             (cim_bwd_g_kernel<bf16><<<grid, 256, 0, st>>>(dparts, (const bf16*)y1, (const bf16*)y2, stats1, stats2, att, davg, dmax, argmax, (bf16*)g1, (bf16*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs, bn_partial1, bn_partial2)));
+  if (row_block_bins(g.ty, (int)H, (int)parts) <= 2) {
+    DISPATCH_T(dtype, (cim_bwd_g_kernel<float, 2><<<grid, 256, 0, st>>>(dparts, (const float*)y1, (const float*)y2, stats1, stats2, att, davg, dmax, argmax, (float*)g1, (float*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs, bn_partial1, bn_partial2)), (cim_bwd_g_kernel<bf16, 2><<<grid, 256, 0, st>>>(dparts, (const bf16*)y1, (const bf16*)y2, stats1, stats2, att, davg, dmax, argmax, (bf16*)g1, (bf16*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs, bn_partial1, bn_partial2)));
+  } else {
+    DISPATCH_T(dtype, (cim_bwd_g_kernel<float, 4><<<grid, 256, 0, st>>>(dparts, (const float*)y1, (const float*)y2, stats1, stats2, att, davg, dmax, argmax, (float*)g1, (float*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs, bn_partial1, bn_partial2)), (cim_bwd_g_kernel<bf16, 4><<<grid, 256, 0, st>>>(dparts, (const bf16*)y1, (const bf16*)y2, stats1, stats2, att, davg, dmax, argmax, (bf16*)g1, (bf16*)g2, g, B * H * W * C, (int)H, (int)parts, mode, pool_gs, bn_partial1, bn_partial2)));
+  }
   return launch_status("cim_bwd_g_kernel");
 }
 
