@@ -59,3 +59,15 @@ timed("cim_bwd_g", lambda: L.check(lib.ieee_cim_tail_bwd_g(
     L.ptr(bp1), L.ptr(bp2), st)), 4 * MB)
 timed("cim_bwd_combine", lambda: L.check(lib.ieee_cim_bwd_combine(L.ptr(g1), L.ptr(g2), L.ptr(Gp), L.ptr(dF), dt, B, H, W, C, 0, st)),
       3 * MB)
+
+# ---- the stem's max-pool at its shape (B=64, 128x64 -> 64x32, 64 channels)
+Hs, Ws, Cs = 128, 64, 64
+xs = torch.randn(3, B, Hs, Ws, Cs, generator=g).to(dev, torch.bfloat16)
+Ho, Wo = (Hs + 2 - 3) // 2 + 1, (Ws + 2 - 3) // 2 + 1
+po = torch.empty(3, B, Ho, Wo, Cs, device=dev, dtype=torch.bfloat16)
+pa = torch.empty(3, B, Ho, Wo, Cs, device=dev, dtype=torch.uint8)
+dpo = torch.randn(3, B, Ho, Wo, Cs, generator=g).to(dev, torch.bfloat16)
+dxs = torch.empty_like(xs)
+MBs = xs.numel() * 2 / 1e6
+timed("maxpool_fwd", lambda: L.check(lib.ieee_maxpool3x3s2_fwd(L.ptr(xs), L.ptr(po), L.ptr(pa), dt, 3, B, Hs, Ws, Cs, st)), MBs * 1.375)
+timed("maxpool_bwd", lambda: L.check(lib.ieee_maxpool3x3s2_bwd(L.ptr(dpo), L.ptr(pa), L.ptr(dxs), dt, 3, B, Hs, Ws, Cs, st)), MBs * 1.375)
