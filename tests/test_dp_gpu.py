@@ -89,6 +89,35 @@ def test_two_rank_step_equals_serial_sum(tmp_path):
     assert err < 1e-6, err
 
 
+def _worker_update(rank, world, port, out_path, overlap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), IEEE_DIST_BACKEND="gloo", IEEE_FORCE_DEVICE="0", IEEE_OPT_OVERLAP=overlap)
+    from ieee_amd import dist as ddp
+    from ieee_amd.optim import build_optimizer
+    ddp.init_from_env()
+    eng, m = _build(7 + rank)
+    eng.optimizer = build_optimizer(m, optim="sgd", lr=0.05, weight_decay=5e-4, momentum=0.9)
+    for step in range(2):
+        eng.forward_backward(_batch(16, 7 + step))
+    torch.cuda.synchronize()
+    torch.save({"params": m._flat_params.cpu(), "momentum": eng.optimizer.momentum_buffer().cpu()}, out_path + str(rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_update_by_part_equals_one_update_and_keeps_replicas_equal(tmp_path):
+    """staged data-parallel step: the optimizer update applied part by part behind each part's all-reduce (the default)
+    leaves bit for bit the parameters and momentum of one optimizer.step() after the last all-reduce, on both ranks"""
+    got = {}
+    for overlap in ("1", "0"):
+        out = str(tmp_path / ("upd%s_" % overlap))
+        mp.spawn(_worker_update, args=(2, _free_port(), out, overlap), nprocs=2, join=True)
+        got[overlap] = [torch.load(out + str(r)) for r in range(2)]
+    for key in ("params", "momentum"):
+        assert torch.equal(got["1"][0][key], got["1"][1][key])          # replicas stay identical
+        assert torch.equal(got["1"][0][key], got["0"][0][key])          # by part == all at once
+    assert not torch.equal(got["1"][0]["momentum"], torch.zeros_like(got["1"][0]["momentum"]))
+
+
 # ---- query-sharded evaluator on the device (SURVEY.md §8e): two ranks share the GPU over gloo
 def _eval_data():
     g = torch.Generator().manual_seed(11)
