@@ -64,7 +64,7 @@ template <typename T> struct StoreEpi {
 // sum / sum-of-squares (of the ROUNDED stored values) so that no separate statistics pass is needed:
 // bn_partial[group][2][N][tiles_m] (row tiles innermost: the finalize kernel reads one channel's partials as
 // one contiguous run instead of a stride-2N walk, which took 15-70 us on the 1024-4096 row tiles of layer1/stem).
-template <typename T, int MODE> struct StagedStoreEpi {
+template <typename T, int MODE, bool PERM = false> struct StagedStoreEpi {
   static constexpr bool kStaged = true;
   static constexpr bool STATS = MODE == 1 || MODE == 2;
   // MODE 3 (inference): the consumer BatchNorm runs on running statistics, so its scale / shift are known before
@@ -82,6 +82,15 @@ template <typename T, int MODE> struct StagedStoreEpi {
   const T* bmask;
   const float* bstats;
   const uint8_t* bbits = nullptr;   // the mask as packed bits (one byte per 8 channels, ieee_bn2d_fwd relu_bits) instead of bmask
+  // GEMM rows in parity-class-major order (stride-2 dgrad, LoaderIm2colNT<.., true>): row m0 + r of the tile is pixel
+  // pbase + (2*(r / pwc))*pW + 2*(r % pwc) of the output map (pwc = 0: rows are pixels)
+  // (pwc = Wo/2 is a power of two on this path: pwl = log2; a tensor of one modality has < 2^31 elements)
+  int pwc = 0, pwl = 0, pW = 0, pimg = 0, phc = 0, pnimg = 0;
+  __device__ __forceinline__ int tile_pixel0(int m0) const {   // pixel of the tile's first row (class offsets included)
+    const int per_img = phc * pwc, per_cls = pnimg * per_img;
+    const int cls = m0 / per_cls, rc = m0 - cls * per_cls, n = rc / per_img, i0 = (rc - n * per_img) >> pwl;
+    return n * pimg + (2 * i0 + (cls >> 1)) * pW + (cls & 1);
+  }
   template <int BM, int BN, int FM, int FN>
   __device__ __forceinline__ void finish(f32x4 (&acc)[FM][FN], char* smem, int m0, int n0) const {
     constexpr int VEC = 16 / sizeof(T);
@@ -116,6 +125,7 @@ template <typename T, int MODE> struct StagedStoreEpi {
       // block-input dgrads ran 1.5x longer than the forward convs of the same GEMM shape).  Rows past M read row M-1.
       constexpr int NP = BM / RPP;
       constexpr int HP = NP > 4 ? 4 : NP;
+      const int pix0 = PERM ? tile_pixel0(m0) : 0;
       const bool has_add = addend != nullptr;
       const bool has_bits = MODE == 2 && sizeof(T) == 2 && bbits != nullptr;
       const bool has_mask = MODE == 2 && (bmask != nullptr || has_bits);
@@ -133,11 +143,16 @@ template <typename T, int MODE> struct StagedStoreEpi {
       for (int p0 = 0; p0 < NP; p0 += HP) {
         uint4 va[HP], vy[HP], vk[HP];
         unsigned kb[HP];
-        int64_t off[HP];
+        int off[HP];
 #pragma unroll
         for (int h = 0; h < HP; ++h) {
-          const int m = m0 + r0 + RPP * (p0 + h);
-          off[h] = (int64_t)(m < M ? m : M - 1) * ld + n;
+          const int rr = r0 + RPP * (p0 + h);
+          const int m = m0 + rr;
+          if constexpr (!PERM) {
+            off[h] = (m < M ? m : M - 1) * (int)ld + n;
+          } else {   // (M is a whole number of tiles on this path)
+            off[h] = (pix0 + 2 * (rr >> pwl) * pW + 2 * (rr & (pwc - 1))) * (int)ld + n;
+          }
           va[h] = vy[h] = vk[h] = make_uint4(0, 0, 0, 0);
           kb[h] = 0;
         }
@@ -150,7 +165,7 @@ template <typename T, int MODE> struct StagedStoreEpi {
           for (int h = 0; h < HP; ++h) vy[h] = *(const uint4*)(by + off[h]);
           if (has_bits) {
 #pragma unroll
-            for (int h = 0; h < HP; ++h) kb[h] = bbits[off[h] >> 3];
+            for (int h = 0; h < HP; ++h) kb[h] = bbits[(unsigned)off[h] >> 3];
           } else if (has_mask) {
 #pragma unroll
             for (int h = 0; h < HP; ++h) vk[h] = *(const uint4*)(bmask + off[h]);
@@ -216,7 +231,7 @@ template <typename T, int MODE> struct StagedStoreEpi {
               for (int e = 0; e < VEC; ++e) { s1[e] += f[e]; s2[e] += f[e] * yv[e]; }
             }
           }
-          *(uint4*)(out + (int64_t)(m0 + r) * ld + n) = v;
+          *(uint4*)(out + off[h]) = v;
         }
       }
     }
@@ -326,7 +341,7 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
 // PIPE = 0: register staging, one LDS stage (high occupancy: the many-workgroup layers).  PIPE = 2..4: LDS-DMA ring
 // of PIPE stages with PIPE-1 k-tiles in flight (few-workgroup layers, where no co-resident workgroup hides the
 // load latency of a one-tile-deep pipeline); bf16 fast path only.
-template <typename T, int BN, bool SLOW, int MODE, int PIPE = 0>
+template <typename T, int BN, bool SLOW, int MODE, int PIPE = 0, bool PERM = false>
 __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ? 3 : 1)))) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
                                                           T* __restrict__ dst, const T* __restrict__ addend,
                                                           float* __restrict__ bn_partial, ConvArgs a, BwdStats bs) {
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
   w += z * a.w_gs;
   dst += z * a.dst_gs;
   if (addend != nullptr) addend += z * a.dst_gs;
-  StagedStoreEpi<T, MODE> epi{0, dst, addend, (MODE == 1 || MODE == 2) ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
+  StagedStoreEpi<T, MODE, PERM> epi{0, dst, addend, (MODE == 1 || MODE == 2) ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
                               MODE == 2 ? (const T*)bs.y + z * bs.act_gs : nullptr,
                               (MODE == 2 && bs.mask && !bs.mask_bits) ? (const T*)bs.mask + z * bs.act_gs : nullptr,
                               ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
@@ -353,7 +368,14 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
     // the packed weights are a plain [N][ldw] matrix (ldw = ktiles * 64, zero padded): lean issue, see glds16_lean
     LoaderPlainLean<BN / 32> lbd;
     lbd.init(w, a.ldw, n0, a.N, ch);
-    if (a.g.R == 1 && a.g.S == 1 && a.g.mul == 1 && a.g.off == 0 && a.g.div == 1) {
+    if constexpr (PERM) {
+      // stride-2 dgrad, GEMM rows in parity-class-major order (LoaderIm2colNT<.., true>): dead taps are skipped
+      epi.pwc = a.g.Wo >> 1; epi.pwl = __ffs(epi.pwc) - 1; epi.phc = a.g.Ho >> 1; epi.pW = a.g.Wo; epi.pimg = a.g.Ho * a.g.Wo;
+      epi.pnimg = a.g.npix / (a.g.Ho * a.g.Wo);
+      LoaderIm2colNT<T, 4, true> la;
+      la.init(src, a.g, m0, ch);
+      gemm_nt_dma<128, BN, PIPE>(la, lbd, epi, a.ktiles, m0, n0, smem);
+    } else if (a.g.R == 1 && a.g.S == 1 && a.g.mul == 1 && a.g.off == 0 && a.g.div == 1) {
       // 1x1 / stride 1 / no padding (two thirds of the launches): im2col(X) is X itself, a plain [pixels][C] matrix --
       // no pixel decode, no tap masks (their set-up rivals the whole k-loop of the K = 64..256 layers), and the same
       // lean issue as the weights (C is a multiple of 64 on this path: no k tail)
@@ -780,21 +802,28 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 template <typename T> static int conv_bk() { return ImgNT<T>::BK; }
 
 // one instantiation of the gather kernel; > 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
-template <typename T, int BN, bool SLOW, int MODE, int PIPE>
+template <typename T, int BN, bool SLOW, int MODE, int PIPE, bool PERM = false>
 static void launch_gather_inst(dim3 grid, size_t smem, hipStream_t st, const T* src, const T* w, T* dst, const T* addend,
                                float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, BN, SLOW, MODE, PIPE>,
+    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, BN, SLOW, MODE, PIPE, PERM>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  conv_gather_kernel<T, BN, SLOW, MODE, PIPE><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
+  conv_gather_kernel<T, BN, SLOW, MODE, PIPE, PERM><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
 }
 
 template <typename T, int BN, int PIPE>
 static void launch_gather_mode(int mode, dim3 grid, size_t smem, hipStream_t st, const T* src, const T* w, T* dst,
                                const T* addend, float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
+  if constexpr (PIPE == 1 && BN != 256 && sizeof(T) == 2) {   // stride-2 dgrad in parity-class row order: its own instantiations
+    if (a.g.perm && (mode == 0 || mode == 2)) {
+      if (mode == 2) launch_gather_inst<T, BN, false, 2, PIPE, true>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
+      else launch_gather_inst<T, BN, false, 0, PIPE, true>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
+      return;
+    }
+  }
   if (mode == 3) launch_gather_inst<T, BN, false, 3, PIPE>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
   else if (mode == 2) launch_gather_inst<T, BN, false, 2, PIPE>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
   else if (mode == 1) launch_gather_inst<T, BN, false, 1, PIPE>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
@@ -845,6 +874,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   GatherPlan plan{N <= 64 ? 64 : 128, 0};
   if (sizeof(T) == 2 && !slow) plan = plan_gather(M, N, a.ktiles, groups);
   const bool narrow = plan.bn == 64;
+  if (plan.pipe != 1 || plan.bn == 256 || affine || (bn_partial && !bwd)) a.g.perm = 0;   // class-major rows: default pipeline, dgrad modes
   a.tiles_n = cdiv(N, plan.bn);
   dim3 grid(a.tiles_m * a.tiles_n, groups);
   const int stages = plan.pipe == 5 ? 1 : (plan.pipe ? plan.pipe : (sizeof(T) == 2 ? 1 : 2));   // PIPE 5 = one stage too
@@ -855,6 +885,10 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
     const size_t red_bytes = 2 * (16 / sizeof(T)) * 260 * 4;   // BN-sum reduction scratch: [2*VEC] planes of 260 floats
     if (smem < epi_bytes) smem = epi_bytes;
     if (smem < red_bytes) smem = red_bytes;
+  }
+  if ((int64_t)M * N >= (1ll << 31)) {   // the staged epilogue keeps 32-bit element offsets
+    set_error(IEEE_ERR_UNSUPPORTED, "conv: more than 2^31 output elements per modality (%ld x %ld)", (long)M, (long)N);
+    return IEEE_ERR_UNSUPPORTED;
   }
   const bool stats = bn_partial != nullptr;
   if (stats && (slow || sizeof(T) != 2)) {
@@ -1074,6 +1108,12 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
     return launch_gather<float>((const float*)dy, (const float*)w_packed_d, (float*)dx, (const float*)addend, g,
                                 g.npix, d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st);
   if (dtype == IEEE_BF16) {
+    // stride 2: rows in parity-class-major order so that a workgroup skips the taps that cannot reach its pixels
+    static const bool f_perm = !(getenv("IEEE_DGRAD_PERM") && atoi(getenv("IEEE_DGRAD_PERM")) == 0);
+    // (3x3 only: for a 1x1 the skipped work is outweighed by the stride-2 scatter of the stores -- 140 -> 167 us alone)
+    if (f_perm && d.stride == 2 && d.R * d.S > 1 && !(d.Hi & 1) && !(d.Wi & 1) && ((d.Hi >> 1) * (d.Wi >> 1)) % 128 == 0 && 128 % (d.Wi >> 1) == 0 && d.Co % 64 == 0 && (int64_t)g.npix * d.Ci < (1ll << 31) &&
+        d.R * d.S <= 56)
+      g.perm = 1;
     BwdStats bs{bn_y, bn_mask, bn_stats, dx_gs, 4 * Ci, 0, bn_mask_bits};
     return launch_gather<bf16>((const bf16*)dy, (const bf16*)w_packed_d, (bf16*)dx, (const bf16*)addend, g, g.npix,
                                d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st, bn_partial,

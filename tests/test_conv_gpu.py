@@ -17,7 +17,8 @@ CASES = [(1, 2, 16, 8, 64, 256, 1, 1, 0),
          (1, 3, 7, 5, 128, 64, 3, 2, 1),
          (3, 2, 32, 16, 3, 64, 7, 2, 3),       # stem: element-wise gather path
          (1, 1, 8, 8, 512, 2048, 1, 1, 0),
-         (1, 4, 16, 8, 128, 128, 1, 1, 0)]
+         (1, 4, 16, 8, 128, 128, 1, 1, 0),
+         (2, 2, 32, 16, 128, 128, 3, 2, 1)]    # stride-2 3x3 dgrad in parity-class row order (bf16: dead taps skipped)
 
 
 def _ref(x, w, dy, stride, pad):
