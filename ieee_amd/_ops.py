@@ -62,7 +62,7 @@ def conv2d_dgrad(dy, wpd, in_hw, Ci, R, S, stride, pad, addend=None):
         assert addend.shape == dx.shape and addend.dtype == dx.dtype
     _lib.check(lib.ieee_conv2d_dgrad(_lib.ptr(dy), _lib.ptr(wpd), _lib.ptr(dx), _lib.ptr(addend), _dt(dy), G, N, H, W,
                                      Ci, Co, R, S, stride, pad, gs, wpd.stride(0) if wpd.dim() == 3 else 0,
-                                     N * H * W * Ci, None, None, None, None, 0, _lib.stream()))
+                                     N * H * W * Ci, None, None, None, None, 0, 1, _lib.stream()))
     return dx
 
 

@@ -64,7 +64,11 @@ template <typename T> struct StoreEpi {
 // sum / sum-of-squares (of the ROUNDED stored values) so that no separate statistics pass is needed:
 // bn_partial[group][2][N][tiles_m] (row tiles innermost: the finalize kernel reads one channel's partials as
 // one contiguous run instead of a stride-2N walk, which took 15-70 us on the 1024-4096 row tiles of layer1/stem).
-template <typename T, int MODE, bool PERM = false> struct StagedStoreEpi {
+// VAR 1: GEMM rows in parity-class order (stride-2 dgrad).  VAR 2: the addend is compact -- it holds only the pixels with even
+// row and column of this tile's map, (H/2) x (W/2) per image (the gradient a stride-2 1x1 branch sends back: every other
+// pixel gets none) -- so the branch's dgrad neither writes nor this epilogue reads the three quarters that are zero.
+template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
+  static constexpr bool PERM = VAR == 1;
   static constexpr bool kStaged = true;
   static constexpr bool STATS = MODE == 1 || MODE == 2;
   // MODE 3 (inference): the consumer BatchNorm runs on running statistics, so its scale / shift are known before
@@ -86,6 +90,7 @@ template <typename T, int MODE, bool PERM = false> struct StagedStoreEpi {
   // pbase + (2*(r / pwc))*pW + 2*(r % pwc) of the output map (pwc = 0: rows are pixels)
   // (pwc = Wo/2 is a power of two on this path: pwl = log2; a tensor of one modality has < 2^31 elements)
   int pwc = 0, pwl = 0, pW = 0, pimg = 0, phc = 0, pnimg = 0;
+  int as_wl = 0, as_hl = 0;   // VAR 2: log2 of this map's width / height (powers of two on this path)
   __device__ __forceinline__ int tile_pixel0(int m0) const {   // pixel of the tile's first row (class offsets included)
     const int per_img = phc * pwc, per_cls = pnimg * per_img;
     const int cls = m0 / per_cls, rc = m0 - cls * per_cls, n = rc / per_img, i0 = (rc - n * per_img) >> pwl;
@@ -157,8 +162,20 @@ template <typename T, int MODE, bool PERM = false> struct StagedStoreEpi {
           kb[h] = 0;
         }
         if (has_add) {
+          if constexpr (VAR == 2) {
 #pragma unroll
-          for (int h = 0; h < HP; ++h) va[h] = *(const uint4*)(addend + off[h]);
+            for (int h = 0; h < HP; ++h) {
+              const int m = min(m0 + r0 + RPP * (p0 + h), M - 1);
+              const int w = m & ((1 << as_wl) - 1), t2 = m >> as_wl, hh = t2 & ((1 << as_hl) - 1), img = t2 >> as_hl;
+              const bool even = !((w | hh) & 1);
+              const int ao = (((img << (as_hl - 1)) + (hh >> 1)) << (as_wl - 1)) + (w >> 1);
+              const uint4 q = *(const uint4*)(addend + (even ? ao : 0) * (int)ld + n);
+              va[h] = even ? q : make_uint4(0, 0, 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int h = 0; h < HP; ++h) va[h] = *(const uint4*)(addend + off[h]);
+          }
         }
         if constexpr (MODE == 2) {
 #pragma unroll
@@ -335,13 +352,14 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
   int64_t act_gs, stats_gs;
   int relu;                  // MODE 3 only
   int mask_bits = 0;         // MODE 2: `mask` is the packed bit form (one byte per 8 channels)
+  int addend_s2 = 0;         // MODE 2: the addend is compact at stride 2 (StagedStoreEpi VAR 2)
 };
 
 // (forcing 4 waves per SIMD here spills 80 VGPRs and is 2.5x slower; the default allocation gives 3)
 // PIPE = 0: register staging, one LDS stage (high occupancy: the many-workgroup layers).  PIPE = 2..4: LDS-DMA ring
 // of PIPE stages with PIPE-1 k-tiles in flight (few-workgroup layers, where no co-resident workgroup hides the
 // load latency of a one-tile-deep pipeline); bf16 fast path only.
-template <typename T, int BN, bool SLOW, int MODE, int PIPE = 0, bool PERM = false>
+template <typename T, int BN, bool SLOW, int MODE, int PIPE = 0, int VAR = 0>
 __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ? 3 : 1)))) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
                                                           T* __restrict__ dst, const T* __restrict__ addend,
                                                           float* __restrict__ bn_partial, ConvArgs a, BwdStats bs) {
@@ -353,12 +371,14 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
   src += z * a.src_gs;
   w += z * a.w_gs;
   dst += z * a.dst_gs;
-  if (addend != nullptr) addend += z * a.dst_gs;
-  StagedStoreEpi<T, MODE, PERM> epi{0, dst, addend, (MODE == 1 || MODE == 2) ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
+  if (addend != nullptr) addend += z * (VAR == 2 ? a.dst_gs / 4 : a.dst_gs);   // (VAR 2: the compact addend is a quarter map)
+  constexpr bool PERM = VAR == 1;
+  StagedStoreEpi<T, MODE, VAR> epi{0, dst, addend, (MODE == 1 || MODE == 2) ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
                               MODE == 2 ? (const T*)bs.y + z * bs.act_gs : nullptr,
                               (MODE == 2 && bs.mask && !bs.mask_bits) ? (const T*)bs.mask + z * bs.act_gs : nullptr,
                               ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
   if constexpr (MODE == 3) epi.relu = bs.relu;
+  if constexpr (VAR == 2) { epi.as_wl = __ffs(a.g.Wo) - 1; epi.as_hl = __ffs(a.g.Ho) - 1; }
   if constexpr (MODE == 2) {
     if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
   }
@@ -802,16 +822,16 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float* __restrict__
 template <typename T> static int conv_bk() { return ImgNT<T>::BK; }
 
 // one instantiation of the gather kernel; > 64 KB of dynamic LDS needs the opt-in (160 KB per CU on gfx950)
-template <typename T, int BN, bool SLOW, int MODE, int PIPE, bool PERM = false>
+template <typename T, int BN, bool SLOW, int MODE, int PIPE, int VAR = 0>
 static void launch_gather_inst(dim3 grid, size_t smem, hipStream_t st, const T* src, const T* w, T* dst, const T* addend,
                                float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, BN, SLOW, MODE, PIPE, PERM>,
+    (void)hipFuncSetAttribute((const void*)conv_gather_kernel<T, BN, SLOW, MODE, PIPE, VAR>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  conv_gather_kernel<T, BN, SLOW, MODE, PIPE, PERM><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
+  conv_gather_kernel<T, BN, SLOW, MODE, PIPE, VAR><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
 }
 
 template <typename T, int BN, int PIPE>
@@ -819,8 +839,12 @@ static void launch_gather_mode(int mode, dim3 grid, size_t smem, hipStream_t st,
                                const T* addend, float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
   if constexpr (PIPE == 1 && BN != 256 && sizeof(T) == 2) {   // stride-2 dgrad in parity-class row order: its own instantiations
     if (a.g.perm && (mode == 0 || mode == 2)) {
-      if (mode == 2) launch_gather_inst<T, BN, false, 2, PIPE, true>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
-      else launch_gather_inst<T, BN, false, 0, PIPE, true>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
+      if (mode == 2) launch_gather_inst<T, BN, false, 2, PIPE, 1>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
+      else launch_gather_inst<T, BN, false, 0, PIPE, 1>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
+      return;
+    }
+    if (bs.addend_s2 && mode == 2) {   // compact stride-2 addend (see StagedStoreEpi VAR 2)
+      launch_gather_inst<T, BN, false, 2, PIPE, 2>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
       return;
     }
   }
@@ -1092,8 +1116,11 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
                                  int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
                                  int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
                                  float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
-                                 int bn_mask_bits, void* stream) {
+                                 int bn_mask_bits, int addend_stride, void* stream) {
   IEEE_REQUIRE(dy && w_packed_d && dx, "conv2d_dgrad: null pointer");
+  IEEE_REQUIRE(addend_stride == 1 || (addend_stride == 2 && addend && bn_partial && dtype == IEEE_BF16 && stride == 1 &&
+                                      Hi > 1 && Wi > 1 && !(Hi & (Hi - 1)) && !(Wi & (Wi - 1))),
+               "conv2d_dgrad: a stride-2 addend needs the bf16 fused form of a stride-1 conv over a power-of-two map");
   IEEE_REQUIRE(!bn_mask_bits || (bn_mask && dx_gs % 8 == 0 && Ci % 8 == 0), "conv2d_dgrad: bit mask needs Cin %% 8 == 0");
   IEEE_REQUIRE(!bn_partial || bn_y, "conv2d_dgrad: fused BN-backward sums need the BN input tensor");
   Dims d;
@@ -1114,7 +1141,7 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
     if (f_perm && d.stride == 2 && d.R * d.S > 1 && !(d.Hi & 1) && !(d.Wi & 1) && ((d.Hi >> 1) * (d.Wi >> 1)) % 128 == 0 && 128 % (d.Wi >> 1) == 0 && d.Co % 64 == 0 && (int64_t)g.npix * d.Ci < (1ll << 31) &&
         d.R * d.S <= 56)
       g.perm = 1;
-    BwdStats bs{bn_y, bn_mask, bn_stats, dx_gs, 4 * Ci, 0, bn_mask_bits};
+    BwdStats bs{bn_y, bn_mask, bn_stats, dx_gs, 4 * Ci, 0, bn_mask_bits, addend_stride == 2 ? 1 : 0};
     return launch_gather<bf16>((const bf16*)dy, (const bf16*)w_packed_d, (bf16*)dx, (const bf16*)addend, g, g.npix,
                                d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st, bn_partial,
                                bn_partial ? &bs : nullptr);

@@ -535,7 +535,7 @@ struct Run {
   // prev: the unit whose BN(+ReLU) output is this conv's input; when given (bf16), the dgrad epilogue also emits
   // that BN's backward sums so that the following bn_bwd(prev) skips its reduction pass
   int dgrad(const ConvUnit& u, const void* dy, void* dx, const void* addend, const ConvUnit* prev = nullptr,
-            bool prev_mask_tensor = false) {
+            bool prev_mask_tensor = false, int addend_stride = 1) {
     const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.S);
     const bool fuse = prev != nullptr && n.dtype == IEEE_BF16;
     fused_bwd = fuse;
@@ -547,7 +547,25 @@ struct Run {
                              fuse ? P(prev->y) : nullptr,
                              (fuse && prev_mask_tensor) ? (prev->abits.numel ? P(prev->abits) : P(prev->a)) : nullptr,
                              (fuse && !prev_mask_tensor) ? F(prev->stats) : nullptr,
-                             (fuse && prev_mask_tensor && prev->abits.numel) ? 1 : 0, st);
+                             (fuse && prev_mask_tensor && prev->abits.numel) ? 1 : 0, addend_stride, st);
+  }
+  // The gradient a stride-2 1x1 (downsample) conv sends to its input touches only the pixels with even row and column:
+  // kept compact, [B, Ho, Wo, Ci], it is a dense 1x1 stride-1 dgrad over the output grid (the lean plain-matrix path) and the
+  // consumer -- the block's conv1 dgrad epilogue, addend_stride = 2 -- reads a quarter of the bytes.  The full-size form
+  // was a 3/4-zero map written and read back (layer2.0 / layer3.0: 140 + 98 us of dgrad, 300 MB of traffic each way).
+  bool compact_ds(const ConvUnit& d, const ConvUnit* prev) const {
+    static const bool on = !(getenv("IEEE_DS_COMPACT") && atoi(getenv("IEEE_DS_COMPACT")) == 0);
+    return on && n.dtype == IEEE_BF16 && prev != nullptr && d.R == 1 && d.S == 1 && d.stride == 2 && d.pad == 0 && d.Hi == 2 * d.Ho &&
+           d.Wi == 2 * d.Wo && !(d.Hi & (d.Hi - 1)) && !(d.Wi & (d.Wi - 1));
+  }
+  int dgrad_compact(const ConvUnit& d, const void* dy, void* dx) {
+    const int64_t ldd = ieee_conv_packed_ld(n.dtype, d.Co, 1, 1);
+    fused_bwd = false;
+    will_write(dx);
+    prof_begin(0, d, "dgrad");
+    struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
+    return ieee_conv2d_dgrad(dy, P(d.wd), dx, nullptr, n.dtype, 3, B, d.Ho, d.Wo, d.Ci, d.Co, 1, 1, 1, 0, d.M(B) * d.Co,
+                             d.Ci * ldd, d.M(B) * d.Ci, nullptr, nullptr, nullptr, nullptr, 0, 1, st);
   }
   // grouped fp32 GEMM over the 3 modalities with uniform strides
   int gemm3(const float* A, int64_t a_gs, const float* Bm, int64_t b_gs, float* C, int64_t c_gs, const float* bias,
@@ -819,21 +837,25 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     IEEE_TRY(bn_bwd(c1, U, nullptr, U, nullptr, 1));
     IEEE_TRY(wgrad(c1, U, xin));
     const void* addend = Q;
+    const ConvUnit* pc3 = bi > 0 ? &N.units[N.blocks[bi - 1].c3] : nullptr;
+    int addend_stride = 1;
     if (b.ds >= 0) {
       const ConvUnit& d = N.units[b.ds];
+      const bool compact = !par_ds && compact_ds(d, pc3);
       if (par_ds) {
         branch_join(bslot);
       } else {
         IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
         IEEE_TRY(wgrad(d, Q, xin));
-        IEEE_TRY(dgrad(d, Q, V, nullptr));
+        if (compact) IEEE_TRY(dgrad_compact(d, Q, V));
+        else IEEE_TRY(dgrad(d, Q, V, nullptr));
       }
       addend = V;
+      if (compact) addend_stride = 2;
     }
     // d(block input) = dgrad(conv1) + identity-branch gradient; it is d(out) of the previous block, whose bn3
     // backward sums (mask = that block's stored output) are emitted here too
-    const ConvUnit* pc3 = bi > 0 ? &N.units[N.blocks[bi - 1].c3] : nullptr;
-    IEEE_TRY(dgrad(c1, U, Xout, addend, pc3, true));
+    IEEE_TRY(dgrad(c1, U, Xout, addend, pc3, true, addend_stride));
   }
   if (lo > 0) return IEEE_OK;
   X = P(N.gbuf[set_of(-1)]);      // d(out) of the stem's max-pool, left by block 0

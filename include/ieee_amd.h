@@ -140,14 +140,17 @@ int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* dx, const vo
                       int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
                       int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
                       float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
-                      int bn_mask_bits, void* stream);
+                      int bn_mask_bits, int addend_stride, void* stream);
 /* bn_partial != NULL (bf16 only): dx is the gradient w.r.t. the output of a BN(+ReLU) whose input is bn_y; the
  * dgrad epilogue also emits that BN's backward sums [2][Ci][rblocks] (sum g, sum g*y; g = dx * [mask], mask from
  * bn_mask > 0, or from bn_y*scale+shift > 0 with bn_stats = that BN's [4][Ci] stats, or none), rblocks =
  * ceil(N*Hi*Wi/128): pass it to ieee_bn2d_bwd(stats_rblocks) and the separate reduction pass disappears.
  * With bn_mask (the ReLU behind a residual add, resnet.py:181-182) dx is stored ALREADY MASKED, dx = g: the
  * BatchNorm backward that follows then takes out_mask = NULL and reads g and y only.  bn_mask_bits = 1: bn_mask is
- * the packed form ieee_bn2d_fwd(relu_bits) wrote (one byte per 8 channels, 1/16 of the bytes), else the activation */
+ * the packed form ieee_bn2d_fwd(relu_bits) wrote (one byte per 8 channels, 1/16 of the bytes), else the activation.
+ * addend_stride = 2 (with bn_partial, stride 1, power-of-two Hi / Wi): addend is [N, Hi/2, Wi/2, Ci] and belongs to the
+ * pixels with even row and column -- what the stride-2 1x1 downsample branch of a block (resnet.py:548-556) sends back;
+ * that branch's dgrad is then a dense 1x1 stride-1 dgrad over the (Ho, Wo) grid instead of a 3/4-zero full-size map */
 
 /* dw (fp32, OIHW, the layout of param.grad) = or += sum over pixels; deterministic split-K:
  * partial slabs in `work` (size from the query below) are reduced in a fixed order */

@@ -174,7 +174,7 @@ def test_fused_bn_partials_in_conv_epilogues():
         mptr = L.ptr(amask) if mode == "mask" else (L.ptr(mbits) if mode == "bits" else None)
         L.check(lib.ieee_conv2d_dgrad(L.ptr(dy), L.ptr(wpd), L.ptr(dx), L.ptr(addend), L.IEEE_BF16, G, N, H, W, Ci, Co, 3, 3,
                                       1, 1, dy[0].numel(), wpd.stride(0), dx[0].numel(), L.ptr(p2), L.ptr(ypre),
-                                      mptr, L.ptr(stats) if mode == "stats" else None, int(mode == "bits"), L.stream()))
+                                      mptr, L.ptr(stats) if mode == "stats" else None, int(mode == "bits"), 1, L.stream()))
         results[mode] = (dx, p2)
         if mode == "bits":   # bit-identical to the mask-tensor form, stores and sums
             assert torch.equal(dx, results["mask"][0]) and torch.equal(p2, results["mask"][1])
@@ -194,6 +194,43 @@ def test_fused_bn_partials_in_conv_epilogues():
             gq = d
         torch.testing.assert_close(p2[:, 0].sum(-1), gq.sum(1), rtol=1e-3, atol=5e-2)
         torch.testing.assert_close(p2[:, 1].sum(-1), (gq * yv).sum(1), rtol=1e-3, atol=5e-2)
+
+
+def test_dgrad_with_compact_stride2_addend():
+    """the block-input dgrad whose identity-branch gradient comes from a stride-2 1x1 downsample conv: the compact
+    [N, H/2, W/2, C] addend (addend_stride = 2) gives bit for bit the stores and BatchNorm sums of the full-size map that
+    is zero at every pixel with an odd row or column"""
+    from ieee_amd import _lib as L, _ops
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(4)
+    G, N, H, W, Ci, Co = 3, 3, 16, 8, 256, 64
+    dt = torch.bfloat16
+    dy = torch.randn(G, N, H, W, Co, generator=g).cuda().to(dt)
+    w = (torch.randn(G, Co, Ci, 1, 1, generator=g) * 0.05).cuda()
+    wpd = _ops.pack_conv_weight(w, dt, 1)
+    ypre = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
+    mask = torch.rand(G, N, H, W, Ci, generator=g).cuda() > 0.5
+    bits = (mask.view(-1, 8).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
+    compact = torch.randn(G, N, H // 2, W // 2, Ci, generator=g).cuda().to(dt)
+    full = torch.zeros(G, N, H, W, Ci, device="cuda", dtype=dt)
+    full[:, :, ::2, ::2] = compact
+    rb = lib.ieee_conv2d_fwd_stats_rblocks(N, H, W)
+    got = []
+    for addend, stride in ((full, 1), (compact, 2)):
+        p2 = torch.zeros(G, 2, Ci, rb, device="cuda")
+        dx = torch.empty(G, N, H, W, Ci, device="cuda", dtype=dt)
+        L.check(lib.ieee_conv2d_dgrad(L.ptr(dy), L.ptr(wpd), L.ptr(dx), L.ptr(addend), L.IEEE_BF16, G, N, H, W, Ci, Co, 1, 1,
+                                      1, 0, dy[0].numel(), wpd.stride(0), dx[0].numel(), L.ptr(p2), L.ptr(ypre), L.ptr(bits),
+                                      None, 1, stride, L.stream()))
+        got.append((dx, p2))
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    plain = _ops.conv2d_dgrad(dy, wpd, (H, W), Ci, 1, 1, 1, 0, addend=full)
+    assert torch.equal(got[1][0], plain * mask.to(dt))
+    with pytest.raises(L.IeeeAmdError):   # the compact form exists for the fused bf16 epilogue only
+        lib_call = lib.ieee_conv2d_dgrad(L.ptr(dy), L.ptr(wpd), L.ptr(dx), L.ptr(compact), L.IEEE_BF16, G, N, H, W, Ci, Co, 1,
+                                         1, 1, 0, dy[0].numel(), wpd.stride(0), dx[0].numel(), None, None, None, None, 0, 2,
+                                         L.stream())
+        L.check(lib_call)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
