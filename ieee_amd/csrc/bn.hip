@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "pool_gather.h"
 
 namespace ieee {
 
@@ -316,6 +317,76 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---- the stem's backward in two passes: d(out) of its ReLU(BatchNorm(y)) is the backward of MaxPool2d(3,2,1) applied
+// to dpool, gathered on the fly (pool_gather.h) instead of materialised; g = that * [y*scale+shift > 0].
+// Pass 1: per-channel sums (sum g, sum g*y); pass 2: dy = k1*g + k2*y + k3.  Replaces maxpool_bwd + bn_bwd_reduce +
+// bn_bwd_apply (a full-resolution write and two full-resolution reads less, on the last stretch of the step)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_pooled_reduce_kernel(const T* __restrict__ dpool,
+                                                                   const uint8_t* __restrict__ arg,
+                                                                   const T* __restrict__ y, int64_t y_gs, int64_t p_gs,
+                                                                   RedGeom g, int Hi, int Wi, int Ho, int Wo,
+                                                                   float* partial, int64_t partial_gs,
+                                                                   const float* __restrict__ stats, int64_t stats_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const T* dd = dpool + blockIdx.y * p_gs;
+  const uint8_t* aa = arg + blockIdx.y * p_gs;
+  const T* yy = y + blockIdx.y * y_gs;
+  const float* sc = stats + blockIdx.y * stats_gs + 2 * g.C;
+  const float* sh = sc + g.C;
+  reduce_channels<T, 2>(g, partial, partial_gs, [&](int64_t off, int c0, float (*acc)[VEC]) {
+    const int row = (int)(off / g.C);
+    const int w = row % Wi, h = (row / Wi) % Hi, b = row / (Wi * Hi);
+    float d[VEC], v[VEC];
+    const uint4 yv = *(const uint4*)(yy + off);
+    pool_grad_gather<T>(dd, aa, b, h, w, c0 / VEC, Ho, Wo, g.C, d);
+    Vec16<T>::unpack(yv, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float m = (v[e] * sc[c0 + e] + sh[c0 + e]) > 0.f ? d[e] : 0.f;
+      acc[0][e] += m;
+      acc[1][e] += m * v[e];
+    }
+  });
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_pooled_apply_kernel(const T* __restrict__ dpool,
+                                                                  const uint8_t* __restrict__ arg,
+                                                                  const T* __restrict__ y, T* __restrict__ dy,
+                                                                  const float* __restrict__ coef, int64_t coef_gs,
+                                                                  int64_t total_chunks, int cprw, int C, int64_t y_gs,
+                                                                  int64_t p_gs, int Hi, int Wi, int Ho, int Wo,
+                                                                  const float* __restrict__ stats, int64_t stats_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  const float* sc = stats + z * stats_gs + 2 * C;
+  const float* sh = sc + C;
+  const float* k1 = coef + z * coef_gs;
+  const float* k2 = k1 + C;
+  const float* k3 = k2 + C;
+  const T* dd = dpool + z * p_gs;
+  const uint8_t* aa = arg + z * p_gs;
+  const T* yy = y + z * y_gs;
+  T* oo = dy + z * y_gs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cprw);
+    const int row = (int)(i / cprw);
+    const int w = row % Wi, h = (row / Wi) % Hi, b = row / (Wi * Hi);
+    const int c0 = ch * VEC;
+    float d[VEC], v[VEC];
+    const uint4 yv = *(const uint4*)(yy + i * VEC);
+    pool_grad_gather<T>(dd, aa, b, h, w, ch, Ho, Wo, C, d);
+    Vec16<T>::unpack(yv, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float m = (v[e] * sc[c0 + e] + sh[c0 + e]) > 0.f ? d[e] : 0.f;
+      v[e] = k1[c0 + e] * m + k2[c0 + e] * v[e] + k3[c0 + e];
+    }
+    *(uint4*)(oo + i * VEC) = Vec16<T>::pack(v);
+  }
+}
+
 static int ew_blocks(int64_t chunks) {
   static const int64_t cap = getenv("IEEE_EW_BLOCKS") ? atoll(getenv("IEEE_EW_BLOCKS")) : 8192;   // 4096: +0.13 ms per step; 16384 and more: same as 8192 (scripts/scan_ew.sh)
   int64_t b = (chunks + 255) / 256;
@@ -410,4 +481,44 @@ extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void*
                                                     (bf16*)dy, (bf16*)g_out, coef, 3 * C, chunks, g.cprw, (int)C,
                                                     act_gs, stats, 4 * C, mask_from_y);
   return launch_status("bn_bwd_apply_kernel");
+}
+
+extern "C" int ieee_bn2d_bwd_pooled(const void* dpool, const uint8_t* argmax, const void* y, void* dy, int dtype,
+                                    int64_t groups, int64_t B, int64_t Hi, int64_t Wi, int64_t C, const float* gamma,
+                                    int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
+                                    float* partial, float* coef, int accumulate, void* stream) {
+  IEEE_REQUIRE(dpool && argmax && y && dy && gamma && stats && partial && coef, "bn2d_bwd_pooled: null pointer");
+  IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_bwd_pooled: bad dtype");
+  IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_bwd_pooled: C not a multiple of the vector width");
+  IEEE_REQUIRE(B * Hi * Wi * C < (1ll << 31), "bn2d_bwd_pooled: more than 2^31 elements per group");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t M = B * Hi * Wi;
+  const int Ho = (int)((Hi + 2 - 3) / 2 + 1), Wo = (int)((Wi + 2 - 3) / 2 + 1);
+  const int64_t y_gs = M * C, p_gs = B * Ho * Wo * C;
+  RedGeom g = red_geom(M, (int)C, vec_of(dtype));
+  const int64_t partial_gs = (int64_t)g.rblocks * 2 * C;
+  dim3 rgrid(g.cblocks * g.rblocks, (unsigned)groups);
+  if (dtype == IEEE_F32)
+    bn_bwd_pooled_reduce_kernel<float><<<rgrid, 256, 0, st>>>((const float*)dpool, argmax, (const float*)y, y_gs, p_gs, g,
+                                                              (int)Hi, (int)Wi, Ho, Wo, partial, partial_gs, stats, 4 * C);
+  else
+    bn_bwd_pooled_reduce_kernel<bf16><<<rgrid, 256, 0, st>>>((const bf16*)dpool, argmax, (const bf16*)y, y_gs, p_gs, g,
+                                                             (int)Hi, (int)Wi, Ho, Wo, partial, partial_gs, stats, 4 * C);
+  IEEE_TRY(launch_status("bn_bwd_pooled_reduce_kernel"));
+  const int lpc = finalize_lpc(g.rblocks);
+  bn_bwd_finalize_kernel<<<dim3(cdiv(C, 256 / lpc), (unsigned)groups), 256, 0, st>>>(
+      partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, param_gs, stats, 4 * C, dgamma, dbeta, grad_gs, coef,
+      3 * C, accumulate, 0, lpc);
+  IEEE_TRY(launch_status("bn_bwd_finalize_kernel"));
+  const int64_t chunks = M * C / vec_of(dtype);
+  dim3 grid(ew_blocks(chunks), (unsigned)groups);
+  if (dtype == IEEE_F32)
+    bn_bwd_pooled_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)dpool, argmax, (const float*)y, (float*)dy, coef,
+                                                            3 * C, chunks, g.cprw, (int)C, y_gs, p_gs, (int)Hi, (int)Wi, Ho,
+                                                            Wo, stats, 4 * C);
+  else
+    bn_bwd_pooled_apply_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)dpool, argmax, (const bf16*)y, (bf16*)dy, coef,
+                                                           3 * C, chunks, g.cprw, (int)C, y_gs, p_gs, (int)Hi, (int)Wi, Ho,
+                                                           Wo, stats, 4 * C);
+  return launch_status("bn_bwd_pooled_apply_kernel");
 }

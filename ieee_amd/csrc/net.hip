@@ -863,8 +863,17 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
   // stem: maxpool -> ReLU/BN -> conv wgrad (no dgrad: the input is the image)
   const ConvUnit& s = N.units[N.u_stem];
   will_write(Q);
-  IEEE_TRY(ieee_maxpool3x3s2_bwd(X, (const uint8_t*)P(N.pool_arg), Q, dt, 3, B, s.Ho, s.Wo, s.Co, st));
-  IEEE_TRY(bn_bwd(s, Q, nullptr, Q, nullptr, 1));
+  // the max-pool backward is gathered inside the two passes of the BatchNorm backward (IEEE_STEM_BWD_FUSE=0: three passes
+  // with the un-pooled gradient written and read back twice)
+  static const bool fuse_stem = !(getenv("IEEE_STEM_BWD_FUSE") && atoi(getenv("IEEE_STEM_BWD_FUSE")) == 0);
+  if (fuse_stem) {
+    fused_bwd = false;
+    IEEE_TRY(ieee_bn2d_bwd_pooled(X, (const uint8_t*)P(N.pool_arg), P(s.y), Q, dt, 3, B, s.Ho, s.Wo, s.Co, par(s.s_g),
+                                  gs(s.s_g), F(s.stats), grd(s.s_g), grd(s.s_b), gs(s.s_g), bnpart_cur, bncoef_cur, 0, st));
+  } else {
+    IEEE_TRY(ieee_maxpool3x3s2_bwd(X, (const uint8_t*)P(N.pool_arg), Q, dt, 3, B, s.Ho, s.Wo, s.Co, st));
+    IEEE_TRY(bn_bwd(s, Q, nullptr, Q, nullptr, 1));
+  }
   IEEE_TRY(wgrad(s, Q, P(N.x0)));
   return IEEE_OK;
 }

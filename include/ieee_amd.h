@@ -200,6 +200,14 @@ int ieee_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int dtype, 
 int ieee_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int dtype, int64_t groups,
                           int64_t B, int64_t Hi, int64_t Wi, int64_t C, void* stream);
 
+/* backward of maxpool(relu(bn(y))) w.r.t. y in two passes (the stem, resnet.py:622-626 reversed): the max-pool
+ * backward of dpool [groups][B][Ho][Wo][C] is gathered on the fly, masked by [y*scale+shift > 0] and pushed through
+ * the BatchNorm backward (same dgamma / dbeta / coef / partial contract as ieee_bn2d_bwd, M = B*Hi*Wi) */
+int ieee_bn2d_bwd_pooled(const void* dpool, const uint8_t* argmax, const void* y, void* dy, int dtype,
+                         int64_t groups, int64_t B, int64_t Hi, int64_t Wi, int64_t C, const float* gamma,
+                         int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
+                         float* partial, float* coef, int accumulate, void* stream);
+
 /* ---- Cross-modal Interacting Module tail (ieee3modalPart.py:266-282, 427-455) -- */
 /* F [3][B][H*W][C]: S_m = F_a + F_b (the two other modalities; S may be NULL), Gp_m = mean over positions
  * (AdaptiveAvgPool2d((1,1)) of the raw trunk map, :449-451) */

@@ -89,6 +89,50 @@ def test_bn2d_fwd_bwd(dtype, G, M, C, residual, relu):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_pooled_bn_backward(dtype):
+    """ieee_bn2d_bwd_pooled (the stem: max-pool backward gathered inside the two passes of the BatchNorm backward) against
+    the chain it replaces, maxpool_bwd -> bn2d_bwd(mask from y).  fp32: same numbers up to the contraction of one
+    multiply-add; bf16: the chain rounds the un-pooled gradient to bf16 in between, the fused form does not"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(5)
+    G, B, H, W, C = 3, 3, 14, 10, 64
+    dev = "cuda"
+    y = (torch.randn(G, B, H, W, C, generator=g) * 1.5 + 0.2).to(dev, dtype)
+    gam, bet = (torch.rand(G, C, generator=g) + 0.5).to(dev), (torch.randn(G, C, generator=g) * 0.3).to(dev)
+    dt = L.IEEE_BF16 if dtype == torch.bfloat16 else L.IEEE_F32
+    M = B * H * W
+    stats = torch.empty(G, 4, C, device=dev)
+    part = torch.empty(G * lib.ieee_bn_partial_floats(dt, M, C) + 64, device=dev)
+    a = torch.empty_like(y)
+    L.check(lib.ieee_bn2d_fwd(L.ptr(y), None, L.ptr(a), dt, G, M, C, M * C, L.ptr(gam), L.ptr(bet), C, None, None, 0,
+                              L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, 1, 0, None, L.stream()))
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = torch.empty(G, B, Ho, Wo, C, device=dev, dtype=dtype)
+    arg = torch.empty(G, B, Ho, Wo, C, device=dev, dtype=torch.uint8)
+    L.check(lib.ieee_maxpool3x3s2_fwd(L.ptr(a), L.ptr(out), L.ptr(arg), dt, G, B, H, W, C, L.stream()))
+    dpool = torch.randn(G, B, Ho, Wo, C, generator=g).to(dev, dtype)
+    da = torch.empty_like(y)
+    L.check(lib.ieee_maxpool3x3s2_bwd(L.ptr(dpool), L.ptr(arg), L.ptr(da), dt, G, B, H, W, C, L.stream()))
+    res = []
+    for fused in (False, True):
+        dy = torch.empty_like(y)
+        dg, db = torch.zeros(G, C, device=dev), torch.zeros(G, C, device=dev)
+        coef = torch.empty(G, 3, C, device=dev)
+        if fused:
+            L.check(lib.ieee_bn2d_bwd_pooled(L.ptr(dpool), L.ptr(arg), L.ptr(y), L.ptr(dy), dt, G, B, H, W, C, L.ptr(gam), C,
+                                             L.ptr(stats), L.ptr(dg), L.ptr(db), C, L.ptr(part), L.ptr(coef), 0, L.stream()))
+        else:
+            L.check(lib.ieee_bn2d_bwd(L.ptr(da), None, L.ptr(y), L.ptr(dy), None, dt, G, M, C, M * C, L.ptr(gam), C,
+                                      L.ptr(stats), L.ptr(dg), L.ptr(db), C, L.ptr(part), L.ptr(coef), 0, 1, 0, L.stream()))
+        res.append((dy, dg, db))
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(res[1][0].float(), res[0][0].float(), **tol)
+    gt = dict(rtol=1e-5, atol=1e-4) if dtype == torch.float32 else dict(rtol=1e-2, atol=0.3)
+    torch.testing.assert_close(res[1][1], res[0][1], **gt)
+    torch.testing.assert_close(res[1][2], res[0][2], **gt)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool_fwd_bwd(dtype):
     L, lib = _lib()
     g = torch.Generator().manual_seed(0)
