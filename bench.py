@@ -28,6 +28,18 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICR
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 TRAIN_GFLOP_PER_TRIPLE = 92.24
+# Algorithmic HBM floor of one train step (SURVEY.md §8d's counting): every conv output written once and
+# read once in the forward (26.47 M elements per triple, bf16), the same bytes again for the dgrad pass (dY read, dX
+# written) and for the wgrad operands (dY and X read); SGD-nesterov reads p, g, momentum and writes p, momentum (20 B per
+# parameter); the packed bf16 operands (forward + dgrad form) are written and read once each.
+CONV_OUT_ELEMS_PER_TRIPLE = 26.47e6
+N_PARAMS = 109499337
+N_CONV_PARAMS = 95714496          # backbones + convOne + convAvgRest
+
+
+def step_floor_bytes(B, esz=2):
+    act = 3 * (CONV_OUT_ELEMS_PER_TRIPLE * esz * 2) * B
+    return act + 20.0 * N_PARAMS + 2 * 2 * esz * N_CONV_PARAMS
 
 
 class _FakeDM(object):
@@ -98,7 +110,7 @@ def cpu_baseline_train(seconds_budget=25.0):
         om.train_step(sd, xs, pids, C)
         n += 1
     dt = (time.time() - t0) / n
-    return {"value": B / dt, "unit": "3-modal images/s", "cores": threads, "kind": "port",
+    return {"value": B / dt, "unit": "3-modal images/s", "cores": threads, "threads": threads, "kind": "port",
             "host_physical_cores": phys, "host_logical_cpus": logical,
             "sample": "%d oracle train steps at batch %d (fp32, torch CPU ops, %d threads of a host with %s physical cores / "
                       "%d logical CPUs), %.2f s/step" % (n, B, threads, phys, logical, dt)}
@@ -232,6 +244,8 @@ def main():
     opt = build_optimizer(model, optim="sgd", lr=1e-3, weight_decay=5e-4, momentum=0.9)
     engine = Image3MEngine(_FakeDM(C), model, opt, margin=1, weight_m=1, weight_x=1, use_gpu=True, label_smooth=True)
     engine.dp_presharded = True          # weak scaling: every rank generates its own 64 triples (identity-aligned)
+    engine.dp_total_rows = args.batch * world    # ... so the global batch is known without asking the other ranks
+    engine.resident_batch = True         # the same batch object every step: its 3M chunk check runs once
     # the loss summary of a step is read back when somebody looks at it (here: after the timed loop), not inside the
     # step: the host enqueues step k+1 while step k runs, as a training loop that prints every print_freq batches does
     engine.defer_summary = os.environ.get("IEEE_DEFER_SUMMARY", "1") != "0"
@@ -292,6 +306,39 @@ def main():
                 "conv_ms_per_step": (g_ms + w_ms) / args.steps,
                 "whole_step_frac_of_peak": value / world * TRAIN_GFLOP_PER_TRIPLE * 1e9 / (peak * 1e12)}
 
+    # whole-step HBM traffic: PMC bytes per step (committed summary of separate rocprofv3 --pmc passes) against the
+    # algorithmic floor, and the rate / fraction of the 8 TB/s peak they mean at THIS run's step time
+    step_hbm = None
+    if args.dtype == "bf16" and B == 64:
+        pmc_bytes, pmc_src = committed_traffic("_step", "hbm_bytes_per_step")
+        floor = step_floor_bytes(B)
+        step_s = dt / args.steps
+        step_hbm = {"pmc_bytes_per_step": pmc_bytes, "pmc_source": pmc_src, "algorithmic_floor_bytes": floor,
+                    "ratio_to_floor": (pmc_bytes / floor) if pmc_bytes else None,
+                    "achieved_TBps": (pmc_bytes / step_s / 1e12) if pmc_bytes else None,
+                    "frac_of_hbm_peak": (pmc_bytes / step_s / 1e9 / PEAK_HBM_GBS) if pmc_bytes else None,
+                    "floor_TBps_at_this_step_time": floor / step_s / 1e12,
+                    "floor": "3 passes x (conv outputs written + read once, bf16) + SGD 20 B/param + packed operands "
+                             "written + read once (DESIGN.md section 5)"}
+
+    # N > 1: what RCCL saw -- rank count and the time of each backward part's gradient all-reduce (a short extra leg
+    # with event pairs on the communication stream; not part of the timed region)
+    rccl = None
+    if world > 1:
+        engine.time_collectives = []
+        for _ in range(min(args.steps, 10)):
+            engine.forward_backward(batch)
+        torch.cuda.synchronize()
+        parts = {}
+        for part, e0, e1, nbytes in engine.time_collectives:
+            parts.setdefault(part, []).append((e0.elapsed_time(e1), nbytes))
+        engine.time_collectives = None
+        rccl = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+                "allreduce_ms_per_part": {str(k): sum(v[0] for v in vs) / len(vs) for k, vs in sorted(parts.items())},
+                "allreduce_bytes_per_part": {str(k): vs[0][1] for k, vs in sorted(parts.items())},
+                "note": "per backward part (0 head+CIM, 1 layer4, 2 layer3, 3 layer2, 4 layer1+stem), measured on rank 0's "
+                        "communication stream; the slices overlap the next part's backward"}
+
     line = {
         "metric": "3-modal images/s (train fwd+bwd)",
         "value": value,
@@ -312,6 +359,10 @@ def main():
                    "summary_readback": "on first look (engine.defer_summary)" if engine.defer_summary else "inside every step"},
         "roofline": roofline,
     }
+    if step_hbm is not None:
+        line["step_hbm"] = step_hbm
+    if rccl is not None:
+        line["rccl"] = rccl
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train()

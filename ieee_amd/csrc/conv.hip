@@ -914,6 +914,15 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
     set_error(IEEE_ERR_UNSUPPORTED, "conv: more than 2^31 output elements per modality (%ld x %ld)", (long)M, (long)N);
     return IEEE_ERR_UNSUPPORTED;
   }
+  // the lean LDS-DMA loaders keep 32-bit BYTE offsets per lane: (row * ld + col) * 2 over the whole source matrix of one
+  // modality (1x1 convs: [M][Cs], which can be 4x the output) and over the packed weights
+  // (and the im2col loaders 32-bit element offsets into the source tensor)
+  const int64_t src_elems = (int64_t)(g.npix / (g.Ho * g.Wo)) * g.Hs * g.Ws * g.Cs;
+  if (sizeof(T) == 2 && !slow && (src_elems >= (1ll << 31) || (int64_t)N * ldw >= (1ll << 31))) {
+    set_error(IEEE_ERR_UNSUPPORTED, "conv: a source tensor of %ld elements per modality exceeds the loaders' 32-bit offsets",
+              (long)src_elems);
+    return IEEE_ERR_UNSUPPORTED;
+  }
   const bool stats = bn_partial != nullptr;
   if (stats && (slow || sizeof(T) != 2)) {
     set_error(IEEE_ERR_UNSUPPORTED, "conv: fused BN statistics need the bf16 vector path");
@@ -1212,7 +1221,10 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
                                           stride % (vec / Ci) == 0);
   const bool slow = !chunk_ok;
   a.plain_x = (d.R == 1 && d.S == 1 && d.stride == 1 && d.pad == 0) ? 1 : 0;
-  a.lean = (a.npix % bk == 0 && d.Co >= 8 && a.ncols >= 8) ? 1 : 0;
+  // (the lean loaders keep 32-bit byte offsets into dY [npix][Co] and, for the 1x1 form, X [npix][ncols]; larger
+  // operands take the pointer-form loaders)
+  a.lean = (a.npix % bk == 0 && d.Co >= 8 && a.ncols >= 8 && (int64_t)a.npix * d.Co * 2 < (1ll << 32) &&
+            (!a.plain_x || (int64_t)a.npix * a.ncols * 2 < (1ll << 32))) ? 1 : 0;
   const int nkz = nsplit * (int)groups;
   static const int f_map = getenv("IEEE_WGRAD_MAP") ? atoi(getenv("IEEE_WGRAD_MAP")) : 2;
   a.xcd_group = (nkz >= 24 || nkz % 8 == 0) ? 1 : f_map;

@@ -97,6 +97,7 @@ struct Net {
   std::vector<hipEvent_t> side_ready;
   hipEvent_t gbuf_read[10] = {};
   hipEvent_t side_done = nullptr;
+  hipEvent_t sync_ev = nullptr;     // ieee_net_sync_streams: the branch stream's join event
   bool gbuf_pending[10] = {};
   bool side_dirty = false;
   size_t side_used = 0;
@@ -105,6 +106,7 @@ struct Net {
     for (hipEvent_t e : side_ready) (void)hipEventDestroy(e);
     for (hipEvent_t e : gbuf_read) if (e) (void)hipEventDestroy(e);
     if (side_done) (void)hipEventDestroy(side_done);
+    if (sync_ev) (void)hipEventDestroy(sync_ev);
     for (hipEvent_t e : pack_ev) if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
     for (hipEvent_t e : branch_ev) if (e) (void)hipEventDestroy(e);
@@ -1177,6 +1179,25 @@ extern "C" int ieee_net_side_wait(void* handle, void* workspace, void* waiting_s
   Run r(*n, workspace, waiting_stream);
   if (is_launch_stream) r.side_join();
   else r.side_wait_on(waiting_stream);
+  return IEEE_OK;
+}
+
+extern "C" int ieee_net_sync_streams(void* handle, void* stream) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n, "net_sync_streams: null handle");
+  hipStream_t st = (hipStream_t)stream;
+  if (n->side != nullptr) {
+    IEEE_HIP(hipEventRecord(n->side_done, n->side));
+    IEEE_HIP(hipStreamWaitEvent(st, n->side_done, 0));
+    n->side_dirty = false;
+    n->side_used = 0;
+    for (int b = 0; b < 10; ++b) n->gbuf_pending[b] = false;
+  }
+  if (n->side2 != nullptr) {
+    if (n->sync_ev == nullptr) IEEE_HIP(hipEventCreateWithFlags(&n->sync_ev, hipEventDisableTiming));
+    IEEE_HIP(hipEventRecord(n->sync_ev, n->side2));
+    IEEE_HIP(hipStreamWaitEvent(st, n->sync_ev, 0));
+  }
   return IEEE_OK;
 }
 

@@ -13,6 +13,8 @@ from collections import OrderedDict, deque
 import numpy as np
 from torch.utils.data.sampler import RandomSampler, Sampler, SequentialSampler
 
+from ..dist import shard_bounds
+
 AVAI_SAMPLERS = ['RandomIdentitySampler', 'SequentialSampler', 'RandomSampler']
 
 
@@ -60,10 +62,58 @@ class RandomIdentitySampler(Sampler):
         return self._epoch_len
 
 
-def build_train_sampler(data_source, train_sampler, batch_size=32, num_instances=4, **kwargs):
-    """the samplers the 3-modal configs can name (reference sampler.py:216-255)"""
+class ShardedIdentitySampler(Sampler):
+    """Rank `rank`'s identity-aligned slice of every GLOBAL batch of a RandomIdentitySampler (the
+    reference's nn.DataParallel scatters each batch over the GPUs, scripts/mainMultiModal.py:219-220; one process per
+    GPU draws only its own rows instead, so a rank decodes and transforms B/world triples per step, not B).
+
+    The global index sequence is the single-process one: rank 0 draws it exactly as RandomIdentitySampler does (same
+    `random` / `numpy.random` seeds => the reference's batches) and, when torch.distributed is initialised, broadcasts
+    it, so the ranks agree even if their seeds do not; without a process group (tests, `world` given explicitly) every
+    rank draws it itself and the caller seeds them alike.  Global batch g = order[g*B:(g+1)*B]; this rank keeps rows
+    [a, b) = dist.shard_bounds(B, K, world, rank) of it -- whole identities, so every 3M chunk stays rank-local.  Feed it
+    to a DataLoader with batch_size = local_batch and drop_last."""
+
+    def __init__(self, base, rank, world):
+        if not isinstance(base, RandomIdentitySampler):
+            raise TypeError('ShardedIdentitySampler shards a RandomIdentitySampler')
+        if not 0 <= rank < world:
+            raise ValueError('rank {} outside world {}'.format(rank, world))
+        self.base, self.rank, self.world = base, int(rank), int(world)
+        self.global_batch = base.ids_per_batch * base.num_instances     # what a batch of the base sampler really holds
+        self.lo, self.hi = shard_bounds(self.global_batch, base.num_instances, self.world, self.rank)
+        self.local_batch = self.hi - self.lo
+        if self.local_batch == 0:
+            raise ValueError('{} identities per batch cannot feed {} ranks'.format(base.ids_per_batch, world))
+
+    def global_order(self):
+        import torch.distributed as dist
+        live = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not live:
+            return list(iter(self.base))
+        box = [list(iter(self.base)) if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def __iter__(self):
+        order, B = self.global_order(), self.global_batch
+        mine = []
+        for start in range(0, len(order) - len(order) % B, B):
+            mine += order[start + self.lo:start + self.hi]
+        return iter(mine)
+
+    def __len__(self):
+        return len(self.base) // self.global_batch * self.local_batch
+
+
+def build_train_sampler(data_source, train_sampler, batch_size=32, num_instances=4, rank=0, world=1, **kwargs):
+    """the samplers the 3-modal configs can name (reference sampler.py:216-255); world > 1: this rank's shard of the
+    identity sampler's batches (batch_size is the GLOBAL batch)"""
     if train_sampler not in AVAI_SAMPLERS:
         raise AssertionError('train_sampler must be one of {}, but got {}'.format(AVAI_SAMPLERS, train_sampler))
     if train_sampler == 'RandomIdentitySampler':
-        return RandomIdentitySampler(data_source, batch_size, num_instances)
+        base = RandomIdentitySampler(data_source, batch_size, num_instances)
+        return base if world == 1 else ShardedIdentitySampler(base, rank, world)
+    if world > 1:
+        raise ValueError('data-parallel training shards on identity boundaries: use RandomIdentitySampler')
     return SequentialSampler(data_source) if train_sampler == 'SequentialSampler' else RandomSampler(data_source)

@@ -3,10 +3,11 @@ over the flat fp32 gradient buffer per step over RCCL/xGMI (issued as 13 slices,
 backward has finished it, so the transfer overlaps the rest of the backward; engine.py) (backend "nccl" is RCCL on ROCm), replacing
 the reference's single-process nn.DataParallel (scripts/mainMultiModal.py:219-220: per-step parameter
 broadcast + scatter + gather + reduce-add to GPU0).  Loss scaling: CE is a batch MEAN
-(cross_entropy_loss.py:50) so each rank scales it by 1/world; 3M is a SUM over identities
-(multi_modal_margin_loss_new.py:33-38) so it is not scaled; BatchNorm statistics stay rank-local, which
-is DataParallel's behaviour.  Batches are sharded on identity boundaries (multiples of K instances) so
-every 3M chunk is rank-local."""
+(cross_entropy_loss.py:50) so each rank scales it by B_local / B_global (1/world only when the identities divide
+evenly, ce_grad_scale); 3M is a SUM over identities (multi_modal_margin_loss_new.py:33-38) so it is not scaled;
+BatchNorm statistics stay rank-local, which is DataParallel's behaviour.  Batches are sharded on identity
+boundaries (multiples of K instances) so every 3M chunk is rank-local; a shard-aware loader
+(ieee_amd/data: ShardedIdentitySampler, build_loaders(rank=, world=)) hands every rank only its own rows."""
 import os
 
 import torch
@@ -83,22 +84,19 @@ def allreduce_sum_(flat):
     return flat
 
 
-_global_rows = {}
-
-
 def global_rows(local_rows):
-    """sum of the ranks' batch sizes (one tiny all-reduce, cached per local size: loaders give every rank the same
-    size sequence)"""
+    """Sum of the ranks' batch sizes: ONE 8-byte all-reduce that EVERY rank enters on EVERY call.  There is
+    deliberately no cache: a cache keyed on the local size makes the decision to issue the collective rank-local (a
+    rank whose size repeats would skip a collective another rank enters: a hang, or a pairing with that rank's first
+    gradient slice).  Loaders that know the global size say so in the batch (`global_rows`, ieee_amd/data/loader.py)
+    or through `Engine.dp_total_rows`, and then this is not called at all."""
     if world_size() == 1:
         return int(local_rows)
-    key = (int(local_rows), world_size())
-    if key not in _global_rows:
-        t = torch.tensor([float(local_rows)], dtype=torch.float64)
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        _global_rows[key] = int(round(float(t.item())))
-    return _global_rows[key]
+    t = torch.tensor([float(local_rows)], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
 
 
 def ce_grad_scale(local_rows=None, total_rows=None):
@@ -121,19 +119,51 @@ def sync_replicas(model, optimizer=None, buffers_only=False, src=0):
     rank-local during training).  The reference gets both for free from its per-step broadcast."""
     if world_size() == 1:
         return
-    flats = [model._flat_buffers, model._flat_counters]
-    if not buffers_only:
-        flats.insert(0, model._flat_params)
-        if optimizer is not None and hasattr(optimizer, "flat_state"):
-            flats.extend(optimizer.flat_state())
     gloo = dist.get_backend() == "gloo"
-    for t in flats:
+
+    def bcast(t):
         if gloo and t.is_cuda:              # gloo stages device tensors through the host anyway
             h = t.cpu()
             dist.broadcast(h, src=src)
             t.copy_(h)
         else:
             dist.broadcast(t, src=src)
+
+    if hasattr(model, "_flat_params"):
+        flats = [model._flat_buffers, model._flat_counters]
+        if not buffers_only:
+            flats.insert(0, model._flat_params)
+    else:
+        # any other nn.Module (the generic autograd path): its state_dict tensors one by one
+        with torch.no_grad():
+            named = list(model.named_buffers()) if buffers_only else list(model.state_dict(keep_vars=True).items())
+        flats = [t.data for _, t in named if torch.is_tensor(t)]
+    if not buffers_only and optimizer is not None:
+        if hasattr(optimizer, "flat_state"):
+            flats.extend(optimizer.flat_state())
+        else:
+            # torch.optim state (momentum buffers, Adam moments, step counters): same parameter order on every rank.
+            # The state must exist on every rank or on none (a freshly built optimizer has none): checked collectively.
+            tensors = []
+            for group in optimizer.param_groups:
+                for p in group["params"]:
+                    for key in sorted(optimizer.state.get(p, {})):
+                        v = optimizer.state[p][key]
+                        if torch.is_tensor(v):
+                            tensors.append(v)
+            n = torch.tensor([float(len(tensors))], dtype=torch.float64)
+            lo, hi = n.clone(), n.clone()
+            if dist.get_backend() == "nccl":
+                lo, hi = lo.cuda(), hi.cuda()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if float(lo.item()) != float(hi.item()):
+                raise RuntimeError("sync_replicas: the ranks hold different amounts of optimizer state "
+                                   "(%d..%d tensors); load the same checkpoint on every rank" % (int(lo.item()), int(hi.item())))
+            flats.extend(tensors)
+    with torch.no_grad():
+        for t in flats:
+            bcast(t)
     if hasattr(model, "invalidate_eval_cache"):
         model.invalidate_eval_cache()
 

@@ -53,9 +53,14 @@ class Engine(object):
         self.model = self.optimizer = self.scheduler = None
         self._registry = OrderedDict()       # name -> _Entry
         self._replicas_synced = False
-        # data parallel: True when every rank's loader already yields that rank's shard (bench.py); otherwise each
-        # rank is handed the global batch and keeps its identity-aligned slice (dist.shard_batch)
+        # data parallel: True when every rank's loader already yields that rank's shard (bench.py; a loader built by
+        # ieee_amd.data.build_loaders says so itself through the batch's `global_rows`); otherwise each rank is handed
+        # the global batch and keeps its identity-aligned slice (dist.shard_batch).  dp_total_rows: the global batch
+        # size of a presharded loader that does not stamp its batches (None: one tiny all-reduce per step asks).
         self.dp_presharded = False
+        self.dp_total_rows = None
+        # True only when the SAME batch object is stepped over and over (bench.py): lets the 3M chunk check run once
+        self.resident_batch = False
 
     # ---- registry ------------------------------------------------------------------------------------------------
     def register_model(self, name='model', model=None, optim=None, sched=None):
@@ -195,14 +200,26 @@ class Engine(object):
         ranks each one runs the forward for every world-th batch and one all-gather completes the matrix."""
         world, me = ddp.world_size(), ddp.rank()
         mine, rows, pids, cams = {}, [], [], []
+        # a loader that is itself sharded over the ranks (ieee_amd.data.DeviceLoader(rank=, world=)) decodes only this
+        # rank's batches and knows every batch's labels from its records; any other loader is walked in full and the
+        # foreign batches are skipped before the forward
+        presharded = world > 1 and getattr(loader, "sharded", False) and getattr(loader, "world", 1) == world
+        if presharded:
+            for p, c in loader.batch_labels():
+                pids.append(np.asarray(p).reshape(-1))
+                cams.append(np.asarray(c).reshape(-1))
+                rows.append(len(p))
         for b, data in enumerate(loader):
             imgs, p, c, timeids = self.parse_data_for_eval(data)
-            p, c = np.asarray(p).reshape(-1), np.asarray(c).reshape(-1)
-            pids.append(p)
-            cams.append(c)
-            rows.append(len(p))
-            if b % world != me:
-                continue
+            if presharded:
+                b = int(data['batch_index'])
+            else:
+                p, c = np.asarray(p).reshape(-1), np.asarray(c).reshape(-1)
+                pids.append(p)
+                cams.append(c)
+                rows.append(len(p))
+                if b % world != me:
+                    continue
             if self.use_gpu:
                 imgs = [im.cuda(non_blocking=True) for im in imgs]
             t0 = time.time()
@@ -223,38 +240,39 @@ class Engine(object):
                   ranks=[1, 5, 10, 20], rerank=False):
         """descriptors -> distance matrix -> CMC / mAP, printed like engine.py:339-441; returns (rank-1, mAP)"""
         clock = AverageMeter()
+        say = print if ddp.rank() == 0 else (lambda *a, **k: None)     # one report, not one per rank
         if ddp.world_size() > 1 and self.model is not None and hasattr(self.model, "_flat_buffers"):
             ddp.sync_replicas(self.model, buffers_only=True)       # DataParallel evaluates with GPU 0's statistics
-        print('Extracting features from query set ...')
+        say('Extracting features from query set ...')
         qf, q_pids, q_camids = self._descriptors(query_loader, clock)
-        print('Done, obtained {}-by-{} matrix'.format(qf.size(0), qf.size(1)))
-        print('Extracting features from gallery set ...')
+        say('Done, obtained {}-by-{} matrix'.format(qf.size(0), qf.size(1)))
+        say('Extracting features from gallery set ...')
         gf, g_pids, g_camids = self._descriptors(gallery_loader, clock)
-        print('Done, obtained {}-by-{} matrix'.format(gf.size(0), gf.size(1)))
-        print('Speed: {:.4f} sec/batch'.format(clock.avg))
+        say('Done, obtained {}-by-{} matrix'.format(gf.size(0), gf.size(1)))
+        say('Speed: {:.4f} sec/batch'.format(clock.avg))
         if normalize_feature:
-            print('Normalzing features with L2 norm ...')
+            say('Normalzing features with L2 norm ...')
             qf, gf = F.normalize(qf, p=2, dim=1), F.normalize(gf, p=2, dim=1)
-        print('Computing distance matrix with metric={} ...'.format(dist_metric))
+        say('Computing distance matrix with metric={} ...'.format(dist_metric))
         sharded = ddp.world_size() > 1 and not use_metric_cuhk03 and not rerank
         if sharded:     # each rank ranks its slice of the queries against the whole gallery (ieee_amd/dist.py)
-            print('Computing CMC and mAP for {} (queries sharded over {} ranks)'.format(dataset_name, ddp.world_size()))
+            say('Computing CMC and mAP for {} (queries sharded over {} ranks)'.format(dataset_name, ddp.world_size()))
             cmc, mAP = ddp.sharded_evaluate_rank(qf, gf, q_pids, g_pids, q_camids, g_camids, metric=dist_metric)
         else:
             distmat = compute_distance_matrix(qf, gf, dist_metric)
             if rerank:  # engine.py:402-406: k-reciprocal re-ranking with the query-query and gallery-gallery matrices
-                print('Applying person re-ranking ...')
+                say('Applying person re-ranking ...')
                 from .rerank import re_ranking
                 distmat = re_ranking(distmat, compute_distance_matrix(qf, qf, dist_metric),
                                      compute_distance_matrix(gf, gf, dist_metric))
-            print('Computing CMC and mAP for {}'.format(dataset_name))
+            say('Computing CMC and mAP for {}'.format(dataset_name))
             cmc, mAP = evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, use_metric_cuhk03=use_metric_cuhk03)
-        print('** Results **')
-        print('mAP: {:.2%}'.format(mAP))
-        print('CMC curve')
+        say('** Results **')
+        say('mAP: {:.2%}'.format(mAP))
+        say('CMC curve')
         for r in ranks:
-            print('Rank-{:<3}: {:.2%}'.format(r, cmc[r - 1]))     # IndexError when r exceeds the curve, as in the reference
-        print('\n')
+            say('Rank-{:<3}: {:.2%}'.format(r, cmc[r - 1]))     # IndexError when r exceeds the curve, as in the reference
+        say('\n')
         return cmc[0], mAP
 
     # ---- small hooks the reference exposes ------------------------------------------------------------------------
@@ -302,13 +320,18 @@ class Engine(object):
         rows = int(data['pid'].shape[0])
         if world == 1:
             return data, rows
+        stamped = data.get('global_rows') if isinstance(data, dict) else None
+        if stamped is not None:                    # a shard-aware loader: this rank's rows of a global batch of `stamped`
+            return data, int(stamped)
         if self.dp_presharded:
-            return data, ddp.global_rows(rows)
+            return data, int(self.dp_total_rows) if self.dp_total_rows is not None else ddp.global_rows(rows)
         k = int(getattr(self.datamanager, 'num_instances', 4))
         return ddp.shard_batch(data, k), rows
 
     def _sync_replicas_once(self):
-        if ddp.world_size() > 1 and not self._replicas_synced and hasattr(self.model, "_flat_params"):
+        """before the first step every rank takes rank 0's parameters, buffers and optimizer state: native models through
+        their flat buffers, any other nn.Module / torch.optim optimizer tensor by tensor (dist.sync_replicas)"""
+        if ddp.world_size() > 1 and not self._replicas_synced and self.model is not None:
             ddp.sync_replicas(self.model, self.optimizer)
         self._replicas_synced = True
 
@@ -337,11 +360,16 @@ class _FusedStepMixin(object):
         """the reference's IndexError, raised where the reference raises it: before backward / the optimizer"""
         if weight_m <= 0:
             return
-        key = (pids.data_ptr(), pids._version, tuple(pids.shape), pids.device)
-        if getattr(self, "_chunk_key", None) != key:       # a resident batch (bench.py) is checked once
-            self._chunk_bad = _chunks_short_of_identities(pids)
-            self._chunk_key = key
-        if self._chunk_bad:
+        # checked on every batch (64 labels: negligible next to a step); only a caller that declares its batch resident
+        # (`engine.resident_batch`, bench.py: the same tensor object every step) gets the answer of the first check --
+        # the address / version / shape of a DataLoader batch is NOT an identity: the allocator hands the same block out
+        # again for the next batch
+        if self.resident_batch and getattr(self, "_chunk_for", None) is pids:
+            bad = self._chunk_bad
+        else:
+            bad = _chunks_short_of_identities(pids)
+            self._chunk_for, self._chunk_bad = (pids if self.resident_batch else None), bad
+        if bad:
             raise IndexError('tuple index out of range')
 
     def _fused_step(self, imgs, pids, weight_x, weight_m, margin, eps, total_rows=None):
@@ -416,10 +444,17 @@ class _FusedStepMixin(object):
                 comm.wait_stream(main)
                 net.side_wait(comm)
                 with torch.cuda.stream(comm):
+                    timing = getattr(self, "time_collectives", None)     # bench.py's RCCL leg: event pair per part
+                    if timing is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(comm)
                     handles = [torch.distributed.all_reduce(m._flat_grads[a:b], op=torch.distributed.ReduceOp.SUM, async_op=True)
                                for a, b in ranges]
                     for h in handles:
                         h.wait()                 # orders the comm stream (not the host) after the collective
+                    if timing is not None:
+                        e1.record(comm)
+                        timing.append((part, e0, e1, 4 * sum(b - a for a, b in ranges)))
                     if by_part:
                         self.optimizer.step_part(part)
             net.side_wait()                      # final join of the weight-gradient stream into the compute stream

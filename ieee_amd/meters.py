@@ -74,6 +74,19 @@ class DeferredSummary(dict):
 
     __hash__ = None
 
+    # pickling / copy.deepcopy: the resolver is a closure over device state; what travels is the settled plain dict
+    def __reduce__(self):
+        self.resolve()
+        return (dict, (dict(super(DeferredSummary, self).items()),))
+
+    def __deepcopy__(self, memo):
+        import copy
+        self.resolve()
+        return copy.deepcopy(dict(super(DeferredSummary, self).items()), memo)
+
+    def __copy__(self):
+        return self.copy()
+
     def __repr__(self):
         self.resolve()
         return super(DeferredSummary, self).__repr__()

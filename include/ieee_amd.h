@@ -337,8 +337,17 @@ int ieee_resize_flip_normalize(const uint8_t* src, float* dst, uint8_t* tmp, int
  *           feats [3][B][768] = F.normalize(fc_{R,N,T}_all); eval: feats = fc_all [B][2304] (T,R,N).
  * backward: dlogits / dfeats in the same layouts; every parameter gradient is OVERWRITTEN in `grads`
  *           (REM.conv_query gets exact zeros, REM.conv_value and unused branches are not touched).
- * All work is enqueued on `stream`; the workspace (ieee_net_workspace_bytes) keeps the activations
- * between forward and backward. */
+ * Streams: the dependent chain of a call (forward; dgrad / BatchNorm backward) is enqueued on the caller's `stream`.
+ * The executor also owns two internal non-blocking streams per handle, created on first use: a low-priority SIDE
+ * stream (every weight-gradient kernel + its slab reduction, and the packing of the layer3 / layer4 / CIM operands
+ * during a training forward) and a BRANCH stream (the downsample branch of the first block of each stage).  They
+ * are ordered against `stream` with events in both directions, and they are JOINED into `stream` before
+ * ieee_net_forward, ieee_net_backward and ieee_net_backward_part return -- after those calls, synchronising (or
+ * enqueuing behind) `stream` covers everything the call launched.  The one exception is
+ * ieee_net_backward_part_async: weight gradients of the part may still run on the side stream when it returns; join
+ * them with ieee_net_side_wait or ieee_net_sync_streams before reading gradients, destroying `stream` or the
+ * workspace, or stepping the optimizer.  No call synchronises the host (ieee_net_profile(.., 0, ..) aside).
+ * The workspace (ieee_net_workspace_bytes) keeps the activations between forward and backward. */
 int ieee_net_create(int64_t batch, int64_t height, int64_t width, int64_t num_classes, int dtype,
                     int interaction, int attention, int using_rem, void** handle);
 int ieee_net_destroy(void* handle);
@@ -363,6 +372,12 @@ int ieee_net_backward_part(void* handle, void* workspace, const float* dlogits, 
 int ieee_net_backward_part_async(void* handle, void* workspace, const float* dlogits, const float* dfeats, int part,
                                  void* stream);
 int ieee_net_side_wait(void* handle, void* workspace, void* waiting_stream, int is_launch_stream);
+/* Make `stream` wait for everything the executor has enqueued on its internal streams so far (side + branch), without
+ * knowing about them: after this, hipStreamSynchronize(stream) -- or any work enqueued on `stream` -- is ordered
+ * behind every kernel of the preceding ieee_net_* calls.  A C caller that uses the _async parts calls this (on the
+ * launch stream) where the Python engine calls ieee_net_side_wait(launch_stream, 1); it is a no-op when nothing is
+ * pending.  Does not block the host. */
+int ieee_net_sync_streams(void* handle, void* stream);
 /* Inference cache: after an eval-mode ieee_net_forward the workspace holds the packed weights and every BatchNorm's
  * scale / shift; the next eval forward on the same workspace reuses them (no packing launch, no finalize launches)
  * unless ieee_net_eval_cache(handle, 0) was called in between.  The CALLER must call it whenever parameters or

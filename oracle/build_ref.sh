@@ -1,7 +1,8 @@
 #!/bin/bash
 # Builds the reference's own native CMC/mAP evaluator (Cython) from the source
-# where it lies under /root/reference, into oracle/_ref/ (git-ignored; travels
-# to the GPU box via gpurun like any built .so).  Only runs where
+# where it lies under /root/reference, into oracle/_ref/ (git-ignored AND
+# gpurun-ignored: a reference-derived binary stays in this container; only the
+# CPU test tests/test_evaluator_oracle.py loads it).  Only runs where
 # /root/reference exists (this container).  The reference's pre-generated
 # rank_cy.c (Cython 0.29.33) does not compile against numpy 2.x
 # ("PyArray_Descr has no member named subarray"), so the .pyx is re-cythonized

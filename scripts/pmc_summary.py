@@ -58,6 +58,22 @@ def main():
                     for k in keys:
                         sums[k][c] += float(row["Counter_Value"])
                         counts[k][c] += 1
+    step_launches = 0
+    step_fetch = step_write = 0.0
+    fam_bytes = collections.defaultdict(float)
+    for d in dirs:
+        for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            with open(path, newline="") as f:
+                for row in csv.DictReader(f):
+                    c = row["Counter_Name"]
+                    if c == "FETCH_SIZE":
+                        step_fetch += float(row["Counter_Value"])
+                        fam_bytes[family(row["Kernel_Name"])] += 2.0 * float(row["Counter_Value"]) * 1024.0
+                        if "margin3m_kernel" in row["Kernel_Name"]:
+                            step_launches += 1        # one per train step
+                    elif c == "WRITE_SIZE":
+                        step_write += float(row["Counter_Value"])
+                        fam_bytes[family(row["Kernel_Name"])] += float(row["Counter_Value"]) * 1024.0
     res = {"_note": __doc__.split("\n\n")[1].replace("\n", " ") if False else
            "rocprofv3 --pmc passes (one counter group per pass) summarised by scripts/pmc_summary.py; per-launch means"}
     for fam in sorted(sums):
@@ -77,10 +93,15 @@ def main():
         if "SQ_LDS_BANK_CONFLICT" in m and m.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
             e["lds_conflict_share"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
         res[fam] = e
+    if step_launches:
+        # whole train step: every kernel's 2 * FETCH_SIZE + WRITE_SIZE, divided by the steps seen (one margin3m launch each)
+        res["_step"] = {"train_steps": step_launches,
+                        "hbm_bytes_per_step": (2.0 * step_fetch + step_write) * 1024.0 / step_launches,
+                        "by_family": {k: v / step_launches for k, v in sorted(fam_bytes.items())}}
     if len(sys.argv) > 1:
         with open(out_path, "w") as f:
             json.dump(res, f, indent=1, sort_keys=True)
-    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_launch"} for k, v in res.items() if k != "_note"}, indent=1))
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_launch"} for k, v in res.items() if not k.startswith("_")}, indent=1))
 
 
 if __name__ == "__main__":

@@ -128,3 +128,139 @@ def test_rgbnt201_parser_and_decode_loader(tmp_path):
     first = batches[0]
     want = np.asarray(Image.open(first['impath'][0][1]).convert('RGB'))
     assert np.array_equal(first['img'][1][0].numpy(), want)
+
+
+# ---- shard-aware sampler / loader
+def test_sharded_sampler_slices_the_single_process_batches():
+    data = _source(n_pid=17)
+    for world, B, K in ((2, 16, 4), (3, 32, 4), (4, 16, 4)):       # (3, 32): 8 identities = shards of 12, 12, 8 rows
+        random.seed(5); np.random.seed(5)
+        order = list(iter(smp.RandomIdentitySampler(data, B, K)))
+        nb = len(order) // B
+        parts = []
+        for r in range(world):
+            s = smp.build_train_sampler(data, 'RandomIdentitySampler', batch_size=B, num_instances=K, rank=r, world=world)
+            assert isinstance(s, smp.ShardedIdentitySampler) and s.global_batch == B
+            random.seed(5); np.random.seed(5)
+            mine = list(iter(s))
+            assert len(mine) == nb * s.local_batch == len(s) and s.local_batch % K == 0
+            parts.append((s, mine))
+        assert sum(s.local_batch for s, _ in parts) == B
+        for g in range(nb):                                         # rank shards, in rank order, ARE the global batch
+            got = []
+            for s, mine in parts:
+                got += mine[g * s.local_batch:(g + 1) * s.local_batch]
+            assert got == order[g * B:(g + 1) * B]
+    with pytest.raises(ValueError):
+        smp.build_train_sampler(data, 'RandomSampler', rank=0, world=2)
+    with pytest.raises(ValueError):
+        smp.ShardedIdentitySampler(smp.RandomIdentitySampler(data, 8, 4), 2, 3)      # 2 identities cannot feed 3 ranks
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/torchreid"), reason="reference tree not present")
+def test_sharded_sampler_is_a_slice_of_the_reference_sequence():
+    from oracle.ref_import import import_reference
+    import_reference()
+    from torchreid.data.sampler import RandomIdentitySampler as RefSampler
+    data = _source(n_pid=17)
+    random.seed(3); np.random.seed(3)
+    want = list(iter(RefSampler(data, 16, 4)))
+    for r in range(2):
+        s = smp.ShardedIdentitySampler(smp.RandomIdentitySampler(data, 16, 4), r, 2)
+        random.seed(3); np.random.seed(3)
+        mine = list(iter(s))
+        for g in range(len(want) // 16):
+            assert mine[g * 8:(g + 1) * 8] == want[g * 16 + 8 * r:g * 16 + 8 * r + 8]
+
+
+class _CountingStub(object):
+    """stand-in device transform: counts the images it is handed (= decoded and transformed rows)"""
+
+    def __init__(self):
+        self.rows = 0
+
+    def draw_flips(self, n):
+        return np.zeros(n, dtype=np.uint8)
+
+    def __call__(self, images, flips=None):
+        self.rows += len(images)
+        return torch.stack([torch.from_numpy(np.asarray(im).copy()).float().mean(dim=(0, 1)) for im in images])
+
+
+def _shard_worker(rank, world, port, root, ret):
+    import torch.distributed as dist
+    from ieee_amd import dist as ddp
+    from ieee_amd.data.loader import DeviceLoader
+    from oracle import model as om
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    ddp.init_from_env(backend="gloo")
+    ds = datasets.RGBNT201(root=root)
+    B, K, C = 8, 2, ds.num_train_pids
+    # --- training loader: this rank's identity-aligned shard of every global batch, and ONLY that is decoded
+    random.seed(100 + rank); np.random.seed(100 + rank)            # deliberately different seeds: rank 0's order is broadcast
+    samp = smp.build_train_sampler(ds.train, 'RandomIdentitySampler', batch_size=B, num_instances=K, rank=rank, world=world)
+    stub = _CountingStub()
+    loader = DeviceLoader(ds.train, stub, samp.local_batch, sampler=samp, workers=0, drop_last=True, global_rows=samp.global_batch)
+    decoded = []
+    real_read = datasets.read_image
+    datasets.read_image = lambda p: (decoded.append(p), real_read(p))[1]
+    batches = list(loader)
+    datasets.read_image = real_read
+    assert len(batches) >= 1 and all(b['global_rows'] == B and len(b['pid']) == B // world for b in batches)
+    assert len(decoded) == 3 * (B // world) * len(batches) and stub.rows == len(decoded)      # B/world triples per step
+    # the summed rank gradients of a small model equal the gradient of the reference's loss on the global batch
+    torch.manual_seed(0)
+    W = torch.randn(9, C, requires_grad=True)
+    Wf = torch.randn(9, 6, requires_grad=True)
+
+    def loss_of(batch, scale):
+        x = torch.cat(batch['img'], dim=1)                          # [rows, 9]: three modalities x RGB means
+        f = torch.nn.functional.normalize(x @ Wf, dim=1)
+        return scale * om.cross_entropy_ls(x @ W / 50.0, batch['pid'], C) + om.margin3m(f[:, 0:2], f[:, 2:4], f[:, 4:6], batch['pid'], 1.0)
+
+    from ieee_amd.engine import Engine
+
+    class _DM(object):
+        train_loader, test_loader, num_train_pids, sources = [], {}, C, []
+    eng = Engine(_DM(), use_gpu=False)
+    flat = torch.zeros(W.numel() + Wf.numel())
+    first = batches[0]
+    data, total = eng._local_batch(first)                          # stamped batch: no slicing, no collective
+    assert data is first and total == B
+    loss_of(first, ddp.ce_grad_scale(len(first['pid']), total)).backward()
+    flat[:W.numel()] = W.grad.flatten(); flat[W.numel():] = Wf.grad.flatten()
+    ddp.allreduce_sum_(flat)
+    # serial reference: all ranks' rows of global batch 0 (gathered), one process
+    rows = [None] * world
+    dist.all_gather_object(rows, {'img': first['img'], 'pid': first['pid']})
+    whole = {'img': [torch.cat([r['img'][m] for r in rows]) for m in range(3)], 'pid': torch.cat([r['pid'] for r in rows])}
+    assert all(len(set(whole['pid'][k:k + K].tolist())) == 1 for k in range(0, B, K))          # identity-contiguous
+    W.grad = None; Wf.grad = None
+    loss_of(whole, 1.0).backward()
+    torch.testing.assert_close(flat[:W.numel()].view_as(W), W.grad, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(flat[W.numel():].view_as(Wf), Wf.grad, rtol=1e-5, atol=1e-7)
+    # --- evaluation loader: every world-th batch is decoded, the labels of ALL batches come from the records
+    stub2 = _CountingStub()
+    q = DeviceLoader(ds.query, stub2, 3, workers=0, rank=rank, world=world)
+    labels = q.batch_labels()
+    seen = [int(b['batch_index']) for b in q]
+    assert seen == list(range(rank, len(labels), world)) and q.sharded
+    assert stub2.rows == 3 * sum(len(labels[b][0]) for b in seen)
+    assert sum(len(p) for p, _ in labels) == len(ds.query)
+    dist.destroy_process_group()
+    ret[rank] = (len(decoded), seen)
+
+
+def test_two_ranks_decode_half_the_rows_and_sum_to_the_serial_gradient(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    names = ["%06d_cam%d_0_%02d.jpg" % (pid, 1 + (j % 4), j) for pid in (3, 8, 11, 20, 21, 30) for j in range(3)]
+    _make_tree(str(tmp_path), names, size=(20, 12))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_shard_worker, args=(2, port, str(tmp_path), ret), nprocs=2, join=True)
+        out = dict(ret)
+        assert len(out) == 2 and out[0][0] == out[1][0]            # both ranks decoded the same (halved) number of files
+        assert sorted(out[0][1] + out[1][1]) == list(range(len(out[0][1]) + len(out[1][1])))

@@ -124,6 +124,24 @@ def _sync_worker(rank, world, port, ret):
     assert torch.equal(m._flat_params, own_params) and m.invalidated == 1
     ddp.sync_replicas(m, opt)                              # first train step: everything, optimizer state included
     assert torch.equal(m._flat_params, ref._flat_params) and torch.equal(opt.buf, torch.zeros(1000))
+    # any other nn.Module with a torch.optim optimizer (the generic autograd path): parameters, buffers and the
+    # optimizer's state tensors are broadcast one by one
+    torch.manual_seed(50 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    sgd = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+    net(torch.randn(5, 4)).sum().backward()
+    sgd.step()                                             # momentum buffers exist now, different on every rank
+    ddp.sync_replicas(net, sgd)
+    mine = [t.clone() for t in net.state_dict().values()] + [sgd.state[p]["momentum_buffer"].clone() for p in net.parameters()]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    for other in everyone:
+        assert all(torch.equal(a, b) for a, b in zip(other, everyone[0]))
+    # the global batch size is asked with a collective that every rank enters on every call (no rank-local cache):
+    # rank 0 repeats its size while the other ranks change theirs
+    for step in range(3):
+        local = 8 if rank == 0 else 4 + step
+        assert ddp.global_rows(local) == 8 + (world - 1) * (4 + step)
     # sharded feature extraction: 5 loader batches of uneven size, rank r holds batches r, r + world, ...
     rows = [4, 4, 3, 4, 1]
     full = torch.arange(sum(rows) * 6, dtype=torch.float32).view(-1, 6)
