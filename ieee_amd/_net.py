@@ -92,6 +92,20 @@ class NativeNet:
             _lib.check(self.lib.ieee_net_side_wait(self.handle, _lib.ptr(self.workspace),
                                                    ctypes.c_void_p(stream.cuda_stream), 0))
 
+    def debug_taps(self, nbytes):
+        """parity tests: allocate a tap buffer of nbytes and make the backward copy its gradient tensors into it
+        (include/ieee_amd.h: ieee_net_debug_taps); nbytes = 0 switches the taps off"""
+        self._taps = torch.empty(nbytes, dtype=torch.uint8, device=self.workspace.device) if nbytes else None
+        _lib.check(self.lib.ieee_net_debug_taps(self.handle, _lib.ptr(self._taps) if nbytes else None, nbytes))
+
+    def tap(self, name):
+        off, numel, dt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        _lib.check(self.lib.ieee_net_debug_tap(self.handle, name.encode(), ctypes.byref(off), ctypes.byref(numel),
+                                               ctypes.byref(dt)))
+        tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.uint8}[dt.value]
+        nbytes = numel.value * torch.empty((), dtype=tdt).element_size()
+        return self._taps[off.value:off.value + nbytes].view(tdt)
+
     def tensor(self, name):
         """a named intermediate as a torch view of the workspace (parity tests / debugging)"""
         off, numel, dt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()

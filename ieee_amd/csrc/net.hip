@@ -116,6 +116,12 @@ struct Net {
       logits, featn, norms;
   Tensor dfeatcat, dfcraw, dpart2, dr, dglob, dZp, dZg, dPp, dGp, datt, dHs, dH, davgmax, remwork;
   int esz() const { return dtype == IEEE_BF16 ? 2 : 4; }
+  // parity tests (ieee_net_debug_taps): while a tap buffer is set, the backward copies every gradient tensor it
+  // produces (dY of each conv unit = the output of its BatchNorm backward; the tensor each dgrad wrote) into it, in
+  // launch order, before the buffer holding it is reused
+  char* tap_base = nullptr;
+  size_t tap_bytes = 0, tap_used = 0;
+  std::map<std::string, Tensor> taps;
   // optional per-launch timing of the conv kernels (bench.py's roofline leg): category 0 = forward +
   // dgrad (conv_gather_kernel), 1 = wgrad (conv_wgrad_kernel)
   bool profiling = false;
@@ -379,6 +385,21 @@ struct Run {
     (void)hipEventRecord(n.ev_pool[n.ev_used + 1], (hipStream_t)st);
     n.ev_used += 2;
   }
+  int tap(const std::string& name, const void* p, int64_t numel, int dt = -1) {
+    if (n.tap_base == nullptr) return IEEE_OK;
+    if (dt < 0) dt = n.dtype;
+    const size_t bytes = (size_t)numel * (dt == IEEE_BF16 ? 2 : (dt == 2 ? 1 : 4));
+    IEEE_REQUIRE(n.tap_used + bytes <= n.tap_bytes, "net: tap buffer too small at '%s' (%zu + %zu > %zu bytes)", name.c_str(),
+                 n.tap_used, bytes, n.tap_bytes);
+    Tensor t;
+    t.off = n.tap_used; t.numel = numel; t.dtype = dt;
+    IEEE_HIP(hipMemcpyAsync(n.tap_base + t.off, p, bytes, hipMemcpyDeviceToDevice, (hipStream_t)st));
+    n.taps[name] = t;
+    n.tap_used += (bytes + 255) / 256 * 256;
+    return IEEE_OK;
+  }
+  int64_t in_numel(const ConvUnit& u) const { return (int64_t)3 * B * u.Hi * u.Wi * u.Ci; }
+  int64_t out_numel(const ConvUnit& u) const { return (int64_t)3 * u.M(B) * u.Co; }
   // fused_stats: the conv epilogue emits the BN partial sums (bf16 training path) -> bn() skips its stats pass
   bool fused_stats = false;
   int conv(const ConvUnit& u, const void* in, bool want_stats = false) {
@@ -816,11 +837,16 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     // out = relu(bn3(y3) + identity): g = dout*[out>0] is the identity-branch gradient, dy3 the conv3 one.
     // bf16, every block but the last: the dgrad that produced X stored it already masked (X = g, conv.hip MODE 2 with
     // the mask tensor), so the BatchNorm backward reads g and y3 only and writes dy3 into Q; the two names then swap.
+    if (N.tap_base && bi + 1 == (int)N.blocks.size()) IEEE_TRY(tap(c3.name + ".dout", X, out_numel(c3)));
     if (dt == IEEE_BF16 && bi + 1 < (int)N.blocks.size()) {
       IEEE_TRY(bn_bwd(c3, X, nullptr, Q, nullptr));
       std::swap(X, Q);
     } else {
       IEEE_TRY(bn_bwd(c3, X, P(c3.a), X, Q));   // g -> Q ; dy3 -> X (in place)
+    }
+    if (N.tap_base) {   // g = dout * [out > 0] (what both BatchNorm backwards of the block read) and dy3
+      IEEE_TRY(tap(c3.name + ".g", Q, out_numel(c3)));
+      IEEE_TRY(tap(c3.name + ".dy", X, out_numel(c3)));
     }
     const int bslot = 4 + (bi == 0 ? 0 : (bi == 3 ? 1 : (bi == 7 ? 2 : 3)));
     const bool par_ds = b.ds >= 0 && branch_enabled(2);
@@ -828,15 +854,21 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
       const ConvUnit& d = N.units[b.ds];
       BranchScope scope(*this, bslot);
       IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
+      IEEE_TRY(tap(d.name + ".dy", Q, out_numel(d)));
       IEEE_TRY(wgrad(d, Q, xin));
       IEEE_TRY(dgrad(d, Q, V, nullptr));
+      IEEE_TRY(tap(d.name + ".dx", V, in_numel(d)));
     }
     IEEE_TRY(wgrad(c3, X, P(c2.a)));
     IEEE_TRY(dgrad(c3, X, Rb, nullptr, &c2));
+    IEEE_TRY(tap(c3.name + ".dx", Rb, in_numel(c3)));
     IEEE_TRY(bn_bwd(c2, Rb, nullptr, Rb, nullptr, 1));   // relu mask recomputed from y2 (no residual)
+    IEEE_TRY(tap(c2.name + ".dy", Rb, out_numel(c2)));
     IEEE_TRY(wgrad(c2, Rb, P(c1.a)));
     IEEE_TRY(dgrad(c2, Rb, U, nullptr, &c1));
+    IEEE_TRY(tap(c2.name + ".dx", U, in_numel(c2)));
     IEEE_TRY(bn_bwd(c1, U, nullptr, U, nullptr, 1));
+    IEEE_TRY(tap(c1.name + ".dy", U, out_numel(c1)));
     IEEE_TRY(wgrad(c1, U, xin));
     const void* addend = Q;
     const ConvUnit* pc3 = bi > 0 ? &N.units[N.blocks[bi - 1].c3] : nullptr;
@@ -848,9 +880,12 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
         branch_join(bslot);
       } else {
         IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
+        IEEE_TRY(tap(d.name + ".dy", Q, out_numel(d)));
         IEEE_TRY(wgrad(d, Q, xin));
         if (compact) IEEE_TRY(dgrad_compact(d, Q, V));
         else IEEE_TRY(dgrad(d, Q, V, nullptr));
+        // (compact: [3][B][Ho][Wo][Ci], the pixels with even row and column of the input map)
+        IEEE_TRY(tap(d.name + (compact ? ".dx_compact" : ".dx"), V, compact ? (int64_t)3 * d.M(B) * d.Ci : in_numel(d)));
       }
       addend = V;
       if (compact) addend_stride = 2;
@@ -858,6 +893,7 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     // d(block input) = dgrad(conv1) + identity-branch gradient; it is d(out) of the previous block, whose bn3
     // backward sums (mask = that block's stored output) are emitted here too
     IEEE_TRY(dgrad(c1, U, Xout, addend, pc3, true, addend_stride));
+    IEEE_TRY(tap(c1.name + ".dx", Xout, in_numel(c1)));
   }
   if (lo > 0) return IEEE_OK;
   X = P(N.gbuf[set_of(-1)]);      // d(out) of the stem's max-pool, left by block 0
@@ -876,6 +912,7 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     IEEE_TRY(ieee_maxpool3x3s2_bwd(X, (const uint8_t*)P(N.pool_arg), Q, dt, 3, B, s.Ho, s.Wo, s.Co, st));
     IEEE_TRY(bn_bwd(s, Q, nullptr, Q, nullptr, 1));
   }
+  IEEE_TRY(tap(s.name + ".dy", Q, out_numel(s)));
   IEEE_TRY(wgrad(s, Q, P(N.x0)));
   return IEEE_OK;
 }
@@ -999,12 +1036,15 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
     IEEE_TRY(ieee_cim_tail_bwd_g(F(N.dPp), P(uo.y), P(ur.y), F(uo.stats), F(ur.stats), F(N.att), F(N.davgmax),
                                  F(N.davgmax) + BC, 2 * BC, (const int32_t*)P(N.amax), g1, g2, dt, B, Hh_, Ww, C, N.parts,
                                  mode, F(N.bnpart), F(N.bnpart) + 6 * BC, st));
+    if (N.tap_base) { IEEE_TRY(tap(uo.name + ".g", g1, out_numel(uo))); IEEE_TRY(tap(ur.name + ".g", g2, out_numel(ur))); }
     IEEE_TRY(bn_bwd(uo, g1, nullptr, g1, nullptr, 0, F(N.bnpart), B));
     IEEE_TRY(bn_bwd(ur, g2, nullptr, g2, nullptr, 0, F(N.bnpart) + 6 * BC, B));
+    if (N.tap_base) { IEEE_TRY(tap(uo.name + ".dy", g1, out_numel(uo))); IEEE_TRY(tap(ur.name + ".dy", g2, out_numel(ur))); }
     IEEE_TRY(wgrad(uo, g1, Fm));
     IEEE_TRY(wgrad(ur, g2, P(N.S)));
     IEEE_TRY(dgrad(uo, g1, P(N.gbuf[3]), nullptr));
     IEEE_TRY(dgrad(ur, g2, P(N.gbuf[4]), nullptr));
+    if (N.tap_base) { IEEE_TRY(tap(uo.name + ".dx", P(N.gbuf[3]), in_numel(uo))); IEEE_TRY(tap(ur.name + ".dx", P(N.gbuf[4]), in_numel(ur))); }
     IEEE_TRY(ieee_cim_bwd_combine(P(N.gbuf[3]), P(N.gbuf[4]), F(N.dGp), dF, dt, B, Hh_, Ww, C, mode, st));
   } else {
     IEEE_TRY(ieee_cim_tail_bwd_g(F(N.dPp), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
@@ -1244,6 +1284,27 @@ extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {
     }
   }
   for (int c = 0; c < 2; ++c) { out6[c * 3 + 0] = ms[c]; out6[c * 3 + 1] = n->prof_flops[c]; out6[c * 3 + 2] = (double)n->prof_launches[c]; }
+  return IEEE_OK;
+}
+
+extern "C" int ieee_net_debug_taps(void* handle, void* buffer, int64_t bytes) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && (buffer == nullptr || bytes > 0), "net_debug_taps: bad arguments");
+  n->tap_base = (char*)buffer;
+  n->tap_bytes = buffer ? (size_t)bytes : 0;
+  n->tap_used = 0;
+  n->taps.clear();
+  return IEEE_OK;
+}
+
+extern "C" int ieee_net_debug_tap(void* handle, const char* name, int64_t* byte_offset, int64_t* numel, int* dtype) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && name && byte_offset && numel && dtype, "net_debug_tap: null pointer");
+  auto it = n->taps.find(name);
+  IEEE_REQUIRE(it != n->taps.end(), "net_debug_tap: no tap named '%s' (set a buffer and run the backward first)", name);
+  *byte_offset = (int64_t)it->second.off;
+  *numel = it->second.numel;
+  *dtype = it->second.dtype;
   return IEEE_OK;
 }
 

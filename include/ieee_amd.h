@@ -390,6 +390,16 @@ int ieee_net_eval_cache(void* handle, int keep);
 int ieee_net_profile(void* handle, int enable, double* out6);
 /* debugging / parity tests: location of a named intermediate inside the workspace */
 int ieee_net_tensor(void* handle, const char* name, int64_t* byte_offset, int64_t* numel, int* dtype);
+/* parity tests of the backward (what autograd keeps implicit in the reference, ieee3modalPart.py:439-523 under
+ * loss.backward()): while `buffer` (device memory, `bytes` long) is set, ieee_net_backward* copies every gradient
+ * tensor it produces into it before the buffer that held it is reused -- "<unit>.dy" (gradient of the conv output =
+ * output of that unit's BatchNorm backward), "<unit>.dx" (what the unit's dgrad wrote: for a block's conv1 the masked
+ * block-input gradient, residual branch added), "<unit>.g" for block-output units (dout * [out > 0]); a stride-2
+ * downsample branch that returns its gradient compact taps "<unit>.dx_compact".  <unit> = the conv's state_dict
+ * prefix, modality as {m}: "backbone.{m}.layer1.0.conv1".  buffer = NULL switches the taps off.
+ * ieee_net_debug_tap: byte offset of a tap inside the buffer (after the backward that wrote it). */
+int ieee_net_debug_taps(void* handle, void* buffer, int64_t bytes);
+int ieee_net_debug_tap(void* handle, const char* name, int64_t* byte_offset, int64_t* numel, int* dtype);
 
 #ifdef __cplusplus
 }

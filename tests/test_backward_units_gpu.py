@@ -1,0 +1,239 @@
+"""GPU: the BACKWARD of the timed configuration (BASELINE config 2: B = 64 triples, 256x128, bf16) under a numerical
+check, unit by unit (reference: autograd under `loss.backward()` in engine/image/margin.py:141, over
+models/resnet.py:164-184 and ieee3modalPart.py:427-435).
+
+One real Image3MEngine step runs with the executor's gradient taps on (include/ieee_amd.h: ieee_net_debug_taps): every
+gradient tensor the backward produces is copied out before its buffer is reused.  Then, for EVERY conv + BatchNorm unit of
+the three ResNet-50 streams and the CIM, the unit's saved operands are pulled from the workspace and what the native
+backward made of them -- dW (flat gradient buffer), dX (the tensor its dgrad stored: masked / with the residual or the
+compact stride-2 branch gradient added, exactly the fused epilogue form the step runs), the BatchNorm backward's dY,
+d(gamma), d(beta) (which rest on the Sigma g, Sigma g*y sums the dgrad epilogues emit at this batch's row-tile counts) --
+is compared with torch fp32 autograd / the BatchNorm-backward formula ON THOSE OPERANDS.  bf16 operands are exact in
+fp32, so what remains is the summation order and one bf16 rounding of each stored output: a wrong row-block index, slab
+split or XCD tile map in a B = 64-only path shows up as an O(1) error in one unit."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util_model import C, generated_state
+
+pytestmark = pytest.mark.gpu
+B, H, W = 64, 256, 128
+EPS_BF16 = 2e-7       # step of the descent test (see test_b64_bf16_descent_along_the_native_gradient)
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+class _DM(object):
+    num_train_pids = C
+    train_loader, test_loader, sources = [], {}, ["synthetic"]
+
+
+def _step_with_taps(seed=3):
+    from ieee_amd.engine import Image3MEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, use_gpu=True, compute_dtype=torch.bfloat16)
+    m.load_state_dict(generated_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed))
+    m.train()
+    # lr = 0, no decay, no momentum: the step leaves the parameters (and so the packed bf16 operands) as the forward saw them
+    eng = Image3MEngine(_DM(), m, build_optimizer(m, optim="sgd", lr=0.0, weight_decay=0.0, momentum=0.0), margin=1, use_gpu=True)
+    net = m.native_net(B, H, W)
+    net.debug_taps(9 << 30)
+    g = torch.Generator().manual_seed(seed)
+    imgs = [torch.randn(B, 3, H, W, generator=g) for _ in range(3)]
+    pids = torch.arange(B) // 4
+    s = eng.forward_backward({"img": imgs, "pid": pids, "camid": pids * 0, "impath": "", "timeid": pids * 0})
+    torch.cuda.synchronize()
+    assert np.isfinite(float(s["loss"]))
+    return m, net
+
+
+def _units():
+    """(name pattern, kind, stride, pad, input tensor name or None for the block input) of every conv unit, with the
+    block structure needed to find each unit's operands"""
+    blocks = []
+    nblk, strides = (3, 4, 6, 3), (1, 2, 2, 1)
+    prev_out = "pool"
+    for L in range(4):
+        for b in range(nblk[L]):
+            p = "backbone.{m}.layer%d.%d." % (L + 1, b)
+            blocks.append(dict(p=p, xin=prev_out, stride=strides[L] if b == 0 else 1, ds=(b == 0), last=(L == 3 and b == nblk[L] - 1)))
+            prev_out = p + "conv3.a"
+    return blocks
+
+
+def _grad_of(m, name):
+    p = dict(m.named_parameters())[name]
+    off = m._offsets[name]
+    return m._flat_grads[off:off + p.numel()].view(p.shape)
+
+
+def _bn_backward_ref(g, y, stats, gamma):
+    """g, y: [M, C]; stats: [4, C] (mean, invstd, scale, shift) -> (dy, dgamma, dbeta), float64 sums"""
+    M = g.shape[0]
+    mean, invstd = stats[0].double(), stats[1].double()
+    gd, yhat = g.double(), (y.double() - mean) * invstd
+    dbeta, dgamma = gd.sum(0), (gd * yhat).sum(0)
+    dy = gamma.double() * invstd * (gd - dbeta / M - yhat * dgamma / M)
+    return dy, dgamma, dbeta
+
+
+def _check_unit(m, net, mod, unit, x_in, stride, pad, g_bn, errs, dx_expect=None, dx_name=".dx", stem=False):
+    """x_in: NHWC input activation of the conv (one modality); g_bn: gradient w.r.t. the BatchNorm OUTPUT, ReLU mask
+    applied ([M, Co]); dx_expect(raw_dgrad NHWC fp32) -> the tensor the native dgrad is expected to have stored"""
+    real = unit.replace("{m}", str(mod))
+    bn = real.replace("conv", "bn") if "downsample" not in real and "layers" not in real else None
+    if "downsample.0" in real:
+        bn = real.replace("downsample.0", "downsample.1")
+    if real.endswith("layers.0"):
+        bn = real[:-1] + "1"
+    w = dict(m.named_parameters())[real + ".weight"].detach()
+    gamma = dict(m.named_parameters())[bn + ".weight"].detach()
+    Co = w.shape[0]
+    y = net.tensor(unit + ".y").view(3, -1, Co)[mod].float()
+    stats = net.tensor(unit + ".stats").view(3, 4, Co)[mod]
+    dy_nat = net.tap(unit + ".dy").view(3, -1, Co)[mod].float()
+    # ---- BatchNorm backward on (g, y, saved statistics)
+    dy_ref, dgamma, dbeta = _bn_backward_ref(g_bn, y, stats, gamma)
+    errs.append((real, "bn.dy", _rel(dy_nat, dy_ref), 4e-3))
+    scale_g = float(dgamma.abs().max()) + 1e-6
+    errs.append((real, "bn.dgamma", float((_grad_of(m, bn + ".weight").double() - dgamma).abs().max()) / scale_g, 2e-3))
+    scale_b = float(dbeta.abs().max()) + 1e-6
+    errs.append((real, "bn.dbeta", float((_grad_of(m, bn + ".bias").double() - dbeta).abs().max()) / scale_b, 2e-3))
+    # ---- convolution backward on (x, W rounded to bf16, the native dY)
+    xi = x_in.float().permute(0, 3, 1, 2).contiguous().requires_grad_(not stem)
+    wi = w.to(torch.bfloat16).float().requires_grad_(True)
+    out = F.conv2d(xi, wi, None, stride, pad)
+    out.backward(dy_nat.view(out.shape[0], out.shape[2], out.shape[3], Co).permute(0, 3, 1, 2))
+    errs.append((real, "wgrad", _rel(_grad_of(m, real + ".weight"), wi.grad), 5e-4))
+    if dx_expect is not None:
+        want = dx_expect(xi.grad.permute(0, 2, 3, 1))
+        got = net.tap(unit + dx_name)
+        got = got.view(3, *want.shape)[mod].float()
+        errs.append((real, "dgrad" + dx_name, _rel(got, want), 4e-3))
+
+
+def test_every_conv_bn_unit_of_the_b64_bf16_backward_matches_autograd_on_its_operands():
+    m, net = _step_with_taps()
+    errs = []
+    blocks = _units()
+    for mod in range(3):
+        for bi, blk in enumerate(blocks):
+            p, s = blk["p"], blk["stride"]
+
+            def nhwc(name, Cc):
+                t = net.tensor(name).view(3, B, -1, Cc)[mod]
+                hw = t.shape[1]
+                hh = int(round((hw * 2) ** 0.5))
+                return t.view(B, hh, hh // 2, Cc)
+            c1w = dict(m.named_parameters())[(p + "conv1.weight").replace("{m}", str(mod))]
+            planes, inpl = c1w.shape[0], c1w.shape[1]
+            xin = nhwc(blk["xin"] if blk["xin"] != "pool" else "pool", inpl)
+            a1, a2 = nhwc(p + "conv1.a", planes), nhwc(p + "conv2.a", planes)
+            g3 = net.tap(p + "conv3.g").view(3, -1, planes * 4)[mod].float()
+            if blk["last"]:        # the last block's mask is applied by its BatchNorm backward: g = dout * [out > 0]
+                dout = net.tap(p + "conv3.dout").view(3, -1, planes * 4)[mod].float()
+                out = net.tensor(p + "conv3.a").view(3, -1, planes * 4)[mod].float()
+                errs.append((p.replace("{m}", str(mod)) + "conv3", "mask.g", _rel(g3, dout * (out > 0)), 1e-6))
+            # conv3 (1x1): stores the raw dgrad; conv2's BatchNorm sums come from its epilogue
+            _check_unit(m, net, mod, p + "conv3", a2, 1, 0, g3, errs, dx_expect=lambda d: d)
+            dx3 = net.tap(p + "conv3.dx").view(3, -1, planes)[mod].float()
+            g2 = dx3 * (a2.reshape(-1, planes).float() > 0)
+            _check_unit(m, net, mod, p + "conv2", a1, s, 1, g2, errs, dx_expect=lambda d: d)
+            dx2 = net.tap(p + "conv2.dx").view(3, -1, planes)[mod].float()
+            g1 = dx2 * (a1.reshape(-1, planes).float() > 0)
+            # conv1: block-input gradient = dgrad + identity-branch gradient, masked by the previous block's output
+            if blk["ds"]:
+                compact = s == 2
+                nm = p + "downsample.0"
+                if compact:
+                    dsx = net.tap(nm + ".dx_compact").view(3, B, xin.shape[1] // 2, xin.shape[2] // 2, inpl)[mod].float()
+                    addend = torch.zeros(xin.shape, dtype=torch.float32, device=xin.device)
+                    addend[:, ::2, ::2] = dsx
+                    _check_unit(m, net, mod, nm, xin, s, 0, g3, errs, dx_expect=lambda d: d[:, ::2, ::2], dx_name=".dx_compact")
+                else:
+                    addend = net.tap(nm + ".dx").view(3, *xin.shape)[mod].float()
+                    _check_unit(m, net, mod, nm, xin, s, 0, g3, errs, dx_expect=lambda d: d)
+            else:
+                addend = g3.view(xin.shape)
+            mask = (xin.float() > 0) if bi > 0 else torch.ones_like(xin, dtype=torch.bool)
+            _check_unit(m, net, mod, p + "conv1", xin, 1, 0, g1, errs,
+                        dx_expect=lambda d, addend=addend, mask=mask: ((d + addend).to(torch.bfloat16).float() * mask))
+        # ---- CIM: convOne (input = the trunk map) and convAvgRest (input = the sum of the two other modalities' maps)
+        Fm = net.tensor("backbone.{m}.layer4.2.conv3.a").view(3, B, 16, 8, 2048)[mod]
+        Ssum = net.tensor("S").view(3, B, 16, 8, 2048)[mod]
+        for unit, xin in (("convOne.{m}.layers.0", Fm), ("convAvgRest.{m}.layers.0", Ssum)):
+            g = net.tap(unit + ".g").view(3, -1, 2048)[mod].float()
+            _check_unit(m, net, mod, unit, xin, 1, 0, g, errs, dx_expect=lambda d: d)
+        # ---- stem: max-pool backward (the stored arg-max) -> ReLU -> BatchNorm backward -> weight gradient
+        dpool = net.tap("backbone.{m}.layer1.0.conv1.dx").view(3, B, 64, 32, 64)[mod].float()
+        arg = net.tensor("pool.arg").view(3, B, 64, 32, 64)[mod].long()
+        a0 = net.tensor("backbone.{m}.conv1.a").view(3, B, 128, 64, 64)[mod]
+        pp = torch.arange(64, device="cuda").view(1, 64, 1, 1)
+        qq = torch.arange(32, device="cuda").view(1, 1, 32, 1)
+        hh, ww = 2 * pp - 1 + arg // 3, 2 * qq - 1 + arg % 3
+        bb = torch.arange(B, device="cuda").view(B, 1, 1, 1)
+        cc = torch.arange(64, device="cuda").view(1, 1, 1, 64)
+        flat = ((bb * 128 + hh) * 64 + ww) * 64 + cc
+        dstem = torch.zeros(B * 128 * 64 * 64, dtype=torch.float32, device="cuda")
+        dstem.index_add_(0, flat.reshape(-1), dpool.reshape(-1))
+        g0 = dstem.view(-1, 64) * (a0.reshape(-1, 64).float() > 0)      # (the fused pooled form keeps the window sums in fp32)
+        x0 = net.tensor("x0").view(3, B, H + 6, W + 6, 4)[mod][:, 3:-3, 3:-3, :3]
+        _check_unit(m, net, mod, "backbone.{m}.conv1", x0, 2, 3, g0, errs, stem=True)
+    bad = [(n, k, e, bar) for n, k, e, bar in errs if not e <= bar]
+    worst = {}
+    for n, k, e, bar in errs:
+        worst[k] = max(worst.get(k, 0.0), e)
+    print("units checked: %d quantities; worst relative error per kind: %s" % (len(errs), {k: "%.2e" % v for k, v in worst.items()}))
+    assert not bad, "backward mismatch on %d / %d quantities, e.g. %s" % (len(bad), len(errs), sorted(bad, key=lambda t: -t[2])[:8])
+    assert len(errs) >= 3 * (16 * 3 + 4 + 2 + 1) * 4
+
+
+def test_b64_bf16_descent_along_the_native_gradient():
+    """Reference-free check of the whole bf16 backward at the timed shape: a plain SGD step of size eps along -g lowers
+    the (bf16-evaluated) loss by eps * |g|^2 to first order.  The bf16 forward is a rounded function of the weights, so its
+    value jitters when they move; eps is chosen so that the predicted decrease is >= 20x the jitter measured by moving
+    the same distance along a random direction (scripts/descent_scan_bf16.py holds the scan this bar comes from)."""
+    from ieee_amd.engine import Image3MEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    seed = 11
+    g = torch.Generator().manual_seed(9)
+    data = {"img": [torch.randn(B, 3, H, W, generator=g) for _ in range(3)], "pid": torch.arange(B) // 4,
+            "camid": torch.zeros(B), "impath": "", "timeid": torch.zeros(B)}
+    m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, compute_dtype=torch.bfloat16)
+    state = generated_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed)
+    m.load_state_dict(state)
+    m.train()
+    opt = build_optimizer(m, optim="sgd", lr=0.0, weight_decay=0.0, momentum=0.0)
+    eng = Image3MEngine(_DM(), m, opt, margin=1, use_gpu=True)
+    l0 = float(eng.forward_backward(data)["loss"])
+    grad = m._flat_grads.clone()
+    g2 = sum(float((grad[a:b].double() ** 2).sum()) for a, b in m.trainable_runs())
+    w0 = m._flat_params.clone()
+    eps = float(EPS_BF16)
+    # along -g
+    with torch.no_grad():
+        for a, b in m.trainable_runs():
+            m._flat_params[a:b] = w0[a:b] - eps * grad[a:b]
+    l_g = float(eng.forward_backward(data)["loss"])
+    # the same distance along a random direction: first-order change ~ eps * |g| * N(0, 1) / sqrt(n) ~ 0 -> what is
+    # left is the jitter of the bf16 forward
+    rnd = torch.randn(w0.shape, generator=torch.Generator(device="cuda").manual_seed(1), device="cuda")
+    rn2 = sum(float((rnd[a:b].double() ** 2).sum()) for a, b in m.trainable_runs())
+    with torch.no_grad():
+        m._flat_params.copy_(w0)
+        for a, b in m.trainable_runs():
+            m._flat_params[a:b] = w0[a:b] + eps * (g2 / rn2) ** 0.5 * rnd[a:b]
+    l_r = float(eng.forward_backward(data)["loss"])
+    pred = eps * g2
+    ratio = (l0 - l_g) / pred
+    print("bf16 B=64 descent: L0 %.5f, along -g %.5f (predicted decrease %.5f, ratio %.3f), random direction %.5f" % (l0, l_g, pred, ratio, l_r))
+    assert abs(l_r - l0) < pred / 5, (l0, l_r, pred)
+    assert 0.7 < ratio < 1.3, (l0, l_g, pred, ratio)
+

@@ -214,6 +214,51 @@ def test_engine_test_matches_reference_evaluate(G):
     np.testing.assert_allclose(dm, dist_o, rtol=2e-4, atol=5e-2)
 
 
+def test_engine_test_in_bf16_matches_reference_evaluate(G):
+    """The drop-in DEFAULT evaluation path -- compute_dtype = bf16: 53 BN-folded bf16 convs per stream, the CIM, the fp32
+    head, descriptors -> distmat -> ranking -- on the same tiny query / gallery loaders: mAP within 1e-3 of the reference's
+    own (fp32, CPU) run, the CMC curve within one query at every rank, and the descriptors no further from the fp32 oracle's
+    than stock torch bf16 autocast puts them (x 1.25), which is the bar every bf16 stage is held to (DESIGN.md "Parity")"""
+    import ieee_amd.engine as E
+    state = calibrated_state(shapes(171), 8)
+    m = build(171, "margin", state, dtype=torch.bfloat16)
+    L = eval_loaders()
+    eng = engine_for(m, "margin", FakeDM(171, test_loader={"synthetic": L}))
+    seen = {}
+    orig_rank, orig_dist = E.evaluate_rank, E.compute_distance_matrix
+
+    def spy_rank(distmat, *a, **k):
+        cmc, m_ap = orig_rank(distmat, *a, **k)
+        seen["cmc"], seen["mAP"] = np.asarray(cmc), m_ap
+        return cmc, m_ap
+
+    def spy_dist(qf, gf, *a, **k):
+        seen["qf"], seen["gf"] = qf.detach().float().cpu(), gf.detach().float().cpu()
+        return orig_dist(qf, gf, *a, **k)
+    E.evaluate_rank, E.compute_distance_matrix = spy_rank, spy_dist
+    try:
+        with redirect_stdout(io.StringIO()):
+            m_ap = eng.test()
+    finally:
+        E.evaluate_rank, E.compute_distance_matrix = orig_rank, orig_dist
+    nq = len(L["query"]) * 4
+    print("bf16 eval: mAP %.6f (reference %.6f), max CMC deviation %.4f" % (m_ap, float(G["evalpipe/mAP"]),
+                                                                         float(np.abs(seen["cmc"] - G["evalpipe/cmc"]).max())))
+    assert abs(m_ap - float(G["evalpipe/mAP"])) <= 1e-3
+    assert float(np.abs(seen["cmc"] - G["evalpipe/cmc"]).max()) <= 1.0 / nq + 1e-6
+    # descriptors against the fp32 oracle, with stock torch bf16 autocast on the same weights as the yardstick
+    _, _, qf_o, gf_o, _ = oe.evaluate(state, L["query"], L["gallery"])
+    sd = {k: v.cuda() for k, v in state.items()}
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        stock = torch.cat([om.forward({k: v.clone() for k, v in sd.items()}, [x.cuda() for x in d["img"]], False).float().cpu()
+                           for d in L["gallery"]], 0)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    e_mine, e_stock = rel(seen["gf"], torch.from_numpy(gf_o)), rel(stock, torch.from_numpy(gf_o))
+    print("bf16 eval descriptors vs fp32 oracle: native %.3e, stock torch bf16 %.3e" % (e_mine, e_stock))
+    assert e_mine <= 1.25 * e_stock + 1e-3
+    assert rel(seen["qf"], torch.from_numpy(qf_o)) <= 1.25 * e_stock + 5e-3
+
+
 def test_engine_run_matches_reference_loop(G):
     """Engine.run(max_epoch=2, eval_freq=1) on a synthetic datamanager: per-batch summaries, the learning-rate schedule,
     the evaluation + checkpoint after epoch 1 only (none after the last epoch, engine.py:216), counters"""
