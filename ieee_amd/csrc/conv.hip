@@ -1470,6 +1470,13 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   }
   hipStream_t st = (hipStream_t)stream;
   float* slab = (float*)work;
+  // one split of a 1x1 conv: the "slab" IS the gradient (slab order [co][ci] = OIHW), so the GEMM writes it in place and no
+  // reduction pass runs (the two CIM convs: 2 x 50 MB written, read back and written again per step otherwise)
+  const bool direct = nsplit == 1 && d.R * d.S == 1 && !accumulate && (dw_gs & 3) == 0 && ((uintptr_t)dw_oihw & 15) == 0;
+  if (direct) {
+    slab = dw_oihw;
+    a.slab_gs = dw_gs;
+  }
   if (dtype == IEEE_F32) {
     if (slow) conv_wgrad_kernel<float, true><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
     else conv_wgrad_kernel<float, false><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
@@ -1485,6 +1492,7 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
     IEEE_REQUIRE(false, "conv2d_wgrad: bad dtype %d", dtype);
   }
   IEEE_TRY(launch_status("conv_wgrad_kernel"));
+  if (direct) return IEEE_OK;
   const int64_t total = (int64_t)d.Co * d.Ci * d.R * d.S;
   const bool vec4 = d.R * d.S == 1 && (total & 3) == 0 && (dw_gs & 3) == 0 && (a.slab_gs & 3) == 0 &&
                     ((uintptr_t)dw_oihw & 15) == 0 && ((uintptr_t)slab & 15) == 0;

@@ -21,6 +21,11 @@ for dt in (torch.bfloat16, torch.float32):
     m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, compute_dtype=dt)
     m.load_state_dict(generated_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 11))
     m.train()
+    # the generated weights sit on a coarse binary grid: many are exact ties of the bf16 rounding, and ANY perturbation moves
+    # all of those by a whole bf16 ulp at once (a jump of ~0.2 in the loss, found in the first scan) -- start from a generic point
+    with torch.no_grad():
+        u = torch.rand(m._flat_params.shape, generator=torch.Generator(device="cuda").manual_seed(7), device="cuda") * 2 - 1
+        m._flat_params.mul_(1 + u * 2.0 ** -10)
     eng = Image3MEngine(DM(), m, build_optimizer(m, optim="sgd", lr=0.0, weight_decay=0.0, momentum=0.0), margin=1, use_gpu=True)
     l0 = float(eng.forward_backward(data)["loss"])
     grad = m._flat_grads.clone()

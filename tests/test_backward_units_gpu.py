@@ -210,6 +210,11 @@ def test_b64_bf16_descent_along_the_native_gradient():
     state = generated_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed)
     m.load_state_dict(state)
     m.train()
+    # a generic starting point: the generated weights lie on a coarse binary grid where many are exact ties of the bf16
+    # rounding -- any perturbation then moves all of those by a whole ulp at once (a jump of ~0.2 in the loss)
+    with torch.no_grad():
+        u = torch.rand(m._flat_params.shape, generator=torch.Generator(device="cuda").manual_seed(7), device="cuda") * 2 - 1
+        m._flat_params.mul_(1 + u * 2.0 ** -10)
     opt = build_optimizer(m, optim="sgd", lr=0.0, weight_decay=0.0, momentum=0.0)
     eng = Image3MEngine(_DM(), m, opt, margin=1, use_gpu=True)
     l0 = float(eng.forward_backward(data)["loss"])

@@ -66,6 +66,21 @@ def test_oracle_evaluation_chain_matches_reference(G):
     assert float(G["evalpipe/returned_mAP"]) == float(G["evalpipe/mAP"])
 
 
+@pytest.mark.parametrize("fixture", ["evalpipe_tame", "evalpipe_tame_hard"])
+def test_oracle_evaluation_chain_matches_reference_on_the_tame_fixtures(golden_dir, fixture):
+    """round 3: the well-conditioned evaluation fixtures of the bf16 tests (tests/golden/gen_model_golden_r3.py: every
+    bottleneck's last BatchNorm scale x 0.25) -- the oracle chain reproduces the reference's descriptors, CMC and mAP"""
+    torch.set_num_threads(8)
+    R = np.load(os.path.join(golden_dir, "model_golden_r3.npz"))
+    noise = float(R[fixture + "/noise"])
+    sd = calibrated_state(shapes(171), seed=8, tame=True, noise=noise)
+    L = eval_loaders(noise)
+    cmc, m_ap, qf, gf, dist = oe.evaluate(sd, L["query"], L["gallery"])
+    scale = np.abs(R[fixture + "/gf"]).max()
+    assert np.abs(qf - R[fixture + "/qf"]).max() < 1e-4 * scale and np.abs(gf - R[fixture + "/gf"]).max() < 1e-4 * scale
+    assert np.array_equal(cmc, R[fixture + "/cmc"]) and abs(m_ap - float(R[fixture + "/mAP"])) < 1e-9
+
+
 def test_oracle_run_loop_matches_reference(G):
     """2 epochs x 2 batches, MultiStepLR([1]), evaluation + checkpoint after epoch 1 only (never after the last epoch)"""
     torch.set_num_threads(8)
