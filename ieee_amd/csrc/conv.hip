@@ -636,59 +636,6 @@ static bool patch_eligible(const GatherGeom& g, int M) {
 }
 
 
-// 256-row tiles for the plain-matrix (1x1 / stride 1) launches whose k-loop is bound by the L2 -> LDS path (gemm_nt_dma256)
-template <int BN, int MODE>
-__global__ __launch_bounds__(512, 2) void conv_gather256_kernel(const bf16* __restrict__ src, const bf16* __restrict__ w,
-                                                                bf16* __restrict__ dst, const bf16* __restrict__ addend,
-                                                                float* __restrict__ bn_partial, ConvArgs a, BwdStats bs, int epi_bytes) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int tm, tn;
-  tile_map_xy(a.tiles_m, a.tiles_n, a.group, tm, tn);      // a.tiles_m counts 256-row tiles here
-  const int m0 = tm * 256, n0 = tn * BN;
-  const int z = blockIdx.y;
-  src += z * a.src_gs;
-  w += z * a.w_gs;
-  dst += z * a.dst_gs;
-  if (addend != nullptr) addend += z * a.dst_gs;
-  const int tiles128 = (a.M + 127) / 128;
-  StagedStoreEpi<bf16, MODE, 0> epi{0, dst, addend, (MODE == 1 || MODE == 2) ? bn_partial + (int64_t)z * tiles128 * 2 * a.N : nullptr, a.N, a.M, a.N, tm, tiles128,
-                                    MODE == 2 ? (const bf16*)bs.y + z * bs.act_gs : nullptr,
-                                    (MODE == 2 && bs.mask && !bs.mask_bits) ? (const bf16*)bs.mask + z * bs.act_gs : nullptr,
-                                    ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
-  if constexpr (MODE == 3) epi.relu = bs.relu;
-  if constexpr (MODE == 2) {
-    if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
-  }
-  const int ch = nt_dma_chunk(threadIdx.x);
-  LoaderPlainLean<BN / 64, 64> lb;
-  lb.init(w, a.ldw, n0, a.N, ch);
-  LoaderPlainLean<4, 64> la;
-  la.init(src, a.g.Cs, m0, a.g.npix, ch);
-  gemm_nt_dma256<BN>(la, lb, epi, a.ktiles, m0, n0, smem, epi_bytes);
-}
-
-template <int BN, int MODE>
-static void launch_gather256_inst(dim3 grid, hipStream_t st, const bf16* src, const bf16* w, bf16* dst, const bf16* addend,
-                                  float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
-  const int epi_bytes = 128 * (BN * 2 + 16);
-  size_t smem = (size_t)(256 + BN) * 128;
-  if (smem < (size_t)2 * epi_bytes) smem = (size_t)2 * epi_bytes;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_gather256_kernel<BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-  conv_gather256_kernel<BN, MODE><<<grid, 512, smem, st>>>(src, w, dst, addend, bn_partial, a, bs, epi_bytes);
-}
-template <int BN>
-static void launch_gather256_mode(int mode, dim3 grid, hipStream_t st, const bf16* src, const bf16* w, bf16* dst, const bf16* addend,
-                                  float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
-  if (mode == 3) launch_gather256_inst<BN, 3>(grid, st, src, w, dst, addend, nullptr, a, bs);
-  else if (mode == 2) launch_gather256_inst<BN, 2>(grid, st, src, w, dst, addend, bn_partial, a, bs);
-  else if (mode == 1) launch_gather256_inst<BN, 1>(grid, st, src, w, dst, addend, bn_partial, a, bs);
-  else launch_gather256_inst<BN, 0>(grid, st, src, w, dst, addend, nullptr, a, bs);
-}
-
 struct WgradArgs {
   GatherGeom g;       // forward geometry of the conv
   int Co, ncols;      // GEMM M (= Cout), N (= R*S*Cin)
@@ -1217,21 +1164,6 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
         else launch_patch_w<128, 1>(wlog, mode, pgrid, st, src, w, dst, addend, bn_partial, a, bs);
       }
       return launch_status("conv3x3_patch_kernel");
-    }
-  }
-  if constexpr (sizeof(T) == 2) {
-    // 256-row tiles (8 waves): the 1x1 / stride-1 launches with a long k-loop and enough 256 x 128 tiles to fill the chip
-    static const int f_big = getenv("IEEE_GATHER_256") ? atoi(getenv("IEEE_GATHER_256")) : 1;
-    static const int f_big_k = getenv("IEEE_GATHER_256_KT") ? atoi(getenv("IEEE_GATHER_256_KT")) : 8;
-    static const int64_t f_big_wg = getenv("IEEE_GATHER_256_WG") ? atoll(getenv("IEEE_GATHER_256_WG")) : 512;
-    const bool plain1x1 = a.g.R == 1 && a.g.S == 1 && a.g.mul == 1 && a.g.off == 0 && a.g.div == 1 && !a.g.perm;
-    if (f_big && !slow && plain1x1 && !bs.addend_s2 && N % 128 == 0 && a.ktiles >= f_big_k &&
-        (int64_t)cdiv(M, 256) * (N / 128) * groups >= f_big_wg) {
-      a.tiles_m = cdiv(M, 256);
-      a.tiles_n = N / 128;
-      dim3 bgrid(a.tiles_m * a.tiles_n, groups);
-      launch_gather256_mode<128>(mode, bgrid, st, src, w, dst, addend, bn_partial, a, bs);
-      return launch_status("conv_gather256_kernel");
     }
   }
   if (slow) {

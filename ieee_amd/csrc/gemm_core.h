@@ -330,29 +330,6 @@ template <> __device__ __forceinline__ void glds16_lean<8>(const unsigned (&voff
                : "memory", "scc");
 }
 #undef IEEE_GLDS_STEP
-// the same for 512-thread workgroups: a pass of the block covers 64 rows, so consecutive slots land 0x2000 bytes apart
-#define IEEE_GLDS_STEP2(v) "s_nop 0\n\tglobal_load_lds_dwordx4 " v ", %[b]\n\ts_add_u32 m0, m0, 0x2000\n\t"
-template <int N> __device__ __forceinline__ void glds16_lean2(const unsigned (&voff)[N], const void* sbase, char* lds_wave_base);
-template <> __device__ __forceinline__ void glds16_lean2<2>(const unsigned (&voff)[2], const void* sbase, char* lds_wave_base) {
-  const unsigned dst =
-      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
-  unsigned keep;
-  asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\t" IEEE_GLDS_STEP2("%[v0]") IEEE_GLDS_STEP2("%[v1]") "s_mov_b32 m0, %[k]"
-               : [k] "=&s"(keep)
-               : [v0] "v"(voff[0]), [v1] "v"(voff[1]), [b] "s"(sbase), [d] "s"(dst)
-               : "memory", "scc");
-}
-template <> __device__ __forceinline__ void glds16_lean2<4>(const unsigned (&voff)[4], const void* sbase, char* lds_wave_base) {
-  const unsigned dst =
-      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
-  unsigned keep;
-  asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\t" IEEE_GLDS_STEP2("%[v0]") IEEE_GLDS_STEP2("%[v1]") IEEE_GLDS_STEP2("%[v2]")
-               IEEE_GLDS_STEP2("%[v3]") "s_mov_b32 m0, %[k]"
-               : [k] "=&s"(keep)
-               : [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [b] "s"(sbase), [d] "s"(dst)
-               : "memory", "scc");
-}
-#undef IEEE_GLDS_STEP2
 
 // One LDS-DMA (1 KB per wave-instruction) with a wave-uniform 64-bit global base in SGPRs + a per-lane 32-bit byte offset,
 // to an arbitrary wave-uniform LDS address (the patch loader of conv3x3_patch_kernel: one image-row segment per instruction)
@@ -541,58 +518,6 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
       for (int j = 0; j < FN; ++j)
         epi(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, acc[i][j]);
   }
-}
-
-// 256 x BN tile, 8 waves (4 along M x 2 along N, 64 x BN/2 outputs each as in the 128-row core), 512 threads: the B tile
-// is shared by twice the rows, so the operand bytes per MFMA fall from (128 + BN) to (128 + BN / 2) rows' worth -- the
-// large-K layers are bound by the L2 -> LDS path, not the matrix pipe.  One LDS stage, two barriers per
-// k-tile, 16 waves per CU (2 workgroups) like the 128-row core's 4 x 4.  Lean plain-matrix loaders only (1x1 / stride 1).
-// The epilogue runs as two independent 128-row halves (waves 0-3 / 4-7), each through its own LDS region.
-template <int BN, class LA, class LB, class Epi>
-__device__ __forceinline__ void gemm_nt_dma256(LA& la, LB& lb, Epi& epi, int ktiles, int m0, int n0, char* smem, int epi_bytes) {
-  typedef ImgNT<bf16> Img;
-  constexpr int BM = 256;
-  constexpr int ACH = 4, BCH = BN / 64;
-  constexpr int FM = 4, FN = BN / 32;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  f32x4 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto issue = [&]() {
-    glds16_lean2<ACH>(la.off, la.base, smem + (8 * wave_u) * 128);
-    glds16_lean2<BCH>(lb.off, lb.base, smem + BM * 128 + (8 * wave_u) * 128);
-  };
-  const char* At = smem + (wm * 64) * 128;
-  const char* Bt = smem + BM * 128 + (wn * (BN / 2)) * 128;
-  issue();
-  for (int kt = 0; kt < ktiles; ++kt) {
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int kk = 0; kk < Img::KSTEPS; ++kk) {
-      Img::Frag fa[FM], fb[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) fa[i] = Img::frag(At, i * 16, kk, lane);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) fb[j] = Img::frag(Bt, j * 16, kk, lane);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
-    }
-    if (kt + 1 < ktiles) {
-      __builtin_amdgcn_s_barrier();
-      la.next();
-      lb.next();
-      issue();
-    }
-  }
-  const int half = wave >> 2;
-  epi.tile_m = epi.tile_m * 2 + half;
-  epi.template finish<128, BN, FM, FN>(acc, smem + half * epi_bytes, m0 + half * 128, n0);
 }
 
 // HALF_M: the GEMM has at most 64 rows (Cout = 64: stem, layer1 conv1/conv2).  The LDS image keeps its 128-column
