@@ -5,6 +5,8 @@
 // unbiased for the running estimate.  HBM-bound streaming kernels, 16 bytes per lane.
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "pool_gather.h"
 
@@ -444,11 +446,32 @@ extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int
   return launch_status("bn_apply_kernel");
 }
 
+extern "C" int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                                int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma,
+                                int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
+                                float* partial, float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks,
+                                void* done_event, void* stream);
+
 extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
                              int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma,
                              int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
                              float* partial, float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks,
                              void* stream) {
+  return ieee_bn2d_bwd_ev(dout, out_mask, y, dy, g_out, dtype, groups, M, C, act_gs, gamma, param_gs, stats, dgamma, dbeta,
+                          grad_gs, partial, coef, accumulate, mask_from_y, stats_rblocks, nullptr, stream);
+}
+
+// done_event (a hipEvent_t, optional): signalled by the LAST kernel of the call itself -- it rides on that dispatch as its
+// completion signal (hipExtLaunchKernelGGL's stop event) instead of a separate hipEventRecord behind it.  An event
+// record is a barrier packet of its own in the queue: the next kernel of the stream starts only after the previous
+// one has drained AND the packet has been processed (+5 us per record on the dgrad / BatchNorm chain of the backward,
+// 49 per step: found in the round-3 kernel trace as a 7.5 us gap behind every bn_bwd_apply that a weight gradient
+// forks from).
+extern "C" int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                                int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma,
+                                int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
+                                float* partial, float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks,
+                                void* done_event, void* stream) {
   IEEE_REQUIRE(dout && y && dy && gamma && stats && partial && coef, "bn2d_bwd: null pointer");
   IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_bwd: bad dtype");
   IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_bwd: C not a multiple of the vector width");
@@ -472,14 +495,26 @@ extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void*
   IEEE_TRY(launch_status("bn_bwd_finalize_kernel"));
   const int64_t chunks = M * C / vec_of(dtype);
   dim3 grid(ew_blocks(chunks), (unsigned)groups);
-  if (dtype == IEEE_F32)
-    bn_bwd_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)dout, (const float*)out_mask, (const float*)y,
-                                                     (float*)dy, (float*)g_out, coef, 3 * C, chunks, g.cprw, (int)C,
-                                                     act_gs, stats, 4 * C, mask_from_y);
-  else
-    bn_bwd_apply_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)dout, (const bf16*)out_mask, (const bf16*)y,
-                                                    (bf16*)dy, (bf16*)g_out, coef, 3 * C, chunks, g.cprw, (int)C,
-                                                    act_gs, stats, 4 * C, mask_from_y);
+  hipEvent_t ev = (hipEvent_t)done_event;
+  if (dtype == IEEE_F32) {
+    if (ev)
+      hipExtLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, nullptr, ev, 0, (const float*)dout,
+                            (const float*)out_mask, (const float*)y, (float*)dy, (float*)g_out, (const float*)coef, (int64_t)(3 * C),
+                            chunks, g.cprw, (int)C, act_gs, stats, (int64_t)(4 * C), mask_from_y);
+    else
+      bn_bwd_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)dout, (const float*)out_mask, (const float*)y,
+                                                       (float*)dy, (float*)g_out, coef, 3 * C, chunks, g.cprw, (int)C,
+                                                       act_gs, stats, 4 * C, mask_from_y);
+  } else {
+    if (ev)
+      hipExtLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, st, nullptr, ev, 0, (const bf16*)dout,
+                            (const bf16*)out_mask, (const bf16*)y, (bf16*)dy, (bf16*)g_out, (const float*)coef, (int64_t)(3 * C),
+                            chunks, g.cprw, (int)C, act_gs, stats, (int64_t)(4 * C), mask_from_y);
+    else
+      bn_bwd_apply_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)dout, (const bf16*)out_mask, (const bf16*)y,
+                                                      (bf16*)dy, (bf16*)g_out, coef, 3 * C, chunks, g.cprw, (int)C,
+                                                      act_gs, stats, 4 * C, mask_from_y);
+  }
   return launch_status("bn_bwd_apply_kernel");
 }
 

@@ -636,6 +636,84 @@ static bool patch_eligible(const GatherGeom& g, int M) {
 }
 
 
+
+// ------------------------------------------------------------------ the stem as a direct convolution over an LDS patch
+// The stem runs as an 8x8 / stride-2 conv over the border-padded 4-channel image (net.hip).  Through the implicit-GEMM
+// kernel its im2col operand is a 16x expansion of the image streamed L2 -> LDS per k-tile (805 MB for 54 MB of pixels at
+// B = 64: 137 us for 255 MB of HBM traffic).  Here a workgroup owns 2 output rows x 64 columns (= 128 GEMM rows) and brings
+// the 10 input rows they see into LDS as they lie in memory (one contiguous 10.7 KB run: 11 LDS-DMA instructions);
+// the A fragment of k-step ks (= filter row ks: 8 taps x 4 channels = 32 k) for output column ow is the 16 bytes at
+// row (2*oh + ks), pixel 2*ow + 2*(lane >> 4) -- consecutive output columns are 16 bytes apart, so a fragment read is a
+// contiguous 256-byte run per 16 lanes: conflict-free with no swizzle and no address arithmetic in the loop.  The packed
+// weights (64 x 256 bf16 = 32 KB) never enter LDS: each wave keeps its B fragments of all 8 k-steps in registers.
+// No barrier inside the k-loop.  Same staged epilogue (BatchNorm sums / folded eval BatchNorm) as the GEMM kernel.
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void stem_conv_kernel(const bf16* __restrict__ src, const bf16* __restrict__ w,
+                                                           bf16* __restrict__ dst, float* __restrict__ bn_partial,
+                                                           ConvArgs a, BwdStats bs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  tile_map_xy(a.tiles_m, 1, a.group, tm, tn);
+  const int m0 = tm * 128;
+  const int z = blockIdx.y;
+  src += z * a.src_gs;
+  w += z * a.w_gs;
+  dst += z * a.dst_gs;
+  StagedStoreEpi<bf16, MODE, 0> epi{0, dst, nullptr, MODE == 1 ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
+                                    nullptr, nullptr, (MODE == 3 && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
+  if constexpr (MODE == 3) epi.relu = bs.relu;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int Hp = a.g.Hs, Wp = a.g.Ws, tiles_per_img = a.g.Ho >> 1;
+  const int img = tm / tiles_per_img, oh0 = (tm - img * tiles_per_img) * 2;
+  const int rowb = Wp * 8;                                   // bytes per input row (4 bf16 channels per pixel)
+  const int patch_bytes = 10 * rowb;
+  const char* pbase = (const char*)src + ((int64_t)(img * Hp + 2 * oh0) * Wp) * 8;
+  const int ninstr = (patch_bytes + 1023) >> 10;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = wave_u + 4 * k;
+    if (j < ninstr) {
+      const unsigned off = (unsigned)min(j * 1024 + lane * 16, patch_bytes - 16);   // the tail lanes re-read the last chunk
+      glds16_s(off, pbase, smem + j * 1024);
+    }
+  }
+  // B fragments of all 8 k-steps: lane (n = lane & 15, k-chunk lane >> 4) of n-fragment j
+  bf16x8 fb[8][2];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      fb[ks][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(w + (int64_t)(wn * 32 + j * 16 + (lane & 15)) * a.ldw + ks * 32 + (lane >> 4) * 8));
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned abase = (unsigned)(2 * wm * rowb + (lane & 15) * 16 + (lane >> 4) * 16);
+  wait_vmcnt<0>();
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    bf16x8 fa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(smem + abase + ks * rowb + i * 256));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fb[ks][j], fa[i], acc[i][j]);
+  }
+  epi.template finish<128, 64, 4, 2>(acc, smem, m0, 0);
+}
+
+// the shapes the direct stem covers: 8x8 / stride 2 / no padding over 4 channels, 64 output channels, 64 output columns
+static bool stem_eligible(const GatherGeom& g, int N, int ldw, int mode, const void* addend) {
+  static const bool on = !(getenv("IEEE_STEM_DIRECT") && atoi(getenv("IEEE_STEM_DIRECT")) == 0);
+  return on && g.R == 8 && g.S == 8 && g.Cs == 4 && g.mul == 2 && g.off == 0 && g.sgn == 1 && g.div == 1 && !g.perm && N == 64 &&
+         g.Wo == 64 && (g.Ho & 1) == 0 && g.Ws == 2 * 64 + 6 && g.Hs == 2 * g.Ho + 6 && ldw == 256 && (mode == 0 || mode == 1 || mode == 3) &&
+         addend == nullptr;
+}
+
 struct WgradArgs {
   GatherGeom g;       // forward geometry of the conv
   int Co, ncols;      // GEMM M (= Cout), N (= R*S*Cin)
@@ -1149,6 +1227,14 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   }
   const int mode = affine ? 3 : ((stats && bwd) ? 2 : (stats ? 1 : 0));
   if constexpr (sizeof(T) == 2) {
+    if (!slow && stem_eligible(a.g, N, ldw, mode, addend)) {
+      dim3 sgrid(a.tiles_m, groups);
+      const size_t ssm = 128 * (64 * 2 + 16);      // staged epilogue (18 KB) > patch (11 KB) > BN-sum scratch
+      if (mode == 3) stem_conv_kernel<3><<<sgrid, 256, ssm, st>>>(src, w, dst, nullptr, a, bs);
+      else if (mode == 1) stem_conv_kernel<1><<<sgrid, 256, ssm, st>>>(src, w, dst, bn_partial, a, bs);
+      else stem_conv_kernel<0><<<sgrid, 256, ssm, st>>>(src, w, dst, nullptr, a, bs);
+      return launch_status("stem_conv_kernel");
+    }
     if (!slow && plan.bn != 256 && !bs.addend_s2 && patch_eligible(a.g, M)) {
       static const int f_style = getenv("IEEE_PATCH_STYLE") ? atoi(getenv("IEEE_PATCH_STYLE")) : 1;
       static const int f_bn = getenv("IEEE_PATCH_BN") ? atoi(getenv("IEEE_PATCH_BN")) : 0;

@@ -433,6 +433,18 @@ struct Run {
   }
   // backward of out = [relu](bn(y) [+res]); dy may alias dout
   bool& fused_bwd = n.fused_bwd_state;   // the last dgrad already emitted the BN-backward sums of the next bn_bwd()
+  // The weight gradient of a unit forks (onto the side stream) from the completion of that unit's BatchNorm backward: its
+  // last kernel carries the fork event as its own completion signal (ieee_bn2d_bwd_ev) -- no event record in the queue
+  // between it and the dgrad that follows on the caller's stream.  wgrad() picks the event up (bn_done).
+  hipEvent_t bn_done = nullptr;
+  hipEvent_t next_ready_event() {
+    if (n.side_used == n.side_ready.size()) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      n.side_ready.push_back(e);
+    }
+    return n.side_ready[n.side_used++];
+  }
   int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0,
              float* partial = nullptr, int64_t partial_rb = 0) {
     const int64_t rb = partial ? partial_rb : (fused_bwd ? (u.M(B) + 127) / 128 : 0);
@@ -440,8 +452,11 @@ struct Run {
     fused_bwd = false;
     will_write(dy);
     if (gout) will_write(gout);
-    return ieee_bn2d_bwd(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
-                         F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, bncoef_cur, 0, mask_from_y, rb, st);
+    static const bool ride = !(getenv("IEEE_EVENT_RIDE") && atoi(getenv("IEEE_EVENT_RIDE")) == 0);
+    bn_done = (ride && side_enabled()) ? next_ready_event() : nullptr;
+    return ieee_bn2d_bwd_ev(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
+                            F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, bncoef_cur, 0, mask_from_y, rb,
+                            (void*)bn_done, st);
   }
   // --- second stream for the weight gradients (see Net::side)
   int gbuf_index(const void* p) const {
@@ -520,13 +535,13 @@ struct Run {
   void branch_join(int slot) { (void)hipStreamWaitEvent((hipStream_t)st, n.branch_ev[2 * slot + 1], 0); }
   int wgrad(const ConvUnit& u, const void* dy, const void* x) {
     if (side_enabled()) {
-      if (n.side_used == n.side_ready.size()) {
-        hipEvent_t e;
-        IEEE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        n.side_ready.push_back(e);
+      hipEvent_t ready = bn_done;          // signalled by the BatchNorm backward that produced dy (see bn_bwd)
+      bn_done = nullptr;
+      if (ready == nullptr) {
+        ready = next_ready_event();
+        IEEE_REQUIRE(ready != nullptr, "net: cannot create an event");
+        IEEE_HIP(hipEventRecord(ready, (hipStream_t)st));
       }
-      hipEvent_t ready = n.side_ready[n.side_used++];
-      IEEE_HIP(hipEventRecord(ready, (hipStream_t)st));
       IEEE_HIP(hipStreamWaitEvent(n.side, ready, 0));
       void* main_st = st;
       st = (void*)n.side;

@@ -185,6 +185,13 @@ int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void* y, void* d
                   int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
                   const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, float* partial,
                   float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks, void* stream);
+/* the same with `done_event` (a hipEvent_t or NULL): signalled when the call's last kernel completes, carried by that
+ * dispatch itself instead of a separate event record behind it (a record is a barrier packet in the queue: +5 us
+ * before the next kernel of the stream).  The executor forks its weight-gradient stream from these events. */
+int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                  int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
+                  const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, float* partial,
+                  float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks, void* done_event, void* stream);
 
 /* ---- stem plumbing ----------------------------------------------------------- */
 /* three fp32 NCHW image tensors (batch dict 'img' = [RGB, NI, TI], dataset.py:338-351) ->
