@@ -714,6 +714,112 @@ static bool stem_eligible(const GatherGeom& g, int N, int ldw, int mode, const v
          addend == nullptr;
 }
 
+
+// The stem's weight gradient the same way: dW[co][(r, s, c)] = sum over output pixels of dY[pix][co] * x[2*oh + r][2*ow + s][c].
+// A workgroup owns STEM_WG_ROWS output rows of one image (one split-K slab) and walks them two rows (128 pixels) at a
+// time: the 10 input rows go into LDS as they lie in memory, the 128 x 64 dY tile beside them (chunks XOR-swizzled on the
+// DMA's source side), and BOTH MFMA operands come out through ds_read_b64_tr_b16 -- dY transposed as in the TN core, the
+// im2col operand straight from the raw patch: for a fixed filter row r the 16 GEMM columns (4 taps x 4 channels) of an
+// output pixel are 32 contiguous bytes of the image, and consecutive output pixels are 16 bytes apart.  No im2col
+// expansion anywhere (the implicit-GEMM form re-reads the image 16x from L2: 177 us for 255 MB of HBM traffic).
+// Each wave accumulates all 64 output channels x 64 of the 256 columns (2 filter rows); slabs are reduced by the common
+// wgrad_reduce kernel.
+constexpr int STEM_WG_ROWS = 32;
+__global__ __launch_bounds__(256, 3) void stem_wgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                            float* __restrict__ slab, int Hp, int Wp, int Ho,
+                                                            int64_t dy_gs, int64_t x_gs, int64_t slab_gs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int z = blockIdx.y;
+  const int splits_per_img = Ho / STEM_WG_ROWS;
+  const int split = blockIdx.x, img = split / splits_per_img, oh_first = (split - img * splits_per_img) * STEM_WG_ROWS;
+  dy += z * dy_gs;
+  x += z * x_gs;
+  slab += z * slab_gs + (int64_t)split * 64 * 256;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int rowb = Wp * 8, patch_bytes = 10 * rowb, ninstr = (patch_bytes + 1023) >> 10;
+  char* patch = smem;                       // 12 KB region
+  char* dtile = smem + 12 * 1024;           // [128 pixels][128 B], chunk slots XOR key(pixel)
+  // dY loader: instruction covers 8 pixels x 8 chunks; lane (pixel j = lane >> 3, slot f = lane & 7) fetches logical
+  // chunk f ^ key(pixel), key = 2 * bit1(pixel) + 4 * bit3(pixel)  (8 rows {0-3, 8-11} + both column halves -> 8 slots)
+  const int lj = lane >> 3, lf = lane & 7;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment addressing (lane = 16 * g + 4 * q + p)
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  for (int it = 0; it < STEM_WG_ROWS / 2; ++it) {
+    const int oh0 = oh_first + 2 * it;
+    const char* pbase = (const char*)x + ((int64_t)(img * Hp + 2 * oh0) * Wp) * 8;
+    const char* dbase = (const char*)dy + ((int64_t)(img * Ho + oh0) * 64) * 128;
+    if (it > 0) __builtin_amdgcn_s_barrier();     // every wave is done reading the previous tiles
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = wave_u + 4 * k;
+      if (j < ninstr) glds16_s((unsigned)min(j * 1024 + lane * 16, patch_bytes - 16), pbase, patch + j * 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = wave_u + 4 * k;               // 16 instructions: pixels 8j .. 8j + 7
+      const int pix = 8 * j + lj;
+      const int key = (((pix >> 1) & 1) << 1) | (((pix >> 3) & 1) << 2);
+      glds16_s((unsigned)(pix * 128 + ((lf ^ key) << 4)), dbase, dtile + j * 1024);
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {               // 32 pixels per MFMA k-step
+      const int m = kk * 32 + 8 * g + q;           // this lane's k-row (pixel) of the first transposed read
+      const int key = (((m >> 1) & 1) << 1) | (((m >> 3) & 1) << 2);   // (m + 4 has the same key)
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                // dY^T: 16 output channels of fragment i
+        const int c = i * 2 + (p >> 1);
+        const char* a0 = dtile + m * 128 + ((c ^ key) << 4) + (p & 1) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 4 * 128));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fa[i] = __builtin_bit_cast(bf16x8, v);
+      }
+      const int ohr = m >> 6, ow = m & 63;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                // im2col^T: columns (r = 2 * wave + (j >> 1), s = 4 * (j & 1) + p, c = 0..3)
+        const int r = 2 * wave_u + (j >> 1), s0 = (j & 1) * 4;
+        const char* b0 = patch + (2 * ohr + r) * rowb + (2 * ow + s0 + p) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(b0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(b0 + 4 * 16));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fb[j] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* o = slab + (int64_t)(i * 16 + (lane & 15)) * 256 + wave * 64 + j * 16 + (lane >> 4) * 4;
+      *(float4*)o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+}
+
+// split-K count of the direct stem weight gradient (0: shape not covered)
+static int64_t stem_wgrad_splits(int dtype, int64_t N, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo, int64_t Ci, int64_t Co,
+                                 int64_t R, int64_t S, int64_t stride, int64_t pad) {
+  static const bool on = !(getenv("IEEE_STEM_DIRECT") && atoi(getenv("IEEE_STEM_DIRECT")) == 0);
+  if (!on || dtype != IEEE_BF16 || R != 8 || S != 8 || Ci != 4 || Co != 64 || stride != 2 || pad != 0 || Wo != 64 ||
+      Ho % STEM_WG_ROWS != 0 || Wi != 2 * Wo + 6 || Hi != 2 * Ho + 6)
+    return 0;
+  return N * (Ho / STEM_WG_ROWS);
+}
+
 struct WgradArgs {
   GatherGeom g;       // forward geometry of the conv
   int Co, ncols;      // GEMM M (= Cout), N (= R*S*Cin)
@@ -1505,7 +1611,10 @@ extern "C" int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t 
 extern "C" int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, int64_t N, int64_t Ho, int64_t Wo,
                                                      int64_t Ci, int64_t Co, int64_t R, int64_t S) {
   const int64_t npix = N * Ho * Wo, ncols = R * S * Ci;
-  return (int64_t)wgrad_splitk(npix, Co, ncols, groups, dtype, R * S) * groups * Co * ncols * 4;
+  const int64_t generic = (int64_t)wgrad_splitk(npix, Co, ncols, groups, dtype, R * S) * groups * Co * ncols * 4;
+  // (the direct stem form: stride 2, no padding -> Hi = 2 Ho + 6; the query has no Hi / stride, so both sizes are covered)
+  const int64_t stem = stem_wgrad_splits(dtype, N, 2 * Ho + 6, 2 * Wo + 6, Ho, Wo, Ci, Co, R, S, 2, 0) * groups * Co * ncols * 4;
+  return generic > stem ? generic : stem;
 }
 
 extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
@@ -1516,6 +1625,21 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   Dims d;
   IEEE_TRY(check_dims("conv2d_wgrad", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
   IEEE_REQUIRE(Co % elem_vec(dtype) == 0, "conv2d_wgrad: Cout must be a multiple of %d", elem_vec(dtype));
+  if (const int64_t ssplits = stem_wgrad_splits(dtype, N, Hi, Wi, d.Ho, d.Wo, Ci, Co, R, S, stride, pad)) {
+    // the stem: direct form over LDS patches (stem_wgrad_kernel), one slab per STEM_WG_ROWS output rows of an image
+    hipStream_t st = (hipStream_t)stream;
+    float* slab = (float*)work;
+    const int64_t slab_gs = ssplits * 64 * 256;
+    stem_wgrad_kernel<<<dim3((unsigned)ssplits, (unsigned)groups), 256, 12 * 1024 + 16 * 1024, st>>>(
+        (const bf16*)dy, (const bf16*)x, slab, d.Hi, d.Wi, d.Ho, dy_gs, x_gs, slab_gs);
+    IEEE_TRY(launch_status("stem_wgrad_kernel"));
+    const int64_t total = (int64_t)d.Co * d.Ci * d.R * d.S;
+    int sl_log2 = 0;
+    while (sl_log2 < 4 && (2 << sl_log2) <= ssplits && (total << sl_log2) * groups < (int64_t)256 * 2048) ++sl_log2;
+    dim3 rgrid(cdiv(total, 256 >> sl_log2), (unsigned)groups);
+    wgrad_reduce_kernel<1><<<rgrid, 256, 0, st>>>(slab, dw_oihw, (int)ssplits, d.Co, d.Ci, d.R * d.S, slab_gs, dw_gs, accumulate, sl_log2);
+    return launch_status("wgrad_reduce_kernel");
+  }
   WgradArgs a;
   a.g = GatherGeom{d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.R, d.S, d.stride, -d.pad, +1, 1, d.N * d.Ho * d.Wo};
   a.Co = d.Co;
