@@ -820,6 +820,131 @@ static int64_t stem_wgrad_splits(int dtype, int64_t N, int64_t Hi, int64_t Wi, i
   return N * (Ho / STEM_WG_ROWS);
 }
 
+
+// ------------------------------------------------------------------ 3x3 / stride 1 weight gradient over LDS patches
+// dW[co][(r, s, ci)] = sum over pixels of dY[pix][co] * X[pix + (r - 1, s - 1)][ci].  The TN kernel above treats the 9 taps as 9
+// independent column blocks: X is fetched from L2 once per tap and dY once per 128 columns.  Here a workgroup owns
+// 128 (64) output channels x ONE filter row r x 64 input channels = 192 GEMM columns (three taps), and per k-tile of 64
+// pixels (whole image rows) brings in the dY tile [64][Co tile] (the TN core's image and loader) and the input rows those
+// pixels see under row r -- RK rows x (Wm + 2) pixels x 64 channels, zero halo included -- ONCE; the three taps read their
+// B fragments from it at shifted addresses through ds_read_b64_tr_b16.  Operand bytes per 128 x 192 x 64 MACs:
+// 16 KB + ~10 KB (the TN kernel: 32 KB per 128 x 128 x 64).  Chunk swizzles (conflict-free for all three shifts, checked
+// exhaustively): 8-wide maps key(w') = 2 * (w' & 3) with the row pitch padded by 128 B; 16 / 32-wide maps
+// key(w') = 2 * bit1(w') + 4 * bit3(w').  Split-K slabs and their reduction are the TN kernel's.
+template <int WLOG> struct WPatch {
+  static constexpr int Wm = 1 << WLOG, RK = 64 / Wm, PARTS = Wm / 8;
+  static constexpr int PITCH = (Wm + 2) * 128 + (WLOG == 3 ? 128 : 0);
+  static constexpr int BYTES = RK * PITCH;
+  __device__ static __forceinline__ int key(int wp) {
+    if constexpr (WLOG == 3) return (wp & 3) << 1;
+    else return (((wp >> 1) & 1) << 1) | (((wp >> 3) & 1) << 2);
+  }
+  // byte address of (k-row = pixel m of the k-tile shifted by ds columns, 16-byte channel chunk c, 8-byte half p1)
+  __device__ static __forceinline__ int addr(int m, int ds, int c, int p1) {
+    const int i = m >> WLOG, wp = (m & (Wm - 1)) + 1 + ds;
+    return i * PITCH + wp * 128 + ((c ^ key(wp)) << 4) + p1 * 8;
+  }
+};
+
+struct WgradPatchArgs {
+  int Hm, Ci, Co, npix, kchunk, nsplit, groups, tiles, nchunks, ncols;
+  int64_t dy_gs, x_gs, slab_gs;
+};
+
+template <int WLOG, bool HALF_M>
+__global__ __launch_bounds__(256, 3) void conv3x3_wgrad_patch_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                                     float* __restrict__ slab, WgradPatchArgs a) {
+  typedef WPatch<WLOG> WP;
+  typedef ImgTN<bf16> Img;
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // every tile of one (k-split, modality) goes to ONE XCD (blocks b, b + 8, ... share an L2): they read the same pixels
+  const int bid = blockIdx.x, xcd = bid & 7, jb = bid >> 3;
+  const int kzi = (jb / a.tiles) * 8 + xcd;
+  int tile = jb % a.tiles;
+  if (kzi >= a.nsplit * a.groups) return;
+  const int r = tile % 3;
+  tile /= 3;
+  const int cq = tile % a.nchunks, tm = tile / a.nchunks;
+  const int ks = kzi % a.nsplit, z = kzi / a.nsplit;
+  const int m0 = tm * 128;
+  dy += z * a.dy_gs;
+  x += z * a.x_gs;
+  slab += z * a.slab_gs + (int64_t)ks * a.Co * a.ncols;
+  const int kbeg = ks * a.kchunk, kend = min(a.npix, kbeg + a.kchunk);
+  const int ktiles = (kend - kbeg) >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  constexpr int FM = HALF_M ? 2 : 4, WROWS = FM * 16;
+  char* dtile = smem;                 // [64 k-rows][128 columns] bf16: the TN core's image (16 KB)
+  char* patch = smem + 64 * 256;
+  for (int i = t * 16; i < WP::BYTES; i += 256 * 16) *(uint4*)(patch + i) = make_uint4(0, 0, 0, 0);
+  f32x4 acc[FM][6];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  LoaderColsLean lad;
+  lad.init(dy, a.Co, m0, a.Co, kbeg, tn_dma_chunk(t));
+  const int lj = lane >> 3, lf = lane & 7;
+  const int hw = a.Hm * WP::Wm, Cs = a.Ci;
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    if (kt > 0) __builtin_amdgcn_s_barrier();        // every wave is done reading the previous k-tile
+    glds16_lean<4>(lad.off, lad.base, dtile + (4 * wave_u) * 256);
+    lad.next();
+    const int pb = kbeg + kt * 64;
+    const int img = pb / hw, h0 = (pb - img * hw) >> WLOG;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int jj = wave_u + 4 * k;                 // 8 instructions: RK rows x PARTS segments of 8 pixels
+      const int prow = jj / WP::PARTS, part = jj % WP::PARTS;
+      const int h = h0 + prow + r - 1;
+      char* dst = patch + prow * WP::PITCH + (part * 8 + 1) * 128;
+      if ((unsigned)h < (unsigned)a.Hm) {
+        const int wp = part * 8 + 1 + lj;
+        const unsigned voff = (unsigned)((lj * Cs + ((lf ^ WP::key(wp)) << 3)) * 2);
+        glds16_s(voff, (const char*)x + ((int64_t)((img * a.Hm + h) * WP::Wm + part * 8) * Cs + cq * 64) * 2, dst);
+      } else {
+        *(uint4*)(dst + lane * 16) = make_uint4(0, 0, 0, 0);   // a row outside the image: zeros, not the previous tile's pixels
+      }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[FM], fb[6];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa[i] = Img::frag(dtile, wm * WROWS + i * 16, kk, lane);
+      const int m = kk * 32 + 8 * g + q;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int ds = (j >> 1) - 1, c = (wn * 2 + (j & 1)) * 2 + (p >> 1);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(patch + WP::addr(m, ds, c, p & 1)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(patch + WP::addr(m + 4, ds, c, p & 1)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fb[j] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int co = m0 + wm * WROWS + i * 16 + (lane & 15);
+    if (co >= a.Co) continue;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int col = (r * 3 + (j >> 1)) * Cs + cq * 64 + (wn * 2 + (j & 1)) * 16 + (lane >> 4) * 4;
+      *(float4*)(slab + (int64_t)co * a.ncols + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  }
+}
+
 struct WgradArgs {
   GatherGeom g;       // forward geometry of the conv
   int Co, ncols;      // GEMM M (= Cout), N (= R*S*Cin)
@@ -1689,7 +1814,27 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
     slab = dw_oihw;
     a.slab_gs = dw_gs;
   }
-  if (dtype == IEEE_F32) {
+  static const bool f_wpatch = !(getenv("IEEE_WGRAD_PATCH") && atoi(getenv("IEEE_WGRAD_PATCH")) == 0);
+  const bool wpatch = f_wpatch && dtype == IEEE_BF16 && d.R == 3 && d.S == 3 && d.stride == 1 && d.pad == 1 &&
+                      (d.Wi == 8 || d.Wi == 16 || d.Wi == 32) && (d.Hi * d.Wi) % 64 == 0 && d.Ci % 64 == 0 &&
+                      (d.Co == 64 || d.Co % 128 == 0) && a.kchunk % 64 == 0 && a.npix % 64 == 0 &&
+                      (int64_t)a.npix * d.Co * 2 < (1ll << 32) && (int64_t)a.npix * d.Ci * 2 < (1ll << 32) && (a.slab_gs & 3) == 0;
+  if (wpatch) {
+    WgradPatchArgs pa;
+    pa.Hm = d.Hi; pa.Ci = d.Ci; pa.Co = d.Co; pa.npix = a.npix; pa.kchunk = a.kchunk; pa.nsplit = nsplit; pa.groups = (int)groups;
+    pa.nchunks = d.Ci / 64;
+    pa.tiles = cdiv(d.Co, 128) * pa.nchunks * 3;
+    pa.ncols = a.ncols;
+    pa.dy_gs = dy_gs; pa.x_gs = x_gs; pa.slab_gs = a.slab_gs;
+    dim3 pgrid((unsigned)(pa.tiles * cdiv(nkz, 8) * 8));
+    const int wlog = d.Wi == 8 ? 3 : (d.Wi == 16 ? 4 : 5);
+    const bool half = d.Co == 64;
+#define IEEE_WP_CASE(W_) \
+    if (half) conv3x3_wgrad_patch_kernel<W_, true><<<pgrid, 256, 64 * 256 + WPatch<W_>::BYTES, st>>>((const bf16*)dy, (const bf16*)x, slab, pa); \
+    else conv3x3_wgrad_patch_kernel<W_, false><<<pgrid, 256, 64 * 256 + WPatch<W_>::BYTES, st>>>((const bf16*)dy, (const bf16*)x, slab, pa)
+    if (wlog == 3) { IEEE_WP_CASE(3); } else if (wlog == 4) { IEEE_WP_CASE(4); } else { IEEE_WP_CASE(5); }
+#undef IEEE_WP_CASE
+  } else if (dtype == IEEE_F32) {
     if (slow) conv_wgrad_kernel<float, true><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
     else conv_wgrad_kernel<float, false><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
   } else if (dtype == IEEE_BF16) {
