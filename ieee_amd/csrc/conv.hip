@@ -810,6 +810,26 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad_kernel(const bf16* __restri
     }
 }
 
+// split-K count of the 3x3 patch weight gradient (0: shape not covered): its tiles are 128 x 192 (one filter row x 64 input
+// channels), two thirds as many as the TN kernel's, so it plans its own splits for ~3 workgroups per CU
+static int64_t wpatch_splits(int dtype, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+                             int64_t stride, int64_t pad, int64_t groups) {
+  static const bool on = !(getenv("IEEE_WGRAD_PATCH") && atoi(getenv("IEEE_WGRAD_PATCH")) == 0);
+  static const int64_t target = getenv("IEEE_WPATCH_TARGET") ? atoll(getenv("IEEE_WPATCH_TARGET")) : 448;
+  const int64_t npix = N * Hi * Wi;
+  if (!on || dtype != IEEE_BF16 || R != 3 || S != 3 || stride != 1 || pad != 1 || (Wi != 8 && Wi != 16 && Wi != 32) ||
+      (Hi * Wi) % 64 != 0 || Ci % 64 != 0 || !(Co == 64 || Co % 128 == 0) || npix * Co * 2 >= (1ll << 32) ||
+      npix * Ci * 2 >= (1ll << 32))
+    return 0;
+  const int64_t tiles = ((Co + 127) / 128) * (Ci / 64) * 3 * groups;
+  const int64_t ktiles = npix / 64;
+  int64_t want = (target + tiles / 2) / tiles;
+  if (want > ktiles / 4) want = ktiles / 4;        // at least 4 k-tiles per split
+  if (want < 1) want = 1;
+  const int64_t per = (ktiles + want - 1) / want;  // k-tiles per split
+  return (ktiles + per - 1) / per;
+}
+
 // split-K count of the direct stem weight gradient (0: shape not covered)
 static int64_t stem_wgrad_splits(int dtype, int64_t N, int64_t Hi, int64_t Wi, int64_t Ho, int64_t Wo, int64_t Ci, int64_t Co,
                                  int64_t R, int64_t S, int64_t stride, int64_t pad) {
@@ -1739,7 +1759,9 @@ extern "C" int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, 
   const int64_t generic = (int64_t)wgrad_splitk(npix, Co, ncols, groups, dtype, R * S) * groups * Co * ncols * 4;
   // (the direct stem form: stride 2, no padding -> Hi = 2 Ho + 6; the query has no Hi / stride, so both sizes are covered)
   const int64_t stem = stem_wgrad_splits(dtype, N, 2 * Ho + 6, 2 * Wo + 6, Ho, Wo, Ci, Co, R, S, 2, 0) * groups * Co * ncols * 4;
-  return generic > stem ? generic : stem;
+  // (3x3 / stride 1 / pad 1: Hi = Ho, Wi = Wo)
+  const int64_t wp = wpatch_splits(dtype, N, Ho, Wo, Ci, Co, R, S, 1, 1, groups) * groups * Co * ncols * 4;
+  return std::max(generic, std::max(stem, wp));
 }
 
 extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
@@ -1814,14 +1836,17 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
     slab = dw_oihw;
     a.slab_gs = dw_gs;
   }
-  static const bool f_wpatch = !(getenv("IEEE_WGRAD_PATCH") && atoi(getenv("IEEE_WGRAD_PATCH")) == 0);
-  const bool wpatch = f_wpatch && dtype == IEEE_BF16 && d.R == 3 && d.S == 3 && d.stride == 1 && d.pad == 1 &&
-                      (d.Wi == 8 || d.Wi == 16 || d.Wi == 32) && (d.Hi * d.Wi) % 64 == 0 && d.Ci % 64 == 0 &&
-                      (d.Co == 64 || d.Co % 128 == 0) && a.kchunk % 64 == 0 && a.npix % 64 == 0 &&
-                      (int64_t)a.npix * d.Co * 2 < (1ll << 32) && (int64_t)a.npix * d.Ci * 2 < (1ll << 32) && (a.slab_gs & 3) == 0;
+  const int64_t wsplits = wpatch_splits(dtype, N, Hi, Wi, Ci, Co, R, S, stride, pad, groups);
+  const bool wpatch = wsplits > 0;
+  int nsplit_used = nsplit;
   if (wpatch) {
     WgradPatchArgs pa;
-    pa.Hm = d.Hi; pa.Ci = d.Ci; pa.Co = d.Co; pa.npix = a.npix; pa.kchunk = a.kchunk; pa.nsplit = nsplit; pa.groups = (int)groups;
+    const int64_t ktiles_all = a.npix / 64, per = (ktiles_all + wsplits - 1) / wsplits;
+    nsplit_used = (int)wsplits;
+    a.kchunk = (int)(per * 64);
+    a.slab_gs = (int64_t)nsplit_used * d.Co * a.ncols;
+    const int nkz = nsplit_used * (int)groups;
+    pa.Hm = d.Hi; pa.Ci = d.Ci; pa.Co = d.Co; pa.npix = a.npix; pa.kchunk = a.kchunk; pa.nsplit = nsplit_used; pa.groups = (int)groups;
     pa.nchunks = d.Ci / 64;
     pa.tiles = cdiv(d.Co, 128) * pa.nchunks * 3;
     pa.ncols = a.ncols;
@@ -1856,19 +1881,19 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   // split lanes: enough blocks to fill the chip on the small-weight layers, no idle lanes on the few-split ones
   const int64_t outs = vec4 ? total / 4 : total;
   int sl_log2 = 0;
-  while (sl_log2 < 4 && (2 << sl_log2) <= nsplit && (outs << sl_log2) * groups < (int64_t)256 * 2048) ++sl_log2;
+  while (sl_log2 < 4 && (2 << sl_log2) <= nsplit_used && (outs << sl_log2) * groups < (int64_t)256 * 2048) ++sl_log2;
   dim3 rgrid(cdiv(outs, 256 >> sl_log2), (unsigned)groups);
   static const int f_taps = getenv("IEEE_WGRAD_REDUCE_TAPS") ? atoi(getenv("IEEE_WGRAD_REDUCE_TAPS")) : 16;
-  if (d.R * d.S > 1 && nsplit <= f_taps && d.Ci % 4 == 0 && (a.slab_gs & 3) == 0 && ((uintptr_t)slab & 15) == 0) {
+  if (d.R * d.S > 1 && nsplit_used <= f_taps && d.Ci % 4 == 0 && (a.slab_gs & 3) == 0 && ((uintptr_t)slab & 15) == 0) {
     const int RS = d.R * d.S;
     dim3 tgrid((unsigned)(d.Co * cdiv(d.Ci, RT_CIB)), (unsigned)groups);
-    wgrad_reduce_taps_kernel<<<tgrid, 256, (size_t)RT_CIB * RS * sizeof(float), st>>>(slab, dw_oihw, nsplit, d.Co, d.Ci, RS, a.slab_gs,
+    wgrad_reduce_taps_kernel<<<tgrid, 256, (size_t)RT_CIB * RS * sizeof(float), st>>>(slab, dw_oihw, nsplit_used, d.Co, d.Ci, RS, a.slab_gs,
                                                                                     dw_gs, accumulate);
     return launch_status("wgrad_reduce_taps_kernel");
   }
   if (vec4)
-    wgrad_reduce_kernel<4><<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs, accumulate, sl_log2);
+    wgrad_reduce_kernel<4><<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit_used, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs, accumulate, sl_log2);
   else
-    wgrad_reduce_kernel<1><<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs, accumulate, sl_log2);
+    wgrad_reduce_kernel<1><<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit_used, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs, accumulate, sl_log2);
   return launch_status("wgrad_reduce_kernel");
 }
