@@ -61,3 +61,24 @@ def test_metric_meter_folds_deferred_summaries_in_order_when_read():
     assert log.meters["loss"].val == 6.0 and log.meters["loss"].avg == 3.0 and log.meters["loss"].count == 4
     log.update(DeferredSummary(("loss",), reader(4)))
     assert str(log) == "loss 4.0000 (3.2000)" and seen == [1, 2, 3, 4]
+
+
+def test_deferred_summary_pickles_and_copies_as_the_settled_dict():
+    """a DeferredSummary's resolver is a closure over device state; what travels through pickle / copy is the plain dict"""
+    import copy
+    import pickle
+    from ieee_amd.meters import DeferredSummary
+    calls = []
+
+    def resolver():
+        calls.append(1)
+        return {"loss": 1.5, "acc": 50.0}
+    d = DeferredSummary(("loss", "acc"), resolver)
+    assert not d.resolved
+    back = pickle.loads(pickle.dumps(d))
+    assert type(back) is dict and back == {"loss": 1.5, "acc": 50.0} and d.resolved and len(calls) == 1
+    d2 = DeferredSummary(("loss", "acc"), resolver)
+    deep = copy.deepcopy(d2)
+    assert type(deep) is dict and deep == {"loss": 1.5, "acc": 50.0}
+    d3 = DeferredSummary(("loss", "acc"), resolver)
+    assert copy.copy(d3) == {"loss": 1.5, "acc": 50.0} and list(d3) == ["loss", "acc"]

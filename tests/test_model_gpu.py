@@ -142,3 +142,34 @@ def test_bf16_mode_drift_not_worse_than_stock_bf16(G):
     assert abs(float(loss) - G["train16/summary"][0]) / G["train16/summary"][0] < 0.02
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_async_parts_joined_by_sync_streams_equal_the_plain_backward():
+    """A C caller's view of the staged backward (include/ieee_amd.h): five ieee_net_backward_part_async calls leave weight
+    gradients in flight on the executor's side stream; ieee_net_sync_streams(handle, stream) -- which knows nothing about
+    that stream's existence on the caller's side -- orders everything before what follows on `stream`.  The gradients must
+    be bit-identical to the one-call backward (same kernels, same fixed summation orders)."""
+    from ieee_amd import _lib as L
+    lib = L.require_gpu()
+    B = 8
+    m = make_model(5, dtype=torch.bfloat16).train()
+    xs = [x.cuda() for x in images(B, 5)]
+    net = m.native_net(B, 256, 128)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dl = torch.randn(18, B, C, generator=g, device="cuda") * 1e-2
+    df = torch.randn(3, B, 768, generator=g, device="cuda") * 1e-2
+    m._bump_counters()
+    net.forward(xs, training=True)
+    net.backward(dl, df)
+    torch.cuda.synchronize()
+    ref = m._flat_grads.clone()
+    m._flat_grads.zero_()
+    net.forward(xs, training=True)
+    for part in range(5):
+        net.backward_part_async(dl, df, part)
+    L.check(lib.ieee_net_sync_streams(net.handle, L.stream()))
+    after = m._flat_grads.clone()            # a copy enqueued on the caller's stream, behind the join
+    torch.cuda.synchronize()
+    runs = m.trainable_runs()
+    assert all(torch.equal(after[a:b], ref[a:b]) for a, b in runs)
+    assert float(ref.abs().max()) > 0
