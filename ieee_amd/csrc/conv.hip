@@ -440,9 +440,9 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
 // all three column shifts (checked exhaustively over the instruction's 16-lane groups).  The halo cells are zeroed once:
 // the DMA only ever writes pixels that exist.
 // Forward and dgrad (of a stride-1 conv) are the same kernel: the dgrad reads dY with the taps mirrored (g.sgn < 0: tap
-// (dr, ds) pairs with weight column 8 - t of Wd).  STYLE 0: one LDS stage for the weights, two barriers per k-tile, small
-// register footprint (4 workgroups per CU); STYLE 1: all fragments of a k-tile are pulled into registers first, so the
-// next k-tile's DMA runs under this tile's MFMAs (3 workgroups per CU).
+// (dr, ds) pairs with weight column 8 - t of Wd).  Both styles pull all fragments of a k-tile into registers first, so the
+// next DMA runs under this tile's MFMAs.  STYLE 1: one weight stage (the tile of tap t + 1 is issued at tap t and waited
+// for at once at tap t + 1).  STYLE 0: two weight stages, the tile of tap t + 2 issued at tap t (a whole tap period to land).
 template <int WLOG> struct PatchGeom {
   static constexpr int Wm = 1 << WLOG, RT = 128 / Wm;
   static constexpr int PITCH = (Wm + 2) * 128;
@@ -452,7 +452,7 @@ template <int WLOG> struct PatchGeom {
 };
 
 template <int BN, int MODE, int WLOG, int STYLE>
-__global__ __launch_bounds__(256, STYLE == 0 ? 4 : 3) void conv3x3_patch_kernel(const bf16* __restrict__ src, const bf16* __restrict__ w,
+__global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const bf16* __restrict__ src, const bf16* __restrict__ w,
                                                                               bf16* __restrict__ dst, const bf16* __restrict__ addend,
                                                                               float* __restrict__ bn_partial, ConvArgs a, BwdStats bs) {
   typedef PatchGeom<WLOG> PG;
@@ -541,6 +541,62 @@ __global__ __launch_bounds__(256, STYLE == 0 ? 4 : 3) void conv3x3_patch_kernel(
   const int nch = Cs >> 6;
 
   __syncthreads();          // the zeroed halo is in place before the first DMA lands
+  if constexpr (STYLE == 0) {
+    // two weight stages, up to two k-tiles in flight: the weights of tap t + 2 are issued as soon as every wave holds the
+    // fragments of tap t, so each tile has a whole tap period (fragment reads + 16-32 MFMAs) to land before its counted wait.
+    // vmcnt order per wave: [B(t+1)] [patch of the next chunk, issued at tap 8] [B(t+2)] -- "all but my youngest BCH" retires
+    // the tile about to be read and, at a chunk boundary, the patch.
+    constexpr int BCH = BN / 32;
+    auto issue_b2 = [&](int q, int tap, int buf) {
+      const int tb = flip ? 8 - tap : tap;
+      lb.base = wbase + ((int64_t)tb * Cs + q * 64) * 2;
+      glds16_lean<BCH>(lb.off, lb.base, bst + buf * (BN * 128) + (8 * wave_u) * 128);
+    };
+    issue_patch(0);
+    issue_b2(0, 0, 0);
+    issue_b2(0, 1, 1);
+    for (int q = 0; q < nch; ++q) {
+      const int par = q & 1;            // 9 taps per chunk: the stage of (q, tap) is (q + tap) & 1
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dri = tap / 3, dsi = tap % 3;
+        const bool lastq = q == nch - 1;
+        const bool more1 = !(lastq && tap == 8), more2 = !(lastq && tap >= 7);   // a tile t+1 / t+2 exists
+        if (more1) wait_vmcnt<BCH>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const int buf = (tap & 1) ^ par;
+        const char* Bs = Bt + buf * (BN * 128);
+        Img::Frag fa[2][FM], fb[2][FN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+            fa[kk][i] = __builtin_bit_cast(bf16x8, *(const uint4*)(patch + abase[dsi][kk] + a_imm(i, dri)));
+#pragma unroll
+          for (int j = 0; j < FN; ++j) fb[kk][j] = Img::frag(Bs, j * 16, kk, lane);
+        }
+        if (more2 || (tap == 8 && !lastq)) {
+          __syncthreads();                // every wave holds its fragments: this stage (and, at tap 8, the patch) is free
+          if (tap == 8 && !lastq) issue_patch(q + 1);
+          if (more2) {
+            if (tap >= 7) issue_b2(q + 1, tap - 7, buf);
+            else issue_b2(q, tap + 2, buf);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[kk][j], fa[kk][i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(acc[i][j]));
+      }
+    }
+  } else {
   issue_patch(0);
   issue_b(0, 0);
   for (int q = 0; q < nch; ++q) {
@@ -550,26 +606,7 @@ __global__ __launch_bounds__(256, STYLE == 0 ? 4 : 3) void conv3x3_patch_kernel(
       const bool last = (q == nch - 1) && (tap == 8);
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();       // this k-tile (and, at tap 0, the patch) has landed for every wave
-      if constexpr (STYLE == 0) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          Img::Frag fa[FM], fb[FN];
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-            fa[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(patch + abase[dsi][kk] + a_imm(i, dri)));
-#pragma unroll
-          for (int j = 0; j < FN; ++j) fb[j] = Img::frag(Bt, j * 16, kk, lane);
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
-        }
-        if (!last) {
-          __builtin_amdgcn_s_barrier();   // every wave is done reading the weight stage (and, at tap 8, the patch)
-          if (tap == 8) { issue_patch(q + 1); issue_b(q + 1, 0); }
-          else issue_b(q, tap + 1);
-        }
-      } else {
+      {
         Img::Frag fa[2][FM], fb[2][FN];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -600,13 +637,14 @@ __global__ __launch_bounds__(256, STYLE == 0 ? 4 : 3) void conv3x3_patch_kernel(
       }
     }
   }
+  }
   epi.template finish<128, BN, FM, FN>(acc, smem, m0, n0);
 }
 
 template <int BN, int MODE, int WLOG, int STYLE>
 static void launch_patch_inst(dim3 grid, hipStream_t st, const bf16* src, const bf16* w, bf16* dst, const bf16* addend,
                               float* bn_partial, const ConvArgs& a, const BwdStats& bs) {
-  const size_t smem = PatchGeom<WLOG>::BYTES + (size_t)BN * 128;
+  const size_t smem = PatchGeom<WLOG>::BYTES + (size_t)BN * 128 * (STYLE == 0 ? 2 : 1);   // STYLE 0: two weight stages
   conv3x3_patch_kernel<BN, MODE, WLOG, STYLE><<<grid, 256, smem, st>>>(src, w, dst, addend, bn_partial, a, bs);
 }
 template <int BN, int WLOG, int STYLE>
