@@ -300,12 +300,6 @@ __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distm
   __shared__ uint32_t removed[RANK_CAP];
   __shared__ uint32_t hist[HIST + 512];          // slack: the scan reads whole per-thread spans
   __shared__ uint32_t cellinfo[RANK_CELLS];      // first key index of the cell | keys in the cell << 16
-  // round 3: a streamed element used to make TWO bank-conflicted LDS accesses (the cellinfo gather over 512 words, then the
-  // histogram atomic; SQ_LDS_BANK_CONFLICT share 0.55).  Most cells hold no match key: a 16-word bitmap of the cells that
-  // do (a gather over 16 addresses in 16 banks: conflict-free) sends those elements straight to one atomic on a per-cell
-  // counter, folded into `hist` after the stream; only elements that share a cell with a key take the exact path.
-  __shared__ uint32_t cellbits[RANK_CELLS / 32];
-  __shared__ uint32_t cellhist[RANK_CELLS];
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t counts[2];
   __shared__ double dsum[256];
@@ -354,8 +348,7 @@ __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distm
   for (uint32_t i = nb + t; i < np2; i += 256) keys[i] = ~0ull;
   const uint32_t hlen = RANK_CELLS + nb + 2;
   for (uint32_t i = t; i < hlen + 512; i += 256) hist[i] = 0;
-  for (uint32_t i = t; i < RANK_CELLS; i += 256) { cellinfo[i] = 0; cellhist[i] = 0; }
-  if (t < RANK_CELLS / 32) cellbits[t] = 0;
+  for (uint32_t i = t; i < RANK_CELLS; i += 256) cellinfo[i] = 0;
   __syncthreads();
   for (uint32_t k = 2; k <= np2; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -383,11 +376,7 @@ __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distm
     uint32_t tot;
     uint32_t run = block_scan_excl(sum, wsum, &tot);
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
-      cellinfo[t * PER + e] = run | (c[e] << 16);
-      run += c[e];
-      if (c[e]) atomicOr(&cellbits[(t * PER + e) >> 5], 1u << ((t * PER + e) & 31));
-    }
+    for (int e = 0; e < PER; ++e) { cellinfo[t * PER + e] = run | (c[e] << 16); run += c[e]; }
   }
   __syncthreads();
   // slot of an element, or -1 when it lies after every match (no rank depends on it).  Float compares decide
@@ -411,10 +400,6 @@ __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distm
   };
   uint32_t below = 0;
   auto visit = [&](float d, int k) {
-    if (d > dmax) return;                          // after every match: no rank depends on it (NaN falls through to the exact path)
-    if (d < dmin) { ++below; return; }
-    const uint32_t c = rank_cell(d, dmin, scale);
-    if (!((cellbits[c >> 5] >> (c & 31)) & 1u)) { atomicAdd(&cellhist[c], 1u); return; }   // a cell without match keys
     const int sl = slot_of(d, k);
     if (sl > 0) atomicAdd(&hist[sl], 1u);
     else if (sl == 0) ++below;
@@ -440,13 +425,6 @@ __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distm
   }
   for (int k = kdone + t; k < num_g; k += 256) visit(row[k], k);
   if (below) atomicAdd(&hist[0], below);
-  __syncthreads();
-  // fold the per-cell counters in: a keyless cell's elements all belong to slot 1 + c + (keys before the cell), and no two
-  // keyless cells share a slot (a keyed cell's top slot may coincide with the next cell's: same gap between two keys)
-  for (uint32_t c = t; c < RANK_CELLS; c += 256) {
-    const uint32_t n = cellhist[c];
-    if (n) atomicAdd(&hist[1 + c + (cellinfo[c] & 0xffffu)], n);
-  }
   __syncthreads();
   // ---- take the removed entries (rank.py:136-137) out of the slots the stream counted them in
   for (uint32_t i = t; i < nr; i += 256) {
