@@ -295,10 +295,13 @@ def main():
     ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
     traffic = traffic_src = None
     if args.dtype == "bf16" and B == 64:
-        traffic, traffic_src = committed_traffic("conv_gather")
+        traffic, traffic_src = committed_traffic("conv_fwd_dgrad")          # gather + LDS-patch + direct-stem launches (round 3)
+        if traffic is None:
+            traffic, traffic_src = committed_traffic("conv_gather")
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "conv_gather_kernel (implicit-GEMM forward + dgrad)",
+                "kernel": "conv forward + dgrad launches: conv_gather_kernel (implicit GEMM), conv3x3_patch_kernel (3x3 from an "
+                          "LDS-resident patch), stem_conv_kernel",
                 "launches": int(g_n), "avg_launch_us": g_ms * 1e3 / max(g_n, 1),
                 "flops_per_launch": g_fl / max(g_n, 1),
                 "wgrad": {"achieved": (w_fl / (w_ms * 1e-3) / 1e12) if w_ms > 0 else 0.0, "launches": int(w_n),

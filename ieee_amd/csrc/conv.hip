@@ -1525,9 +1525,13 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
       return launch_status("stem_conv_kernel");
     }
     if (!slow && plan.bn != 256 && !bs.addend_s2 && patch_eligible(a.g, M)) {
-      static const int f_style = getenv("IEEE_PATCH_STYLE") ? atoi(getenv("IEEE_PATCH_STYLE")) : 1;
+      static const int f_style_env = getenv("IEEE_PATCH_STYLE") ? atoi(getenv("IEEE_PATCH_STYLE")) : -1;
       static const int f_bn = getenv("IEEE_PATCH_BN") ? atoi(getenv("IEEE_PATCH_BN")) : 0;
       const int bn = (N <= 64) ? 64 : (f_bn ? f_bn : plan.bn);
+      // measured per layer (scripts/scan_r3g.sh): the two-stage weight ring wins where the tile is 128 x 64 (39 KB of LDS keeps
+      // 4 workgroups per CU: 256->256 755 -> 923 TFLOP/s, 64->64 608 -> 650) and loses at 128 x 128 (55 KB -> 2 per CU:
+      // 512->512 1 320 -> 1 234, 128->128 871 -> 767)
+      const int f_style = f_style_env >= 0 ? f_style_env : (bn == 64 ? 0 : 1);
       a.tiles_n = cdiv(N, bn);
       dim3 pgrid(a.tiles_m * a.tiles_n, groups);
       const int wlog = a.g.Ws == 8 ? 3 : (a.g.Ws == 16 ? 4 : 5);

@@ -19,8 +19,8 @@ import os
 import sys
 
 FAMILIES = (
-    ("conv_patch", "conv3x3_patch_kernel"), ("conv_wgrad_patch", "conv3x3_wgrad_patch_kernel"), ("stem", "stem_conv_kernel"),
-    ("stem", "stem_wgrad_kernel"), ("conv_gather", "conv_gather_kernel"), ("conv_wgrad", "conv_wgrad_kernel"), ("wgrad_reduce", "wgrad_reduce_kernel"),
+    ("conv_patch", "conv3x3_patch_kernel"), ("conv_wgrad_patch", "conv3x3_wgrad_patch_kernel"), ("stem_fwd", "stem_conv_kernel"),
+    ("stem_wgrad", "stem_wgrad_kernel"), ("conv_gather", "conv_gather_kernel"), ("conv_wgrad", "conv_wgrad_kernel"), ("wgrad_reduce", "wgrad_reduce_kernel"),
     ("bn_apply", "bn_apply_kernel"), ("bn_bwd_apply", "bn_bwd_apply_kernel"), ("bn_bwd_reduce", "bn_bwd_reduce_kernel"),
     ("bn_finalize", "bn_finalize_kernel"), ("bn_finalize", "bn_bwd_finalize_kernel"), ("distmat_f16split", "distmat_kernel<bool _Accum"),
     ("distmat_f16split", "distmat_kernelIDF16bLb1"), ("distmat_bf16", "distmat_kernelIDF16b"), ("distmat_fp32", "distmat_kernel<float"),
@@ -96,6 +96,12 @@ def main():
         res[fam] = e
     if step_launches:
         # whole train step: every kernel's 2 * FETCH_SIZE + WRITE_SIZE, divided by the steps seen (one margin3m launch each)
+        # the bench line's dominant kernel = every forward / dgrad conv launch (gather + LDS-patch + direct stem forms)
+        fd = [k for k in ("conv_gather", "conv_patch", "stem_fwd") if k in res]
+        n_fd = sum(res[k]["launches"] for k in fd)
+        if n_fd and all("hbm_bytes_per_launch" in res[k] for k in fd):
+            res["conv_fwd_dgrad"] = {"launches": n_fd, "families": fd,
+                                     "hbm_bytes_per_launch": sum(res[k]["hbm_bytes_per_launch"] * res[k]["launches"] for k in fd) / n_fd}
         res["_step"] = {"train_steps": step_launches,
                         "hbm_bytes_per_step": (2.0 * step_fetch + step_write) * 1024.0 / step_launches,
                         "by_family": {k: v / step_launches for k, v in sorted(fam_bytes.items())}}
