@@ -423,17 +423,19 @@ extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int
   RedGeom g = red_geom(M, (int)C, vec_of(dtype));
   if (stats_rblocks > 0) g.rblocks = (int)stats_rblocks;   // partial sums already emitted by the producing conv
   const int64_t partial_gs = (int64_t)g.rblocks * 2 * C;
-  if (training && stats_rblocks <= 0) {
+  if (training && stats_rblocks == 0) {
     dim3 grid(g.cblocks * g.rblocks, (unsigned)groups);
     if (dtype == IEEE_F32) bn_stats_kernel<float><<<grid, 256, 0, st>>>((const float*)y, act_gs, g, partial, partial_gs);
     else bn_stats_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y, act_gs, g, partial, partial_gs);
     IEEE_TRY(launch_status("bn_stats_kernel"));
   }
-  const int lpc = training ? finalize_lpc(g.rblocks) : 32;
-  bn_finalize_kernel<<<dim3(cdiv(C, 256 / lpc), (unsigned)groups), 256, 0, st>>>(
-      partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, beta, param_gs, running_mean, running_var, buf_gs, stats,
-      4 * C, momentum, eps, training, stats_rblocks > 0 ? 1 : 0, lpc);
-  IEEE_TRY(launch_status("bn_finalize_kernel"));
+  if (!(training && stats_rblocks < 0)) {   // stats_rblocks < 0: the producing conv finalized `stats` itself (ieee_conv2d_fwd_bn_train)
+    const int lpc = training ? finalize_lpc(g.rblocks) : 32;
+    bn_finalize_kernel<<<dim3(cdiv(C, 256 / lpc), (unsigned)groups), 256, 0, st>>>(
+        partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, beta, param_gs, running_mean, running_var, buf_gs, stats,
+        4 * C, momentum, eps, training, stats_rblocks > 0 ? 1 : 0, lpc);
+    IEEE_TRY(launch_status("bn_finalize_kernel"));
+  }
   if (out == nullptr) return IEEE_OK;   // statistics only: the consumer applies scale/shift itself
   const int64_t chunks = M * C / vec_of(dtype);
   dim3 grid(ew_blocks(chunks), (unsigned)groups);

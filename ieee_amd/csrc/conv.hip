@@ -57,6 +57,26 @@ template <typename T> struct StoreEpi {
   }
 };
 
+// Train-mode BatchNorm finalize inside the conv that produced the sums (round 3): the workgroup that arrives LAST at a
+// column block's ticket reduces that block's per-tile partial sums (fixed tile order: deterministic) and writes the
+// unit's mean / invstd / scale / shift and running statistics, so no finalize launch sits between the conv and the
+// BatchNorm apply.  Protocol (platform guide, split-K reduction recipe): every workgroup stores its partials write-through
+// (sc1), every wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, lane 0 takes a ticket (relaxed, agent scope);
+// the last arriver's lane 0 runs ONE agent-scope acquire, waits for it, workgroup barrier, plain loads.  Only for launches
+// of at most FIN_MAX_TILES row tiles per modality (one workgroup reads 2 x 128 x tiles partials: 64 KB at 64 tiles).
+constexpr int FIN_MAX_TILES = 64;
+struct BnFin {
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float* rm = nullptr;         // running mean / var (may be null)
+  float* rv = nullptr;
+  float* stats = nullptr;      // [groups][4][C]
+  int* counter = nullptr;      // [groups][tiles_n] tickets, zero before the launch; the last arriver resets its own
+  int64_t param_gs = 0, buf_gs = 0;
+  float momentum = 0.f, eps = 0.f;
+  int M = 0, on = 0;
+};
+
 // Tile epilogue through LDS: the accumulators (4 consecutive channels of one pixel per lane) are written
 // to an LDS image of the C tile, then every thread stores full 16-byte, row-contiguous chunks (a wave
 // instruction covers 4 rows x 256 B) instead of 8-byte pieces scattered over 16 rows.  Optionally adds a
@@ -91,6 +111,8 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
   // (pwc = Wo/2 is a power of two on this path: pwl = log2; a tensor of one modality has < 2^31 elements)
   int pwc = 0, pwl = 0, pW = 0, pimg = 0, phc = 0, pnimg = 0;
   int as_wl = 0, as_hl = 0;   // VAR 2: log2 of this map's width / height (powers of two on this path)
+  BnFin fin;                  // MODE 1: finalize the BatchNorm statistics in this kernel (pointers already at this group)
+  int tn = 0;                 // column-block index (ticket slot)
   __device__ __forceinline__ int tile_pixel0(int m0) const {   // pixel of the tile's first row (class offsets included)
     const int per_img = phc * pwc, per_cls = pnimg * per_img;
     const int cls = m0 / per_cls, rc = m0 - cls * per_cls, n = rc / per_img, i0 = (rc - n * per_img) >> pwl;
@@ -265,6 +287,7 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { red[e * PLANE + t] = s1[e]; red[(VEC + e) * PLANE + t] = s2[e]; }
       __syncthreads();
+      const bool fuse = MODE == 1 && fin.on;
       for (int idx = t; idx < BN * 2; idx += 256) {
         const int q = idx / BN, c = idx % BN;          // quantity, channel within the tile
         const int cc = c / VEC, e = c % VEC;
@@ -272,7 +295,60 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
         float s = 0.f;
 #pragma unroll
         for (int y = 0; y < RPP; ++y) s += col[y * CPRW];
-        if (n0 + c < N && tile_m < tiles_m) bn_partial[((int64_t)q * N + n0 + c) * tiles_m + tile_m] = s;
+        if (n0 + c < N && tile_m < tiles_m) {
+          float* dstp = bn_partial + ((int64_t)q * N + n0 + c) * tiles_m + tile_m;
+          if (fuse) __hip_atomic_store(dstp, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
+          else *dstp = s;
+        }
+      }
+      if constexpr (MODE == 1) {
+        if (fuse) {
+          int* flag = (int*)(red + 2 * VEC * PLANE);          // one word behind the reduction planes (dynamic LDS)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores (partials and output tile) have left
+          __syncthreads();
+          if (t == 0) {
+            const int ticket = __hip_atomic_fetch_add(fin.counter + tn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = ticket == tiles_m - 1;
+          }
+          __syncthreads();
+          if (*flag) {                                          // workgroup-uniform: every other workgroup of this column is done
+            if (t == 0) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              __hip_atomic_store(fin.counter + tn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            __syncthreads();
+            double* dred = (double*)smem;                        // [2][BN] sums (the planes are consumed)
+            __syncthreads();
+            for (int idx = t; idx < BN * 2; idx += 256) {
+              const int q = idx / BN, c = idx % BN;
+              double sum = 0.0;
+              if (n0 + c < N) {
+                const float* pp = bn_partial + ((int64_t)q * N + n0 + c) * tiles_m;
+                for (int rt = 0; rt < tiles_m; ++rt) sum += (double)pp[rt];     // fixed order: the same bits whoever is last
+              }
+              dred[idx] = sum;
+            }
+            __syncthreads();
+            if (t < BN && n0 + t < N) {
+              const int c = n0 + t;
+              const double mu = dred[t] / fin.M;
+              double var = dred[BN + t] / fin.M - mu * mu;
+              if (var < 0) var = 0;
+              const float mean = (float)mu, invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+              if (fin.rm != nullptr) {
+                const double unbiased = fin.M > 1 ? var * ((double)fin.M / (double)(fin.M - 1)) : var;
+                fin.rm[c] = (1.f - fin.momentum) * fin.rm[c] + fin.momentum * mean;
+                fin.rv[c] = (1.f - fin.momentum) * fin.rv[c] + fin.momentum * (float)unbiased;
+              }
+              const float sc = fin.gamma[c] * invstd;
+              fin.stats[c] = mean;
+              fin.stats[N + c] = invstd;
+              fin.stats[2 * N + c] = sc;
+              fin.stats[3 * N + c] = fin.beta[c] - mean * sc;
+            }
+          }
+        }
       }
     }
   }
@@ -354,7 +430,20 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
   int relu;                  // MODE 3 only
   int mask_bits = 0;         // MODE 2: `mask` is the packed bit form (one byte per 8 channels)
   int addend_s2 = 0;         // MODE 2: the addend is compact at stride 2 (StagedStoreEpi VAR 2)
+  BnFin fin;                 // MODE 1: fused BatchNorm finalize (group-0 pointers; the kernels step them by blockIdx.y)
 };
+
+// MODE 1: hand the epilogue its group's finalize operands
+template <class Epi> __device__ __forceinline__ void set_fin(Epi& epi, const BwdStats& bs, int z, int tn, int tiles_n, int N) {
+  if (!bs.fin.on) return;
+  epi.fin = bs.fin;
+  epi.fin.gamma += z * bs.fin.param_gs;
+  epi.fin.beta += z * bs.fin.param_gs;
+  if (bs.fin.rm != nullptr) { epi.fin.rm += z * bs.fin.buf_gs; epi.fin.rv += z * bs.fin.buf_gs; }
+  epi.fin.stats += (int64_t)z * 4 * N;
+  epi.fin.counter += z * tiles_n;
+  epi.tn = tn;
+}
 
 // (forcing 4 waves per SIMD here spills 80 VGPRs and is 2.5x slower; the default allocation gives 3)
 // PIPE = 0: register staging, one LDS stage (high occupancy: the many-workgroup layers).  PIPE = 2..4: LDS-DMA ring
@@ -379,6 +468,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
                               (MODE == 2 && bs.mask && !bs.mask_bits) ? (const T*)bs.mask + z * bs.act_gs : nullptr,
                               ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
   if constexpr (MODE == 3) epi.relu = bs.relu;
+  if constexpr (MODE == 1) set_fin(epi, bs, z, tn, a.tiles_n, a.N);
   if constexpr (VAR == 2) { epi.as_wl = __ffs(a.g.Wo) - 1; epi.as_hl = __ffs(a.g.Ho) - 1; }
   if constexpr (MODE == 2) {
     if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
@@ -471,6 +561,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const bf16* __res
                                     (MODE == 2 && bs.mask && !bs.mask_bits) ? (const bf16*)bs.mask + z * bs.act_gs : nullptr,
                                     ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
   if constexpr (MODE == 3) epi.relu = bs.relu;
+  if constexpr (MODE == 1) set_fin(epi, bs, z, tn, a.tiles_n, a.N);
   if constexpr (MODE == 2) {
     if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
   }
@@ -1462,7 +1553,8 @@ static GatherPlan plan_gather(int M, int N, int ktiles, int groups) {
 template <typename T>
 static int launch_gather(const T* src, const T* w, T* dst, const T* addend, const GatherGeom& g, int M, int N,
                          int Ktrue, int ldw, int groups, int64_t src_gs, int64_t w_gs, int64_t dst_gs, bool slow,
-                         hipStream_t st, float* bn_partial = nullptr, const BwdStats* bwd = nullptr, bool affine = false) {
+                         hipStream_t st, float* bn_partial = nullptr, const BwdStats* bwd = nullptr, bool affine = false,
+                         const BnFin* fin = nullptr) {
   const int BK = ImgNT<T>::BK;
   ConvArgs a;
   a.g = g;
@@ -1510,6 +1602,14 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   }
   BwdStats bs{nullptr, nullptr, nullptr, 0, 0, 0};
   if (bwd) bs = *bwd;
+  if (fin != nullptr && fin->on) {
+    if (!(sizeof(T) == 2 && !slow && stats && !bwd && !affine && cdiv(M, 128) <= FIN_MAX_TILES && a.g.Cs != 4)) {
+      set_error(IEEE_ERR_UNSUPPORTED, "conv: the fused BatchNorm finalize needs the bf16 training form with at most %d row tiles", FIN_MAX_TILES);
+      return IEEE_ERR_UNSUPPORTED;
+    }
+    bs.fin = *fin;
+    bs.fin.M = M;
+  }
   if (affine && slow) {
     set_error(IEEE_ERR_UNSUPPORTED, "conv: the fused inference BatchNorm needs the vector path");
     return IEEE_ERR_UNSUPPORTED;
@@ -1704,6 +1804,30 @@ extern "C" int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int
     return launch_gather<bf16>((const bf16*)x, (const bf16*)w_packed, (bf16*)y, nullptr, g, g.npix, d.Co,
                                d.R * d.S * d.Ci, ldw, (int)groups, x_gs, w_gs, y_gs, slow, st, bn_partial);
   IEEE_REQUIRE(false, "conv2d_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int64_t ieee_conv2d_fwd_bn_train_max_rows(void) { return (int64_t)FIN_MAX_TILES * 128; }
+
+extern "C" int ieee_conv2d_fwd_bn_train(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N,
+                                        int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride,
+                                        int64_t pad, int64_t x_gs, int64_t w_gs, int64_t y_gs, float* bn_partial,
+                                        const float* gamma, const float* beta, int64_t param_gs, float* running_mean,
+                                        float* running_var, int64_t buf_gs, float* stats, float momentum, float eps,
+                                        int32_t* tickets, void* stream) {
+  IEEE_REQUIRE(x && w_packed && y && bn_partial && gamma && beta && stats && tickets, "conv2d_fwd_bn_train: null pointer");
+  IEEE_REQUIRE(dtype == IEEE_BF16, "conv2d_fwd_bn_train: bf16 only");
+  Dims d;
+  IEEE_TRY(check_dims("conv2d_fwd_bn_train", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
+  IEEE_REQUIRE(Co % 8 == 0 && Ci % 64 == 0, "conv2d_fwd_bn_train: Cin %% 64, Cout %% 8");
+  IEEE_REQUIRE((int64_t)d.N * d.Ho * d.Wo <= ieee_conv2d_fwd_bn_train_max_rows(), "conv2d_fwd_bn_train: more than %ld output pixels",
+               (long)ieee_conv2d_fwd_bn_train_max_rows());
+  GatherGeom g{d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.R, d.S, d.stride, -d.pad, +1, 1, d.N * d.Ho * d.Wo};
+  const int ldw = (int)ieee_conv_packed_ld(dtype, Ci, R, S);
+  BnFin fin;
+  fin.gamma = gamma; fin.beta = beta; fin.rm = running_mean; fin.rv = running_var; fin.stats = stats; fin.counter = (int*)tickets;
+  fin.param_gs = param_gs; fin.buf_gs = buf_gs; fin.momentum = momentum; fin.eps = eps; fin.on = 1;
+  return launch_gather<bf16>((const bf16*)x, (const bf16*)w_packed, (bf16*)y, nullptr, g, g.npix, d.Co, d.R * d.S * d.Ci, ldw,
+                             (int)groups, x_gs, w_gs, y_gs, false, (hipStream_t)stream, bn_partial, nullptr, false, &fin);
 }
 
 extern "C" int ieee_conv2d_fwd_bn_eval(const void* x, const void* w_packed, void* out, const void* residual,

@@ -71,6 +71,7 @@ struct Net {
   size_t ws_bytes = 0;
   std::map<std::string, Tensor> tensors;
   Tensor x0, pool, pool_arg, S, gbuf[10], slab, bnpart, bncoef, bnpart2, bncoef2, packtab, gemm_work;
+  Tensor tickets;   // 2 x 256 int32: arrival tickets of the convs that finalize their BatchNorm themselves (launch / branch stream)
   std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
   int pack_blocks_train = 0, pack_blocks_eval = 0;
   // training: the layer3 / layer4 / CIM operands (90 % of the bytes) are packed on the side stream while the
@@ -254,6 +255,7 @@ extern "C" int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, 
                                                      int64_t Ci, int64_t Co, int64_t R, int64_t S);
 extern "C" int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C);
 extern "C" int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t Wo);
+extern "C" int64_t ieee_conv2d_fwd_bn_train_max_rows(void);
 
 void Net::plan() {
   ws_bytes = 0;
@@ -331,6 +333,7 @@ void Net::plan() {
   davgmax = alloc("davgmax", 3 * 2 * Bq * fdim, IEEE_F32);
   remwork = alloc("", 3 * Bq + 64, IEEE_F32);
   gemm_work = alloc("", (int64_t)8 << 20, IEEE_F32);   // split-K slabs of the head GEMMs (32 MiB)
+  tickets = alloc("", 512, IEEE_F32);
   packtab = alloc("", (int64_t)(5 * units.size() + 8) * sizeof(PackDescHost) / 4, IEEE_F32);
 }
 
@@ -341,9 +344,11 @@ struct Run {
   void* st;
   int B;
   float *bnpart_cur, *bncoef_cur;      // BN scratch of the stream `st` currently denotes (see BranchScope)
+  int32_t* tickets_cur;
   Run(Net& net, void* workspace, void* stream) : n(net), ws((char*)workspace), st(stream), B(net.B) {
     bnpart_cur = (float*)(ws + net.bnpart.off);
     bncoef_cur = (float*)(ws + net.bncoef.off);
+    tickets_cur = (int32_t*)(ws + net.tickets.off);
   }
   void* P(const Tensor& t) const { return ws + t.off; }
   float* F(const Tensor& t) const { return (float*)(ws + t.off); }
@@ -402,17 +407,26 @@ struct Run {
   int64_t out_numel(const ConvUnit& u) const { return (int64_t)3 * u.M(B) * u.Co; }
   // fused_stats: the conv epilogue emits the BN partial sums (bf16 training path) -> bn() skips its stats pass
   bool fused_stats = false;
+  bool fused_fin = false;    // ... and finalized them too (ieee_conv2d_fwd_bn_train): bn() only applies
   int conv(const ConvUnit& u, const void* in, bool want_stats = false) {
     const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
     fused_stats = want_stats && n.dtype == IEEE_BF16;
+    static const bool f_fin = !(getenv("IEEE_BN_FIN_FUSE") && atoi(getenv("IEEE_BN_FIN_FUSE")) == 0);
+    fused_fin = f_fin && fused_stats && u.M(B) <= ieee_conv2d_fwd_bn_train_max_rows() && u.Ci % 64 == 0 && u.Co % 8 == 0;
     prof_begin(0, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
+    if (fused_fin)
+      return ieee_conv2d_fwd_bn_train(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
+                                      (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, bnpart_cur, par(u.s_g), par(u.s_b),
+                                      gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), n.bn_mom, n.bn_eps, tickets_cur, st);
     return ieee_conv2d_fwd(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
                            (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, fused_stats ? bnpart_cur : nullptr, st);
   }
   int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training, void* relu_bits = nullptr) {
-    const int64_t rb = (training && fused_stats) ? ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) : 0;
+    const int64_t rb = (training && fused_fin) ? -1 : ((training && fused_stats) ? ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) : 0);
     fused_stats = false;
+    fused_fin = false;
+    if (rb < 0 && out == nullptr) return IEEE_OK;   // statistics only, and the conv has already finalized them: nothing to launch
     return ieee_bn2d_fwd(P(u.y), residual, out, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b),
                          gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), bnpart_cur, n.bn_mom, n.bn_eps,
                          training, relu, rb, relu_bits, st);
@@ -520,6 +534,7 @@ struct Run {
       r.st = (void*)r.n.side2;
       r.bnpart_cur = (float*)(r.ws + r.n.bnpart2.off);
       r.bncoef_cur = (float*)(r.ws + r.n.bncoef2.off);
+      r.tickets_cur = (int32_t*)(r.ws + r.n.tickets.off) + 256;
       r.fused_stats = false;
       r.fused_bwd = false;
     }
@@ -528,6 +543,7 @@ struct Run {
       r.st = main_st;
       r.bnpart_cur = part0;
       r.bncoef_cur = coef0;
+      r.tickets_cur = (int32_t*)(r.ws + r.n.tickets.off);
       r.fused_stats = fs;
       r.fused_bwd = fb;
     }
@@ -669,6 +685,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
       IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev, (int64_t)N.pack_eval.size(), N.pack_blocks_eval, dt, st));
     if (training) N.eval_cache_valid = false;     // the step that follows changes parameters and running statistics
   }
+  if (training) IEEE_HIP(hipMemsetAsync(P(N.tickets), 0, 512 * 4, (hipStream_t)st));   // arrival tickets of the fused finalizes
   IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, 4, 3, st));
   // stem: conv7x7/2 -> BN -> ReLU -> maxpool3x3/2   (resnet.py:622-626)
   const ConvUnit& s = N.units[N.u_stem];

@@ -126,6 +126,18 @@ int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int dtype, int
  * sum / sum-of-squares of the stored outputs, rblocks = ieee_conv2d_fwd_stats_rblocks(); hand the same buffer
  * and rblocks to ieee_bn2d_fwd(stats_rblocks) and the separate statistics pass disappears */
 int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t Wo);
+/* Training forward with the consumer BatchNorm's FINALIZE fused in (bf16, at most ieee_conv2d_fwd_bn_train_max_rows() output
+ * pixels per group): besides y and the per-tile partial sums, the launch leaves that BatchNorm's stats [groups][4][Co] (mean,
+ * invstd, scale, shift) and updates the running statistics (running_* may be NULL) -- what ieee_bn2d_fwd's finalize step
+ * computes (resnet.py:164-184 under nn.BatchNorm2d in train mode); follow with ieee_bn2d_fwd(..., stats_rblocks = -1) for the
+ * apply pass only.  `tickets`: groups x ceil(Co / 64) int32, ZERO on entry (the launch leaves them zero again).  The
+ * workgroup that arrives last at a column block's ticket reduces that block's partials in tile order (deterministic). */
+int64_t ieee_conv2d_fwd_bn_train_max_rows(void);
+int ieee_conv2d_fwd_bn_train(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N, int64_t Hi,
+                             int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                             int64_t x_gs, int64_t w_gs, int64_t y_gs, float* bn_partial, const float* gamma,
+                             const float* beta, int64_t param_gs, float* running_mean, float* running_var, int64_t buf_gs,
+                             float* stats, float momentum, float eps, int32_t* tickets, void* stream);
 /* inference: conv + eval-mode BatchNorm (+ residual) (+ ReLU) in one launch -- Bottleneck.forward / the stem in eval
  * mode (resnet.py:164-184, 622-626).  bn_stats: that BN's [groups][4][Co] statistics as ieee_bn2d_fwd(training = 0,
  * out = NULL) leaves them (scale at 2*Co, shift at 3*Co); out = [relu](conv(x)*scale + shift [+ residual]). */
