@@ -270,3 +270,51 @@ def test_conv_with_fused_eval_batchnorm(dtype, res, relu):
     tol = dict(rtol=2e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
     for i in range(G):
         torch.testing.assert_close(out[i].float().cpu().permute(0, 3, 1, 2), want[i], **tol)
+
+
+@pytest.mark.parametrize("R,Ci,Co,H,W", [(1, 128, 320, 16, 8), (3, 64, 128, 16, 8), (3, 128, 64, 8, 16)])
+def test_conv_with_fused_train_batchnorm_finalize(R, Ci, Co, H, W):
+    """ieee_conv2d_fwd_bn_train (the BatchNorm finalize done by the last-arriving workgroup of each column block) against
+    the two-launch form -- ieee_conv2d_fwd with partial sums + ieee_bn2d_fwd's finalize: same y bit for bit, the same
+    statistics / scale / shift / running statistics up to the summation order of the per-tile partials (float64 on both
+    sides), tickets left at zero; twice in a row (the second launch reuses the tickets the first one reset)."""
+    from ieee_amd import _lib as L, _ops
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(R * 100 + Co)
+    G, N = 3, 20                                        # M = 2560 rows: 20 row tiles
+    dt = torch.bfloat16
+    pad = R // 2
+    x = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
+    w = (torch.randn(G, Co, Ci, R, R, generator=g) * (2.0 / (Ci * R * R)) ** 0.5).cuda()
+    wp = _ops.pack_conv_weight(w, dt, 0)
+    M = N * H * W
+    assert M <= lib.ieee_conv2d_fwd_bn_train_max_rows()
+    rb = lib.ieee_conv2d_fwd_stats_rblocks(N, H, W)
+    gam, bet = torch.rand(G, Co, generator=g).cuda() + 0.5, torch.randn(G, Co, generator=g).cuda()
+    rm0, rv0 = torch.randn(G, Co, generator=g).cuda(), torch.rand(G, Co, generator=g).cuda() + 0.5
+    # two launches
+    part = torch.zeros(G, 2, Co, rb, device="cuda")
+    y_a = torch.empty(G, N, H, W, Co, device="cuda", dtype=dt)
+    L.check(lib.ieee_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(y_a), L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad, x[0].numel(),
+                                wp.stride(0), y_a[0].numel(), L.ptr(part), L.stream()))
+    st_a, rm_a, rv_a = torch.zeros(G, 4, Co, device="cuda"), rm0.clone(), rv0.clone()
+    L.check(lib.ieee_bn2d_fwd(L.ptr(y_a), None, None, L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co, L.ptr(rm_a),
+                              L.ptr(rv_a), Co, L.ptr(st_a), L.ptr(part), 0.1, 1e-5, 1, 1, rb, None, L.stream()))
+    # one launch, twice
+    tickets = torch.zeros(G * ((Co + 63) // 64), dtype=torch.int32, device="cuda")
+    for rep in range(2):
+        part_b = torch.zeros_like(part)
+        y_b = torch.empty_like(y_a)
+        st_b, rm_b, rv_b = torch.zeros_like(st_a), rm0.clone(), rv0.clone()
+        L.check(lib.ieee_conv2d_fwd_bn_train(L.ptr(x), L.ptr(wp), L.ptr(y_b), L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad,
+                                             x[0].numel(), wp.stride(0), y_b[0].numel(), L.ptr(part_b), L.ptr(gam), L.ptr(bet), Co,
+                                             L.ptr(rm_b), L.ptr(rv_b), Co, L.ptr(st_b), 0.1, 1e-5, L.ptr(tickets), L.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(y_a, y_b) and torch.equal(part, part_b)
+        assert int(tickets.abs().sum()) == 0
+        torch.testing.assert_close(st_b, st_a, rtol=2e-6, atol=1e-6)
+        torch.testing.assert_close(rm_b, rm_a, rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(rv_b, rv_a, rtol=2e-6, atol=1e-7)
+    # and the statistics are the batch statistics of the stored y
+    yf = y_a.float().view(G, M, Co)
+    torch.testing.assert_close(st_a[:, 0], yf.mean(1), rtol=1e-4, atol=1e-4)
