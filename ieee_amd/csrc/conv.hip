@@ -1986,7 +1986,13 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   // default: single-stage LDS-DMA (106 VGPRs -> 4 workgroups per CU): -6 % wgrad time over register staging at 3
   static const int f_pipe = getenv("IEEE_WGRAD_PIPE") ? atoi(getenv("IEEE_WGRAD_PIPE")) : 1;
   const int pipe = (dtype == IEEE_BF16 && !slow) ? f_pipe : 0;
-  const size_t smem = pipe ? (size_t)pipe * 32 * 1024 : (dtype == IEEE_BF16 ? 32 * 1024 : 64 * 1024);
+  // IEEE_WGRAD_LDS: dynamic LDS of the weight-gradient kernels in KB (>= what they use): caps their workgroups per CU, i.e. how
+  // much of every CU the low-priority stream may hold against the launch stream's kernels.  48 KB = 3 per CU instead of 4:
+  // each weight gradient alone is a little slower (511 vs 515 TFLOP/s serialized), the step is 0.15 ms faster (15.31 -> 15.16,
+  // five interleaved rounds): the dgrad / BatchNorm chain finds free slots sooner.  64 KB (2 per CU) loses (15.4).
+  static const size_t f_lds = (size_t)(getenv("IEEE_WGRAD_LDS") ? atoi(getenv("IEEE_WGRAD_LDS")) : 48) * 1024;
+  size_t smem = pipe ? (size_t)pipe * 32 * 1024 : (dtype == IEEE_BF16 ? 32 * 1024 : 64 * 1024);
+  if (smem < f_lds) smem = f_lds;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2021,8 +2027,8 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
     const int wlog = d.Wi == 8 ? 3 : (d.Wi == 16 ? 4 : 5);
     const bool half = d.Co == 64;
 #define IEEE_WP_CASE(W_) \
-    if (half) conv3x3_wgrad_patch_kernel<W_, true><<<pgrid, 256, 64 * 256 + WPatch<W_>::BYTES, st>>>((const bf16*)dy, (const bf16*)x, slab, pa); \
-    else conv3x3_wgrad_patch_kernel<W_, false><<<pgrid, 256, 64 * 256 + WPatch<W_>::BYTES, st>>>((const bf16*)dy, (const bf16*)x, slab, pa)
+    if (half) conv3x3_wgrad_patch_kernel<W_, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa); \
+    else conv3x3_wgrad_patch_kernel<W_, false><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa)
     if (wlog == 3) { IEEE_WP_CASE(3); } else if (wlog == 4) { IEEE_WP_CASE(4); } else { IEEE_WP_CASE(5); }
 #undef IEEE_WP_CASE
   } else if (dtype == IEEE_F32) {
