@@ -53,6 +53,14 @@ def _parse_header(path=HEADER_PATH):
 _SIGNATURES, _RESTYPE = _parse_header()
 
 
+class WgradReduceDesc(ctypes.Structure):
+    """struct ieee_wgrad_reduce_desc of include/ieee_amd.h (ieee_conv2d_wgrad_deferred / ieee_wgrad_reduce_batch)."""
+    _fields_ = [("slab", c_void_p), ("dw", c_void_p), ("slab_gs", c_int64), ("dw_gs", c_int64),
+                ("nsplit", ctypes.c_int32), ("Co", ctypes.c_int32), ("Ci", ctypes.c_int32), ("RS", ctypes.c_int32),
+                ("kind", ctypes.c_int32), ("sl_log2", ctypes.c_int32), ("blocks", ctypes.c_int32),
+                ("accumulate", ctypes.c_int32), ("block_begin", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+
+
 class IeeeAmdError(RuntimeError):
     pass
 

@@ -1201,15 +1201,13 @@ __global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wg
 // the lanes' sums are then added in lane order through LDS.  Threads walk the slab order, so the (dominant) slab
 // reads are coalesced; for 3x3 / 7x7 the 4-byte writes scatter.
 template <int VEC>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                           int splitk, int Co, int Ci, int RS, int64_t slab_gs,
-                                                           int64_t dw_gs, int accumulate, int sl_log2) {
-  __shared__ float part[256 * VEC];
-  const int z = blockIdx.y;
+__device__ __forceinline__ void wgrad_reduce_body(float* part, int bx, int z, const float* __restrict__ slab, float* __restrict__ dw,
+                                                  int splitk, int Co, int Ci, int RS, int64_t slab_gs, int64_t dw_gs,
+                                                  int accumulate, int sl_log2) {
   const int SL = 1 << sl_log2, per = 256 >> sl_log2;
   const int t = threadIdx.x, lane = t >> (8 - sl_log2), x = t & (per - 1);
   const int64_t total = (int64_t)Co * Ci * RS;
-  const int64_t i = ((int64_t)blockIdx.x * per + x) * VEC;    // index in slab order [co][rs][ci]
+  const int64_t i = ((int64_t)bx * per + x) * VEC;    // index in slab order [co][rs][ci]
   float acc[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
@@ -1255,18 +1253,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+template <int VEC>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                           int splitk, int Co, int Ci, int RS, int64_t slab_gs,
+                                                           int64_t dw_gs, int accumulate, int sl_log2) {
+  __shared__ float part[256 * VEC];
+  wgrad_reduce_body<VEC>(part, blockIdx.x, blockIdx.y, slab, dw, splitk, Co, Ci, RS, slab_gs, dw_gs, accumulate, sl_log2);
+}
+
 // The same reduction for the few-split layers with taps (3x3 of layer2-4): one block per (output channel, 128 input
 // channels).  The slab rows [rs][ci] are read as float4 along ci, turned through LDS, and the [ci][rs] run of the OIHW
 // gradient -- contiguous for a fixed output channel -- leaves as coalesced stores (the element-wise form above scatters
 // 4-byte stores RS floats apart: 70 us for the 512x512x3x3 gradients, 3x what their bytes need).  Splits are added in order.
 constexpr int RT_CIB = 128;
-__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                                int splitk, int Co, int Ci, int RS, int64_t slab_gs,
-                                                                int64_t dw_gs, int accumulate) {
-  extern __shared__ float tile[];   // [RT_CIB][RS]
-  const int z = blockIdx.y;
+__device__ __forceinline__ void wgrad_reduce_taps_body(float* tile /* [RT_CIB][RS] */, int bx, int z, const float* __restrict__ slab,
+                                                       float* __restrict__ dw, int splitk, int Co, int Ci, int RS, int64_t slab_gs,
+                                                       int64_t dw_gs, int accumulate) {
   const int cibs = (Ci + RT_CIB - 1) / RT_CIB;
-  const int co = blockIdx.x / cibs, ci0 = (blockIdx.x % cibs) * RT_CIB;
+  const int co = bx / cibs, ci0 = (bx % cibs) * RT_CIB;
   const int nci = min(RT_CIB, Ci - ci0);
   const int t = threadIdx.x;
   const int64_t total = (int64_t)Co * Ci * RS;
@@ -1287,6 +1291,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __r
   __syncthreads();
   float* d = dw + z * dw_gs + ((int64_t)co * Ci + ci0) * RS;
   for (int j = t; j < nci * RS; j += 256) d[j] = accumulate ? (d[j] + tile[j]) : tile[j];
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                int splitk, int Co, int Ci, int RS, int64_t slab_gs,
+                                                                int64_t dw_gs, int accumulate) {
+  extern __shared__ float tile[];   // [RT_CIB][RS]
+  wgrad_reduce_taps_body(tile, blockIdx.x, blockIdx.y, slab, dw, splitk, Co, Ci, RS, slab_gs, dw_gs, accumulate);
+}
+
+// One launch reduces the slabs of MANY weight gradients (a whole backward part): blockIdx.x walks a device-side table of
+// ieee_wgrad_reduce_desc (block_begin = prefix sums), blockIdx.y = modality.  53 latency-bound launches of 10-30 us on
+// the low-priority stream (1.6 ms of it in the step) become 5 launches that stream their 1.6 GB of slabs.
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ieee_wgrad_reduce_desc* __restrict__ tab, int n) {
+  __shared__ float lds[RT_CIB * 9];          // >= 256 * 4 floats (the split-lane form) and [RT_CIB][9] (the taps form)
+  int lo = 0, hi = n - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].block_begin <= b) lo = mid; else hi = mid - 1;
+  }
+  const ieee_wgrad_reduce_desc d = tab[lo];
+  const int bx = b - d.block_begin, z = blockIdx.y;
+  if (bx >= d.blocks) return;
+  if (d.kind == 1) wgrad_reduce_body<4>(lds, bx, z, d.slab, d.dw, d.nsplit, d.Co, d.Ci, d.RS, d.slab_gs, d.dw_gs, d.accumulate, d.sl_log2);
+  else if (d.kind == 2) wgrad_reduce_body<1>(lds, bx, z, d.slab, d.dw, d.nsplit, d.Co, d.Ci, d.RS, d.slab_gs, d.dw_gs, d.accumulate, d.sl_log2);
+  else if (d.kind == 3) wgrad_reduce_taps_body(lds, bx, z, d.slab, d.dw, d.nsplit, d.Co, d.Ci, d.RS, d.slab_gs, d.dw_gs, d.accumulate);
 }
 
 // Weight packing from the reference's fp32 OIHW parameters:
@@ -1930,10 +1960,17 @@ extern "C" int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, 
   return std::max(generic, std::max(stem, wp));
 }
 
-extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
-                                 int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
-                                 int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs,
-                                 int accumulate, void* stream) {
+static void fill_reduce_desc(ieee_wgrad_reduce_desc* o, const float* slab, float* dw, int64_t slab_gs, int64_t dw_gs, int nsplit,
+                             int Co, int Ci, int RS, int kind, int sl_log2, int blocks, int accumulate) {
+  o->slab = slab; o->dw = dw; o->slab_gs = slab_gs; o->dw_gs = dw_gs; o->nsplit = nsplit; o->Co = Co; o->Ci = Ci; o->RS = RS;
+  o->kind = kind; o->sl_log2 = sl_log2; o->blocks = blocks; o->accumulate = accumulate; o->block_begin = 0; o->reserved_ = 0;
+}
+
+// defer != NULL: run the GEMM only and describe the slab reduction in *defer (kind 0: nothing left to do)
+static int wgrad_impl(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
+                      int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+                      int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs,
+                      int accumulate, void* stream, ieee_wgrad_reduce_desc* defer) {
   IEEE_REQUIRE(dy && x && dw_oihw && work, "conv2d_wgrad: null pointer");
   Dims d;
   IEEE_TRY(check_dims("conv2d_wgrad", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
@@ -1950,6 +1987,10 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
     int sl_log2 = 0;
     while (sl_log2 < 4 && (2 << sl_log2) <= ssplits && (total << sl_log2) * groups < (int64_t)256 * 2048) ++sl_log2;
     dim3 rgrid(cdiv(total, 256 >> sl_log2), (unsigned)groups);
+    if (defer) {
+      fill_reduce_desc(defer, slab, dw_oihw, slab_gs, dw_gs, (int)ssplits, d.Co, d.Ci, d.R * d.S, 2, sl_log2, (int)rgrid.x, accumulate);
+      return IEEE_OK;
+    }
     wgrad_reduce_kernel<1><<<rgrid, 256, 0, st>>>(slab, dw_oihw, (int)ssplits, d.Co, d.Ci, d.R * d.S, slab_gs, dw_gs, accumulate, sl_log2);
     return launch_status("wgrad_reduce_kernel");
   }
@@ -2046,6 +2087,7 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
     IEEE_REQUIRE(false, "conv2d_wgrad: bad dtype %d", dtype);
   }
   IEEE_TRY(launch_status("conv_wgrad_kernel"));
+  if (defer) fill_reduce_desc(defer, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
   if (direct) return IEEE_OK;
   const int64_t total = (int64_t)d.Co * d.Ci * d.R * d.S;
   const bool vec4 = d.R * d.S == 1 && (total & 3) == 0 && (dw_gs & 3) == 0 && (a.slab_gs & 3) == 0 &&
@@ -2059,13 +2101,45 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
   if (d.R * d.S > 1 && nsplit_used <= f_taps && d.Ci % 4 == 0 && (a.slab_gs & 3) == 0 && ((uintptr_t)slab & 15) == 0) {
     const int RS = d.R * d.S;
     dim3 tgrid((unsigned)(d.Co * cdiv(d.Ci, RT_CIB)), (unsigned)groups);
+    if (defer && RS <= 9) {
+      fill_reduce_desc(defer, slab, dw_oihw, a.slab_gs, dw_gs, nsplit_used, d.Co, d.Ci, RS, 3, 0, (int)tgrid.x, accumulate);
+      return IEEE_OK;
+    }
     wgrad_reduce_taps_kernel<<<tgrid, 256, (size_t)RT_CIB * RS * sizeof(float), st>>>(slab, dw_oihw, nsplit_used, d.Co, d.Ci, RS, a.slab_gs,
                                                                                     dw_gs, accumulate);
     return launch_status("wgrad_reduce_taps_kernel");
+  }
+  if (defer) {
+    fill_reduce_desc(defer, slab, dw_oihw, a.slab_gs, dw_gs, nsplit_used, d.Co, d.Ci, d.R * d.S, vec4 ? 1 : 2, sl_log2, (int)rgrid.x, accumulate);
+    return IEEE_OK;
   }
   if (vec4)
     wgrad_reduce_kernel<4><<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit_used, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs, accumulate, sl_log2);
   else
     wgrad_reduce_kernel<1><<<rgrid, 256, 0, st>>>(slab, dw_oihw, nsplit_used, d.Co, d.Ci, d.R * d.S, a.slab_gs, dw_gs, accumulate, sl_log2);
   return launch_status("wgrad_reduce_kernel");
+}
+
+extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
+                                 int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+                                 int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs,
+                                 int accumulate, void* stream) {
+  return wgrad_impl(dy, x, dw_oihw, work, dtype, groups, N, Hi, Wi, Ci, Co, R, S, stride, pad, dy_gs, x_gs, dw_gs, accumulate,
+                    stream, nullptr);
+}
+
+extern "C" int ieee_conv2d_wgrad_deferred(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
+                                          int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+                                          int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs,
+                                          int accumulate, ieee_wgrad_reduce_desc* reduce, void* stream) {
+  IEEE_REQUIRE(reduce, "conv2d_wgrad_deferred: null descriptor");
+  return wgrad_impl(dy, x, dw_oihw, work, dtype, groups, N, Hi, Wi, Ci, Co, R, S, stride, pad, dy_gs, x_gs, dw_gs, accumulate,
+                    stream, reduce);
+}
+
+extern "C" int ieee_wgrad_reduce_batch(const ieee_wgrad_reduce_desc* device_descs, int64_t n, int64_t total_blocks, int64_t groups,
+                                       void* stream) {
+  IEEE_REQUIRE(device_descs && n > 0 && total_blocks > 0 && groups > 0, "wgrad_reduce_batch: bad arguments");
+  wgrad_reduce_batch_kernel<<<dim3((unsigned)total_blocks, (unsigned)groups), 256, 0, (hipStream_t)stream>>>(device_descs, (int)n);
+  return launch_status("wgrad_reduce_batch_kernel");
 }

@@ -6,6 +6,7 @@
 // out exactly like the reference's state_dict (the caller binds name -> offset, see ieee_net_bind).
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <map>
 #include <string>
@@ -29,7 +30,7 @@ struct ConvUnit {
   int S = 0;                       // kernel width (== R except for the column-padded stem)
   int Ci_src = 0, S_src = 0, R_src = 0;   // dims of the reference parameter when the unit runs zero-padded
   int s_w, s_g, s_b, s_rm, s_rv;   // slot ids of modality 0 (modality m = id + m)
-  Tensor y, a, stats, wf, wd, dwpad;
+  Tensor y, a, stats, wf, wd, dwpad, slab;
   Tensor abits;                    // bf16 block outputs: the ReLU mask of `a` as packed bits (bn_apply writes it, the next block's conv1 dgrad reads it)
   bool want_bits = false;
   bool need_dgrad = true;
@@ -45,6 +46,15 @@ struct PackDescHost {
 };
 extern "C" int ieee_pack_all_weights(const float* params, void* ws_base, const void* descs, int64_t ndesc,
                                      int64_t total_blocks, int dtype, void* stream);
+
+// IEEE_WGRAD_BATCH: 0 (default) every weight gradient reduces its split-K slabs at once; 1 one batched reduction per
+// backward part (own slab region per unit, +1.7 GB); 2 one per bottleneck block.  Measured: 1 and 2 are 0.1 ms per step
+// SLOWER than 0 (the serialized weight-gradient time improves 1 %, but the large reductions take HBM bandwidth from the
+// dependent chain at once instead of in slices) -- kept as an option of the C ABI, not the default.
+static int wgrad_batch_mode() {
+  static const int m = getenv("IEEE_WGRAD_BATCH") ? atoi(getenv("IEEE_WGRAD_BATCH")) : 0;
+  return m;
+}
 
 struct Block {
   int c1, c2, c3, ds;   // unit indices (ds = -1 when there is no downsample branch)
@@ -71,6 +81,15 @@ struct Net {
   size_t ws_bytes = 0;
   std::map<std::string, Tensor> tensors;
   Tensor x0, pool, pool_arg, S, gbuf[10], slab, bnpart, bncoef, bnpart2, bncoef2, packtab, gemm_work;
+  // Weight-gradient slabs: every unit owns its region, so the split-K reductions of a whole backward part can run as ONE
+  // launch at the end of the part (ieee_wgrad_reduce_batch; IEEE_WGRAD_BATCH=0: one reduction per gradient, at once).
+  // rtab: the device copies of the (at most 6) descriptor tables; uploaded again only when their content changes.
+  static constexpr int RT_SLOTS = 24, RT_MAX = 32;
+  Tensor rtab;
+  std::vector<ieee_wgrad_reduce_desc> rpend;
+  std::vector<ieee_wgrad_reduce_desc> rtab_host[RT_SLOTS];
+  const void* rtab_ws[RT_SLOTS] = {};
+  ConvUnit reduce_unit;   // profiling label of the batched reductions
   Tensor tickets;   // 2 x 256 int32: arrival tickets of the convs that finalize their BatchNorm themselves (launch / branch stream)
   std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
   int pack_blocks_train = 0, pack_blocks_eval = 0;
@@ -274,7 +293,11 @@ void Net::plan() {
     if (u.Ci != u.Ci_src || u.S != u.S_src || u.R != u.R_src) u.dwpad = alloc("", (int64_t)3 * u.Co * u.Ci * u.R * u.S, IEEE_F32);
     max_act = std::max(max_act, n);
     if (u.need_dgrad) max_act = std::max(max_act, (int64_t)3 * B * u.Hi * u.Wi * u.Ci);
-    max_slab = std::max(max_slab, ieee_conv2d_wgrad_workspace_bytes(dt, 3, B, u.Ho, u.Wo, u.Ci, u.Co, u.R, u.S));
+    {
+      const int64_t sb = ieee_conv2d_wgrad_workspace_bytes(dt, 3, B, u.Ho, u.Wo, u.Ci, u.Co, u.R, u.S);
+      max_slab = std::max(max_slab, sb);
+      if (wgrad_batch_mode() != 0) u.slab = alloc("", sb / 4 + 64, IEEE_F32);
+    }
     max_part = std::max(max_part, 3 * ieee_bn_partial_floats(dt, u.M(B), u.Co));
     max_part = std::max(max_part, 3 * ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) * 2 * u.Co);
     max_c = std::max(max_c, (int64_t)u.Co);
@@ -334,6 +357,11 @@ void Net::plan() {
   remwork = alloc("", 3 * Bq + 64, IEEE_F32);
   gemm_work = alloc("", (int64_t)8 << 20, IEEE_F32);   // split-K slabs of the head GEMMs (32 MiB)
   tickets = alloc("", 512, IEEE_F32);
+  rtab = alloc("", (int64_t)RT_SLOTS * RT_MAX * sizeof(ieee_wgrad_reduce_desc) / 4, IEEE_F32);
+  reduce_unit = ConvUnit();
+  reduce_unit.name = "wgrad_reduce_batch";
+  reduce_unit.Ci = reduce_unit.Co = reduce_unit.R = reduce_unit.stride = reduce_unit.pad = 0;
+  reduce_unit.Hi = reduce_unit.Wi = reduce_unit.Ho = reduce_unit.Wo = 0;
   packtab = alloc("", (int64_t)(5 * units.size() + 8) * sizeof(PackDescHost) / 4, IEEE_F32);
 }
 
@@ -585,8 +613,44 @@ struct Run {
       return ieee_unpad_weight_grad(F(u.dwpad), grd(u.s_w), 3, u.Co, u.Ci, u.R, u.S, u.Ci_src, u.R_src, u.S_src, npad, gs(u.s_w), 0,
                                     st);
     }
-    return ieee_conv2d_wgrad(dy, x, grd(u.s_w), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride,
-                             u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, gs(u.s_w), 0, st);
+    if (wgrad_batch_mode() == 0)
+      return ieee_conv2d_wgrad(dy, x, grd(u.s_w), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride,
+                               u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, gs(u.s_w), 0, st);
+    ieee_wgrad_reduce_desc d;
+    IEEE_TRY(ieee_conv2d_wgrad_deferred(dy, x, grd(u.s_w), P(u.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride,
+                                        u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, gs(u.s_w), 0, &d, st));
+    if (d.kind != 0) n.rpend.push_back(d);
+    return IEEE_OK;
+  }
+  // The slab reductions of every weight gradient issued since the last flush, as one launch on the stream the weight
+  // gradients run on.  slot: which of the step's flush points this is (its descriptor table is cached on the device).
+  int wgrad_flush(int slot) {
+    if (n.rpend.empty()) return IEEE_OK;
+    std::vector<ieee_wgrad_reduce_desc> tab;
+    tab.swap(n.rpend);
+    IEEE_REQUIRE(slot >= 0 && slot < Net::RT_SLOTS && (int)tab.size() <= Net::RT_MAX, "net: reduce table overflow (%d entries, slot %d)",
+                 (int)tab.size(), slot);
+    int blocks = 0;
+    for (auto& d : tab) { d.block_begin = blocks; blocks += d.blocks; }
+    void* main_st = st;
+    const bool on_side = side_enabled();
+    if (on_side) st = (void*)n.side;
+    struct G { Run* r; void* m; ~G() { r->st = m; } } restore{this, main_st};
+    ieee_wgrad_reduce_desc* dev = (ieee_wgrad_reduce_desc*)(ws + n.rtab.off) + (size_t)slot * Net::RT_MAX;
+    std::vector<ieee_wgrad_reduce_desc>& host = n.rtab_host[slot];
+    const size_t bytes = tab.size() * sizeof(ieee_wgrad_reduce_desc);
+    if (n.rtab_ws[slot] != (const void*)ws || host.size() != tab.size() || memcmp(host.data(), tab.data(), bytes) != 0) {
+      // the previous table may still be read by an upload in flight only if this stream has not drained; the copy below is
+      // ordered behind it on the same stream and hipMemcpyAsync stages pageable memory before it returns
+      host = tab;
+      IEEE_HIP(hipMemcpyAsync(dev, host.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)st));
+      n.rtab_ws[slot] = (const void*)ws;
+    }
+    prof_begin(1, n.reduce_unit, "wgrad_reduce");
+    struct H { Run* r; ~H() { r->prof_end(); } } guard{this};
+    const int rc = ieee_wgrad_reduce_batch(dev, (int64_t)tab.size(), blocks, 3, st);
+    if (on_side) n.side_dirty = true;
+    return rc;
   }
   // prev: the unit whose BN(+ReLU) output is this conv's input; when given (bf16), the dgrad epilogue also emits
   // that BN's backward sums so that the following bn_bwd(prev) skips its reduction pass
@@ -852,6 +916,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
 int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
   Net& N = n;
   const int dt = N.dtype;
+  N.rpend.clear();   // (a failed call may have left entries behind)
   if (part <= 0) IEEE_TRY(backward_head(dlogits, dfeats));
   if (part == 0) return IEEE_OK;
   static const int first_block[5] = {0, 3, 7, 13, 16};   // layer1..4 start indices ([3,4,6,3] blocks)
@@ -928,6 +993,9 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     // backward sums (mask = that block's stored output) are emitted here too
     IEEE_TRY(dgrad(c1, U, Xout, addend, pc3, true, addend_stride));
     IEEE_TRY(tap(c1.name + ".dx", Xout, in_numel(c1)));
+    if (wgrad_batch_mode() == 2 && bi > 0) IEEE_TRY(wgrad_flush(5 + bi));
+    if (bi > 0)   // a layer is complete: reduce its weight gradients (layer1's go with the stem's below)
+      for (int l = 1; l < 4; ++l) if (bi == first_block[l]) IEEE_TRY(wgrad_flush(4 - l));
   }
   if (lo > 0) return IEEE_OK;
   X = P(N.gbuf[set_of(-1)]);      // d(out) of the stem's max-pool, left by block 0
@@ -948,6 +1016,7 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
   }
   IEEE_TRY(tap(s.name + ".dy", Q, out_numel(s)));
   IEEE_TRY(wgrad(s, Q, P(N.x0)));
+  IEEE_TRY(wgrad_flush(4));
   return IEEE_OK;
 }
 
@@ -1076,6 +1145,7 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
     if (N.tap_base) { IEEE_TRY(tap(uo.name + ".dy", g1, out_numel(uo))); IEEE_TRY(tap(ur.name + ".dy", g2, out_numel(ur))); }
     IEEE_TRY(wgrad(uo, g1, Fm));
     IEEE_TRY(wgrad(ur, g2, P(N.S)));
+    IEEE_TRY(wgrad_flush(0));
     IEEE_TRY(dgrad(uo, g1, P(N.gbuf[3]), nullptr));
     IEEE_TRY(dgrad(ur, g2, P(N.gbuf[4]), nullptr));
     if (N.tap_base) { IEEE_TRY(tap(uo.name + ".dx", P(N.gbuf[3]), in_numel(uo))); IEEE_TRY(tap(ur.name + ".dx", P(N.gbuf[4]), in_numel(ur))); }

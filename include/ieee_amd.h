@@ -172,6 +172,30 @@ int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work,
                       int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
                       int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs, int accumulate,
                       void* stream);
+/* The same weight gradient with its slab reduction DEFERRED: the launch leaves the split-K slabs in `work` (which must then
+ * stay untouched until the reduction has run) and describes the reduction in *reduce; ieee_wgrad_reduce_batch runs the
+ * reductions of many weight gradients in ONE launch.  Usage: collect the descriptors of a group of layers, drop those
+ * with kind == 0 (nothing left to reduce), set block_begin to the running sum of `blocks`, copy the table to the device
+ * and call ieee_wgrad_reduce_batch(table, n, sum of blocks, groups, stream) on the stream the gradients were launched on.
+ * Same arithmetic, same fixed summation order as the immediate form (bit-identical gradients). */
+typedef struct ieee_wgrad_reduce_desc {
+  const float* slab;        /* device: [groups][nsplit][Co][RS * Ci] */
+  float* dw;                /* device: OIHW gradient, group stride dw_gs */
+  int64_t slab_gs, dw_gs;
+  int32_t nsplit, Co, Ci, RS;
+  int32_t kind;             /* 0 nothing to do, 1 / 2 split-lane form (16-byte / scalar), 3 LDS-transposed 3x3 form */
+  int32_t sl_log2, blocks;  /* workgroups per group */
+  int32_t accumulate;
+  int32_t block_begin;      /* filled by the caller: first blockIdx.x of this entry in the batched launch */
+  int32_t reserved_;
+} ieee_wgrad_reduce_desc;
+int ieee_conv2d_wgrad_deferred(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
+                      int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+                      int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs, int accumulate,
+                      ieee_wgrad_reduce_desc* reduce, void* stream);
+int ieee_wgrad_reduce_batch(const ieee_wgrad_reduce_desc* device_descs, int64_t n, int64_t total_blocks, int64_t groups,
+                            void* stream);
+
 
 /* ---- BatchNorm2d (+ residual, + ReLU) over NHWC maps [M][C] ------------------ */
 /* torch.nn.BatchNorm2d as the reference instantiates it (resnet.py:151,164-184;

@@ -318,3 +318,52 @@ def test_conv_with_fused_train_batchnorm_finalize(R, Ci, Co, H, W):
     # and the statistics are the batch statistics of the stored y
     yf = y_a.float().view(G, M, Co)
     torch.testing.assert_close(st_a[:, 0], yf.mean(1), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deferred_wgrad_with_one_batched_reduction_is_bit_identical(dtype):
+    """ieee_conv2d_wgrad_deferred + ONE ieee_wgrad_reduce_batch over several layers (what the executor does per backward
+    part) must give the bits of the immediate ieee_conv2d_wgrad: same slabs, same fixed summation order.  Covers the four
+    reduction forms: in place (no slab), 16-byte split-lane (1x1), LDS-transposed (3x3), scalar (odd shapes / stem)."""
+    import ctypes
+    from ieee_amd import _lib as L
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(11)
+    dt = L.IEEE_BF16 if dtype == torch.bfloat16 else L.IEEE_F32
+    #        N   H   W   Ci   Co   R  stride pad
+    layers = [(8, 16, 8, 256, 64, 1, 1, 0), (8, 16, 8, 64, 64, 3, 1, 1), (8, 16, 8, 512, 512, 3, 1, 1), (16, 8, 8, 1024, 256, 1, 1, 0),
+              (2, 16, 8, 256, 512, 1, 2, 0), (3, 5, 7, 64, 128, 3, 1, 1), (8, 32, 16, 8, 64, 7, 2, 3), (64, 32, 16, 64, 256, 1, 1, 0)]
+    G = 3
+    descs, keep, want = [], [], []
+    for (N, H, W, Ci, Co, R, stride, pad) in layers:
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+        x = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dtype)
+        dy = torch.randn(G, N, Ho, Wo, Co, generator=g).cuda().to(dtype)
+        nbytes = lib.ieee_conv2d_wgrad_workspace_bytes(dt, G, N, Ho, Wo, Ci, Co, R, R)
+        args = (dt, G, N, H, W, Ci, Co, R, R, stride, pad, dy[0].numel(), x[0].numel(), Co * Ci * R * R)
+        for acc in (0, 1):
+            base = torch.randn(G, Co, Ci, R, R, generator=g).cuda()
+            ref, out = base.clone(), base.clone()
+            work0 = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            L.check(lib.ieee_conv2d_wgrad(L.ptr(dy), L.ptr(x), L.ptr(ref), L.ptr(work0), *args, acc, L.stream()))
+            work = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            d = L.WgradReduceDesc()
+            L.check(lib.ieee_conv2d_wgrad_deferred(L.ptr(dy), L.ptr(x), L.ptr(out), L.ptr(work), *args, acc, ctypes.addressof(d),
+                                                   L.stream()))
+            keep.append((x, dy, work, out)); want.append(ref)
+            if d.kind != 0:
+                descs.append(d)
+    kinds = {d.kind for d in descs}
+    assert {1, 3} <= kinds <= {1, 2, 3}, kinds
+    assert len(descs) < len(want)          # at least one gradient was written in place (kind 0)
+    tab = (L.WgradReduceDesc * len(descs))()
+    blocks = 0
+    for i, d in enumerate(descs):
+        ctypes.memmove(ctypes.addressof(tab[i]), ctypes.addressof(d), ctypes.sizeof(d))
+        tab[i].block_begin = blocks
+        blocks += d.blocks
+    raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda()
+    L.check(lib.ieee_wgrad_reduce_batch(L.ptr(raw), len(descs), blocks, G, L.stream()))
+    torch.cuda.synchronize()
+    for (x, dy, work, out), ref in zip(keep, want):
+        assert torch.equal(out, ref)

@@ -173,3 +173,47 @@ def test_async_parts_joined_by_sync_streams_equal_the_plain_backward():
     runs = m.trainable_runs()
     assert all(torch.equal(after[a:b], ref[a:b]) for a, b in runs)
     assert float(ref.abs().max()) > 0
+
+
+_GRAD_DIGEST = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from tests.test_model_gpu import make_model, images, C
+B = 8
+m = make_model(5, dtype=torch.bfloat16).train()
+xs = [x.cuda() for x in images(B, 5)]
+net = m.native_net(B, 256, 128)
+g = torch.Generator(device="cuda").manual_seed(3)
+dl = torch.randn(18, B, C, generator=g, device="cuda") * 1e-2
+df = torch.randn(3, B, 768, generator=g, device="cuda") * 1e-2
+m._bump_counters()
+for staged in (False, True):
+    m._flat_grads.zero_()
+    net.forward(xs, training=True)
+    if staged:
+        for part in range(5):
+            net.backward_part(dl, df, part)
+    else:
+        net.backward(dl, df)
+    torch.cuda.synchronize()
+    print("DIGEST", hashlib.sha1(m._flat_grads.cpu().numpy().tobytes()).hexdigest(), float(m._flat_grads.abs().max()) > 0)
+"""
+
+
+def test_batched_weight_gradient_reductions_leave_the_same_bits():
+    """IEEE_WGRAD_BATCH=1 / 2 (one ieee_wgrad_reduce_batch per backward part / per bottleneck block over per-unit slabs)
+    against the default (every gradient reduced at once): same partial sums, same fixed order -> the same flat gradient
+    buffer, bit for bit, through the one-call and the staged backward.  (The switch is read once per process.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for mode in ("0", "1", "2"):
+        env = dict(os.environ, IEEE_WGRAD_BATCH=mode)
+        out = subprocess.run([sys.executable, "-c", _GRAD_DIGEST % root], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l.split() for l in out.stdout.splitlines() if l.startswith("DIGEST")]
+        assert len(lines) == 2 and all(l[2] == "True" for l in lines), out.stdout
+        digests[mode] = [l[1] for l in lines]
+    assert digests["0"][0] == digests["0"][1]
+    assert digests["1"] == digests["0"] and digests["2"] == digests["0"]
