@@ -284,6 +284,40 @@ __device__ __forceinline__ float key_dist(uint64_t key) {
   return __uint_as_float(u);
 }
 
+// ---- identity buckets: gallery indices grouped by a hash of their identity (counting sort, order inside a bucket
+// arbitrary -- the consumers sort what they collect).  work: start[RANK_BUCKETS + 1], cursor[RANK_BUCKETS], idx[num_g].
+constexpr int RANK_BUCKETS = 16384;
+__device__ __forceinline__ uint32_t rank_bucket_of(int32_t pid) { return ((uint32_t)pid * 2654435761u) >> 18; }
+
+__global__ __launch_bounds__(256) void rank_bucket_count_kernel(const int32_t* __restrict__ g_pids, int num_g, int32_t* count) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < num_g) atomicAdd(&count[1 + rank_bucket_of(g_pids[j])], 1);
+}
+// start[0] = 0 and start[1 + b] = count of bucket b on entry; exclusive starts on exit, copied into cursor
+__global__ __launch_bounds__(1024) void rank_bucket_scan_kernel(int32_t* start, int32_t* cursor) {
+  constexpr int PER = RANK_BUCKETS / 1024;
+  __shared__ int32_t wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int32_t c[PER], sum = 0;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) { c[e] = start[1 + t * PER + e]; sum += c[e]; }
+  int32_t inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  int32_t run = base + inc - sum;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) { cursor[t * PER + e] = run; run += c[e]; start[1 + t * PER + e] = run; }
+}
+__global__ __launch_bounds__(256) void rank_bucket_fill_kernel(const int32_t* __restrict__ g_pids, int num_g, int32_t* cursor,
+                                                               int32_t* idx) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < num_g) idx[atomicAdd(&cursor[rank_bucket_of(g_pids[j])], 1)] = j;
+}
+
 // The common case of the evaluator, one workgroup per query: at most RANK_CAP true matches and at most RANK_CAP
 // removed entries (same identity, same camera).  No sort of the gallery row and no identity lookups while it is
 // streamed: the matches are sorted in LDS, a grid of RANK_CELLS cells over their distance range maps a streamed
@@ -294,7 +328,9 @@ __device__ __forceinline__ float key_dist(uint64_t key) {
 __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distmat, int64_t ldd, int num_g,
                                                               const int32_t* q_pids, const int32_t* g_pids,
                                                               const int32_t* q_camids, const int32_t* g_camids,
-                                                              double* ap_out, int32_t* first_out) {
+                                                              double* ap_out, int32_t* first_out,
+                                                              const int32_t* __restrict__ bucket_start,
+                                                              const int32_t* __restrict__ bucket_idx) {
   constexpr int HIST = RANK_CELLS + RANK_CAP + 2;
   __shared__ uint64_t keys[RANK_CAP];
   __shared__ uint32_t removed[RANK_CAP];
@@ -321,7 +357,16 @@ __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distm
       if (pos < (uint32_t)RANK_CAP) removed[pos] = (uint32_t)j;
     }
   };
-  {
+  if (bucket_start) {
+    // the gallery entries were bucketed by identity hash once per call (rank_bucket_* below): this query looks at its
+    // identity's bucket only -- a few dozen entries -- instead of all num_g identities (400 KB of L2 reads per query)
+    const uint32_t h = rank_bucket_of(qpid);
+    const int b0 = bucket_start[h], b1 = bucket_start[h + 1];
+    for (int i = b0 + t; i < b1; i += 256) {
+      const int j = bucket_idx[i];
+      collect(g_pids[j], j);
+    }
+  } else {
     int j = 0;
     for (; ((uintptr_t)g_pids & 15) == 0 && j + 1024 <= num_g; j += 1024) {
       const int4 p4 = *(const int4*)(g_pids + j + t * 4);
@@ -798,10 +843,9 @@ extern "C" int ieee_sqeuclid_distmat_split(const float* q, const float* g, int64
   return launch_status("distmat_split");
 }
 
-extern "C" int ieee_rank_market1501(const float* distmat, int64_t ldd, int64_t num_q, int64_t num_g,
-                                    const int32_t* q_pids, const int32_t* g_pids, const int32_t* q_camids,
-                                    const int32_t* g_camids, int64_t max_rank, double* ap, int32_t* first_pos,
-                                    int64_t* summary, void* stream) {
+static int rank_impl(const float* distmat, int64_t ldd, int64_t num_q, int64_t num_g, const int32_t* q_pids,
+                     const int32_t* g_pids, const int32_t* q_camids, const int32_t* g_camids, int64_t max_rank, double* ap,
+                     int32_t* first_pos, int64_t* summary, void* work, int64_t work_bytes, void* stream) {
   IEEE_REQUIRE(distmat && q_pids && g_pids && q_camids && g_camids && ap && first_pos && summary, "rank: null pointer");
   IEEE_REQUIRE(num_q > 0 && num_g > 0, "rank: empty distmat");
   IEEE_REQUIRE(num_g < (1ll << 31) && num_q < (1ll << 31), "rank: too large");
@@ -810,11 +854,47 @@ extern "C" int ieee_rank_market1501(const float* distmat, int64_t ldd, int64_t n
   IEEE_REQUIRE(max_rank >= 1 && max_rank <= 1024, "rank: max_rank %ld out of range [1,1024]", (long)max_rank);
   hipStream_t st = (hipStream_t)stream;
   const bool general_only = getenv("IEEE_RANK_GENERAL") && atoi(getenv("IEEE_RANK_GENERAL")) != 0;   // tests
+  int32_t *start = nullptr, *idx = nullptr;
+  if (work && !general_only) {
+    IEEE_REQUIRE(work_bytes >= ieee_rank_workspace_bytes(num_g), "rank: workspace of %ld bytes, %ld needed", (long)work_bytes,
+                 (long)ieee_rank_workspace_bytes(num_g));
+    IEEE_REQUIRE(((uintptr_t)work & 3) == 0, "rank: workspace not 4-byte aligned");
+    start = (int32_t*)work;
+    int32_t* cursor = start + RANK_BUCKETS + 1;
+    idx = cursor + RANK_BUCKETS;
+    IEEE_HIP(hipMemsetAsync(start, 0, sizeof(int32_t) * (RANK_BUCKETS + 1), st));
+    rank_bucket_count_kernel<<<cdiv(num_g, 256), 256, 0, st>>>(g_pids, (int)num_g, start);
+    rank_bucket_scan_kernel<<<1, 1024, 0, st>>>(start, cursor);
+    rank_bucket_fill_kernel<<<cdiv(num_g, 256), 256, 0, st>>>(g_pids, (int)num_g, cursor, idx);
+    IEEE_TRY(launch_status("rank_bucket"));
+  }
   if (!general_only)
     rank_query_fast_kernel<<<(int)num_q, 256, 0, st>>>(distmat, ldd, (int)num_g, q_pids, g_pids, q_camids, g_camids,
-                                                       ap, first_pos);
+                                                       ap, first_pos, start, idx);
   rank_query_kernel<<<(int)num_q, 256, 0, st>>>(distmat, ldd, (int)num_g, q_pids, g_pids, q_camids, g_camids, ap,
                                                 first_pos, general_only ? 0 : 1);
   rank_finalize_kernel<<<1, 256, 0, st>>>(ap, first_pos, (int)num_q, (int)max_rank, summary);
   return launch_status("rank_market1501");
 }
+
+extern "C" int64_t ieee_rank_workspace_bytes(int64_t num_g) {
+  return (int64_t)sizeof(int32_t) * (2 * RANK_BUCKETS + 1 + (num_g > 0 ? num_g : 0));
+}
+
+extern "C" int ieee_rank_market1501(const float* distmat, int64_t ldd, int64_t num_q, int64_t num_g,
+                                    const int32_t* q_pids, const int32_t* g_pids, const int32_t* q_camids,
+                                    const int32_t* g_camids, int64_t max_rank, double* ap, int32_t* first_pos,
+                                    int64_t* summary, void* stream) {
+  return rank_impl(distmat, ldd, num_q, num_g, q_pids, g_pids, q_camids, g_camids, max_rank, ap, first_pos, summary, nullptr, 0,
+                   stream);
+}
+
+extern "C" int ieee_rank_market1501_ws(const float* distmat, int64_t ldd, int64_t num_q, int64_t num_g,
+                                       const int32_t* q_pids, const int32_t* g_pids, const int32_t* q_camids,
+                                       const int32_t* g_camids, int64_t max_rank, double* ap, int32_t* first_pos,
+                                       int64_t* summary, void* work, int64_t work_bytes, void* stream) {
+  IEEE_REQUIRE(work, "rank: null workspace");
+  return rank_impl(distmat, ldd, num_q, num_g, q_pids, g_pids, q_camids, g_camids, max_rank, ap, first_pos, summary, work,
+                   work_bytes, stream);
+}
+

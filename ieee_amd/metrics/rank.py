@@ -36,9 +36,10 @@ def rank_counts(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
     ap = torch.empty(num_q, dtype=torch.float64, device=dev)
     first = torch.empty(num_q, dtype=torch.int32, device=dev)
     summary = torch.empty(max_rank + 2, dtype=torch.int64, device=dev)
-    _lib.check(lib.ieee_rank_market1501(_lib.ptr(d), d.stride(0), num_q, num_g, _lib.ptr(qp), _lib.ptr(gp),
-                                        _lib.ptr(qc), _lib.ptr(gc), max_rank, _lib.ptr(ap), _lib.ptr(first),
-                                        _lib.ptr(summary), _lib.stream()))
+    work = torch.empty(lib.ieee_rank_workspace_bytes(num_g), dtype=torch.uint8, device=dev)
+    _lib.check(lib.ieee_rank_market1501_ws(_lib.ptr(d), d.stride(0), num_q, num_g, _lib.ptr(qp), _lib.ptr(gp),
+                                           _lib.ptr(qc), _lib.ptr(gc), max_rank, _lib.ptr(ap), _lib.ptr(first),
+                                           _lib.ptr(summary), _lib.ptr(work), work.numel(), _lib.stream()))
     s = summary.cpu().numpy()          # the evaluator's single read-back (22 words)
     return s[:max_rank].copy(), float(s[max_rank]), float(s[max_rank + 1:max_rank + 2].view(np.float64)[0])
 

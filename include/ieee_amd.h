@@ -85,6 +85,14 @@ int ieee_rank_market1501(const float* distmat, int64_t ldd, int64_t num_q, int64
                          const int32_t* q_pids, const int32_t* g_pids, const int32_t* q_camids,
                          const int32_t* g_camids, int64_t max_rank, double* ap, int32_t* first_pos,
                          int64_t* summary, void* stream);
+/* The same evaluation with a workspace of ieee_rank_workspace_bytes(num_g) bytes (device, 4-byte aligned): the gallery is
+ * bucketed by identity once per call, so a query collects its true matches and its same-camera entries from one bucket
+ * instead of scanning all num_g identities.  Same results, bit for bit. */
+int64_t ieee_rank_workspace_bytes(int64_t num_g);
+int ieee_rank_market1501_ws(const float* distmat, int64_t ldd, int64_t num_q, int64_t num_g,
+                            const int32_t* q_pids, const int32_t* g_pids, const int32_t* q_camids,
+                            const int32_t* g_camids, int64_t max_rank, double* ap, int32_t* first_pos,
+                            int64_t* summary, void* work, int64_t work_bytes, void* stream);
 
 /* ---- convolution as implicit GEMM over NHWC (MFMA) ------------------------ */
 /* These replace torch's conv2d forward / backward as dispatched by the

@@ -290,3 +290,47 @@ def test_config4_full_size_sampled_and_property_checks(monkeypatch):
     assert 1.0 / 200 < map_f <= 1.0
     del dm
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("nq,ng,ids", [(257, 12345, "dense"), (64, 5000, "hashed"), (33, 3000, "collide")])
+def test_rank_with_identity_buckets_equals_the_scanning_form(nq, ng, ids):
+    """ieee_rank_market1501_ws (gallery bucketed by identity hash once per call; what evaluate_rank uses) against
+    ieee_rank_market1501 (every query scans all gallery identities): per-query AP, first-match position and the summary
+    must be the same bits.  Identities: small dense ints, arbitrary 32-bit values incl. negatives, and values that
+    share a bucket (equal hash, different identity)."""
+    from ieee_amd import _lib as L
+    lib = L.require_gpu()
+    rng = np.random.RandomState(nq)
+    if ids == "dense":
+        pool = np.arange(200)
+    elif ids == "hashed":
+        pool = rng.randint(-2**31, 2**31 - 1, size=120, dtype=np.int64)
+    else:   # multiples of 2^32 / odd constant do not exist; build collisions by brute force on the kernel's hash
+        cand = np.arange(1, 400000, dtype=np.int64)
+        h = ((cand * 2654435761) & 0xFFFFFFFF) >> 18
+        pool = np.concatenate([cand[h == b][:6] for b in (7, 4097, 16383)])
+        assert len(pool) == 18
+    gp = rng.choice(pool, ng).astype(np.int32)
+    qp = rng.choice(pool, nq).astype(np.int32)
+    qc, gc = rng.randint(0, 3, nq).astype(np.int32), rng.randint(0, 3, ng).astype(np.int32)
+    d = torch.from_numpy((rng.rand(nq, ng) * 10).astype(np.float32)).cuda()
+    dev = [torch.from_numpy(a).cuda() for a in (qp, gp, qc, gc)]
+    outs = []
+    for ws in (False, True):
+        ap = torch.full((nq,), 7.0, dtype=torch.float64, device="cuda")
+        first = torch.full((nq,), 7, dtype=torch.int32, device="cuda")
+        summ = torch.zeros(22, dtype=torch.int64, device="cuda")
+        args = (L.ptr(d), d.stride(0), nq, ng, *[L.ptr(a) for a in dev], 20, L.ptr(ap), L.ptr(first), L.ptr(summ))
+        if ws:
+            work = torch.empty(lib.ieee_rank_workspace_bytes(ng), dtype=torch.uint8, device="cuda")
+            L.check(lib.ieee_rank_market1501_ws(*args, L.ptr(work), work.numel(), L.stream()))
+            assert lib.ieee_rank_market1501_ws(*args, L.ptr(work), 16, L.stream()) != 0      # short workspace: refused
+        else:
+            L.check(lib.ieee_rank_market1501(*args, L.stream()))
+        torch.cuda.synchronize()
+        outs.append((ap.cpu(), first.cpu(), summ.cpu()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    assert int(outs[0][2][20]) > 0
+    cmc_o, map_o = ev.rank_market1501_c(d.cpu().numpy(), qp, gp, qc, gc, 20)
+    nv = float(outs[1][2][20])
+    assert np.array_equal(outs[1][2][:20].numpy().astype(np.float32) / np.float32(nv), cmc_o)
