@@ -61,6 +61,7 @@ struct Block {
 };
 
 struct Net {
+  static constexpr int NGBUF = 15;   // three sets of five activation-sized gradient buffers (IEEE_GBUF_SETS=2: two of them used)
   // config
   int B, H, W, num_classes, dtype, interaction, attention, using_rem;
   int parts = 6, rdim = 768, cdim = 128, fdim = 2048, hid = 128;
@@ -80,7 +81,7 @@ struct Net {
   // workspace
   size_t ws_bytes = 0;
   std::map<std::string, Tensor> tensors;
-  Tensor x0, pool, pool_arg, S, gbuf[10], slab, bnpart, bncoef, bnpart2, bncoef2, packtab, gemm_work;
+  Tensor x0, pool, pool_arg, S, gbuf[NGBUF], slab, bnpart, bncoef, bnpart2, bncoef2, packtab, gemm_work;
   // Weight-gradient slabs: every unit owns its region, so the split-K reductions of a whole backward part can run as ONE
   // launch at the end of the part (ieee_wgrad_reduce_batch; IEEE_WGRAD_BATCH=0: one reduction per gradient, at once).
   // rtab: the device copies of the (at most 6) descriptor tables; uploaded again only when their content changes.
@@ -115,10 +116,12 @@ struct Net {
   hipStream_t side2 = nullptr;
   hipEvent_t branch_ev[16] = {};
   std::vector<hipEvent_t> side_ready;
-  hipEvent_t gbuf_read[10] = {};
+  hipEvent_t gbuf_read[NGBUF] = {};
   hipEvent_t side_done = nullptr;
   hipEvent_t sync_ev = nullptr;     // ieee_net_sync_streams: the branch stream's join event
-  bool gbuf_pending[10] = {};
+  bool gbuf_pending[NGBUF] = {};
+  uint64_t gbuf_seq[NGBUF] = {}, gbuf_clock = 0;   // order of the gbuf_read records on the side stream
+  int gbuf_evt[NGBUF] = {};                          // which gbuf_read event protects buffer b (several buffers may share one)
   bool side_dirty = false;
   size_t side_used = 0;
   ~Net() {
@@ -311,7 +314,7 @@ void Net::plan() {
   S = alloc("S", (int64_t)3 * B * P * fdim, dt);
   // two sets of five activation-sized gradient buffers: consecutive bottleneck blocks alternate between them, so a
   // buffer is rewritten two blocks after the side-stream wgrad that reads it was issued (one set stalled the chain)
-  for (int i = 0; i < 10; ++i) gbuf[i] = alloc("g" + std::to_string(i), max_act, dt);
+  for (int i = 0; i < NGBUF; ++i) gbuf[i] = alloc("g" + std::to_string(i), max_act, dt);
   slab = alloc("", max_slab / 4 + 64, IEEE_F32);
   max_part = std::max(max_part, (int64_t)12 * B * fdim);   // two [3][2][C][B] sets from ieee_cim_tail_bwd_g
   bnpart = alloc("", max_part + 64, IEEE_F32);
@@ -504,7 +507,7 @@ struct Run {
   }
   // --- second stream for the weight gradients (see Net::side)
   int gbuf_index(const void* p) const {
-    for (int i = 0; i < 10; ++i) if (p == (const void*)(ws + n.gbuf[i].off)) return i;
+    for (int i = 0; i < Net::NGBUF; ++i) if (p == (const void*)(ws + n.gbuf[i].off)) return i;
     return -1;
   }
   bool side_enabled() {
@@ -515,7 +518,7 @@ struct Run {
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
       const int prio = getenv("IEEE_SIDE_PRIO") ? atoi(getenv("IEEE_SIDE_PRIO")) : least;
       if (hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, prio) != hipSuccess) { n.side = nullptr; return false; }
-      for (int i = 0; i < 10; ++i) (void)hipEventCreateWithFlags(&n.gbuf_read[i], hipEventDisableTiming);
+      for (int i = 0; i < Net::NGBUF; ++i) (void)hipEventCreateWithFlags(&n.gbuf_read[i], hipEventDisableTiming);
       (void)hipEventCreateWithFlags(&n.side_done, hipEventDisableTiming);
       for (int i = 0; i < 2; ++i) (void)hipEventCreateWithFlags(&n.pack_ev[i], hipEventDisableTiming);
     }
@@ -523,10 +526,21 @@ struct Run {
   }
   // the caller's stream is about to overwrite p: wait for the side-stream wgrad that still reads it
   void will_write(const void* p) {
-    const int b = gbuf_index(p);
+    int b = gbuf_index(p);
     if (b < 0 || !n.gbuf_pending[b]) return;
-    (void)hipStreamWaitEvent((hipStream_t)st, n.gbuf_read[b], 0);
-    n.gbuf_pending[b] = false;
+    // A cross-stream wait is a barrier packet in the launch stream's queue (5-7 us of bubble even when the event is long
+    // complete).  The side stream runs in order, so ONE wait on the newest pending event of this buffer's set frees every
+    // buffer whose event was recorded before it: one wait per bottleneck block instead of three.
+    static const bool merge = !(getenv("IEEE_GBUF_MERGE") && atoi(getenv("IEEE_GBUF_MERGE")) == 0);
+    if (merge) {
+      const int s0 = b / 5 * 5;
+      for (int i = s0; i < s0 + 5; ++i)
+        if (n.gbuf_pending[i] && n.gbuf_seq[i] > n.gbuf_seq[b]) b = i;
+    }
+    (void)hipStreamWaitEvent((hipStream_t)st, n.gbuf_read[n.gbuf_evt[b]], 0);
+    const uint64_t upto = n.gbuf_seq[b];
+    for (int i = 0; i < Net::NGBUF; ++i)
+      if (n.gbuf_pending[i] && n.gbuf_seq[i] <= upto) n.gbuf_pending[i] = false;
   }
   // every weight gradient issued so far is final for work submitted to the caller's stream after this
   void side_join() {
@@ -535,7 +549,7 @@ struct Run {
     (void)hipStreamWaitEvent((hipStream_t)st, n.side_done, 0);
     n.side_dirty = false;
     n.side_used = 0;
-    for (int b = 0; b < 10; ++b) n.gbuf_pending[b] = false;
+    for (int b = 0; b < Net::NGBUF; ++b) n.gbuf_pending[b] = false;
   }
   // --- third stream for the downsample branches (see Net::side2)
   bool branch_enabled(int phase = 3) {   // phase bit 1: forward, bit 2: backward
@@ -598,6 +612,8 @@ struct Run {
       if (b >= 0) {
         IEEE_HIP(hipEventRecord(n.gbuf_read[b], n.side));
         n.gbuf_pending[b] = true;
+        n.gbuf_seq[b] = ++n.gbuf_clock;
+        n.gbuf_evt[b] = b;
       }
       return rc;
     }
@@ -924,7 +940,9 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
   if (part > 0) { hi = first_block[5 - part] - 1; lo = first_block[4 - part]; }
   // trunk backward (Bottleneck blocks in reverse); X holds d(out) of the current block
   // block bi reads d(out) from xbuf(bi) and leaves d(in) in xbuf(bi - 1); its scratch buffers come from set(bi)
-  auto set_of = [](int bi) { return (bi & 1) ? 0 : 5; };
+  // (2 sets: block 15 -- odd -- reads the head's gbuf[0]; 3 sets: 15 % 3 == 0 does too)
+  static const int nsets = getenv("IEEE_GBUF_SETS") ? atoi(getenv("IEEE_GBUF_SETS")) : 3;
+  auto set_of = [](int bi) { return nsets == 2 ? ((bi & 1) ? 0 : 5) : ((bi + 3) % 3) * 5; };
   void *X = nullptr, *Q = nullptr, *Rb = nullptr, *U = nullptr, *V = nullptr, *Xout = nullptr;
   for (int bi = hi; bi >= lo; --bi) {
     const Block& b = N.blocks[bi];
@@ -1335,7 +1353,7 @@ extern "C" int ieee_net_sync_streams(void* handle, void* stream) {
     IEEE_HIP(hipStreamWaitEvent(st, n->side_done, 0));
     n->side_dirty = false;
     n->side_used = 0;
-    for (int b = 0; b < 10; ++b) n->gbuf_pending[b] = false;
+    for (int b = 0; b < Net::NGBUF; ++b) n->gbuf_pending[b] = false;
   }
   if (n->side2 != nullptr) {
     if (n->sync_ev == nullptr) IEEE_HIP(hipEventCreateWithFlags(&n->sync_ev, hipEventDisableTiming));
