@@ -51,6 +51,11 @@ extern "C" int ieee_pack_all_weights(const float* params, void* ws_base, const v
 // backward part (own slab region per unit, +1.7 GB); 2 one per bottleneck block.  Measured: 1 and 2 are 0.1 ms per step
 // SLOWER than 0 (the serialized weight-gradient time improves 1 %, but the large reductions take HBM bandwidth from the
 // dependent chain at once instead of in slices) -- kept as an option of the C ABI, not the default.
+static int gbuf_sets() {
+  static const int n = getenv("IEEE_GBUF_SETS") ? atoi(getenv("IEEE_GBUF_SETS")) : 3;
+  return n == 2 ? 2 : 3;
+}
+
 static int wgrad_batch_mode() {
   static const int m = getenv("IEEE_WGRAD_BATCH") ? atoi(getenv("IEEE_WGRAD_BATCH")) : 0;
   return m;
@@ -941,7 +946,7 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
   // trunk backward (Bottleneck blocks in reverse); X holds d(out) of the current block
   // block bi reads d(out) from xbuf(bi) and leaves d(in) in xbuf(bi - 1); its scratch buffers come from set(bi)
   // (2 sets: block 15 -- odd -- reads the head's gbuf[0]; 3 sets: 15 % 3 == 0 does too)
-  static const int nsets = getenv("IEEE_GBUF_SETS") ? atoi(getenv("IEEE_GBUF_SETS")) : 3;
+  static const int nsets = gbuf_sets();
   auto set_of = [](int bi) { return nsets == 2 ? ((bi & 1) ? 0 : 5) : ((bi + 3) % 3) * 5; };
   void *X = nullptr, *Q = nullptr, *Rb = nullptr, *U = nullptr, *V = nullptr, *Xout = nullptr;
   for (int bi = hi; bi >= lo; --bi) {
@@ -1153,7 +1158,10 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
       IEEE_TRY(gemm3(F(N.dH), 2 * (int64_t)B * N.hid, par(N.s_ca1), gs(N.s_ca1), F(N.davgmax), 2 * BC, nullptr, 0, 2 * B, C,
                      N.hid, N.hid, 1, 1, C, C, 0, 0));
     }
-    void *g1 = P(N.gbuf[1]), *g2 = P(N.gbuf[2]);
+    // scratch of the CIM backward: with three buffer sets it lives in the set that block 13 uses, so that block 15 (set 0,
+    // which only has to hold dF) does not start by waiting for the two CIM weight gradients that read g1 / g2
+    const int hb = gbuf_sets() == 3 ? 5 : 0;
+    void *g1 = P(N.gbuf[hb + 1]), *g2 = P(N.gbuf[hb + 2]);
     IEEE_TRY(ieee_cim_tail_bwd_g(F(N.dPp), P(uo.y), P(ur.y), F(uo.stats), F(ur.stats), F(N.att), F(N.davgmax),
                                  F(N.davgmax) + BC, 2 * BC, (const int32_t*)P(N.amax), g1, g2, dt, B, Hh_, Ww, C, N.parts,
                                  mode, F(N.bnpart), F(N.bnpart) + 6 * BC, st));
@@ -1164,10 +1172,10 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
     IEEE_TRY(wgrad(uo, g1, Fm));
     IEEE_TRY(wgrad(ur, g2, P(N.S)));
     IEEE_TRY(wgrad_flush(0));
-    IEEE_TRY(dgrad(uo, g1, P(N.gbuf[3]), nullptr));
-    IEEE_TRY(dgrad(ur, g2, P(N.gbuf[4]), nullptr));
-    if (N.tap_base) { IEEE_TRY(tap(uo.name + ".dx", P(N.gbuf[3]), in_numel(uo))); IEEE_TRY(tap(ur.name + ".dx", P(N.gbuf[4]), in_numel(ur))); }
-    IEEE_TRY(ieee_cim_bwd_combine(P(N.gbuf[3]), P(N.gbuf[4]), F(N.dGp), dF, dt, B, Hh_, Ww, C, mode, st));
+    IEEE_TRY(dgrad(uo, g1, P(N.gbuf[hb + 3]), nullptr));
+    IEEE_TRY(dgrad(ur, g2, P(N.gbuf[hb + 4]), nullptr));
+    if (N.tap_base) { IEEE_TRY(tap(uo.name + ".dx", P(N.gbuf[hb + 3]), in_numel(uo))); IEEE_TRY(tap(ur.name + ".dx", P(N.gbuf[hb + 4]), in_numel(ur))); }
+    IEEE_TRY(ieee_cim_bwd_combine(P(N.gbuf[hb + 3]), P(N.gbuf[hb + 4]), F(N.dGp), dF, dt, B, Hh_, Ww, C, mode, st));
   } else {
     IEEE_TRY(ieee_cim_tail_bwd_g(F(N.dPp), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
                                  P(N.gbuf[1]), nullptr, dt, B, Hh_, Ww, C, N.parts, 2, nullptr, nullptr, st));
