@@ -319,6 +319,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+struct PoolShifts { int pow2, lw, lh, lc, lq; };   // log2 of Wi, Hi, C, chunks per row when all are powers of two
+
 // ---- the stem's backward in two passes: d(out) of its ReLU(BatchNorm(y)) is the backward of MaxPool2d(3,2,1) applied
 // to dpool, gathered on the fly (pool_gather.h) instead of materialised; g = that * [y*scale+shift > 0].
 // Pass 1: per-channel sums (sum g, sum g*y); pass 2: dy = k1*g + k2*y + k3.  Replaces maxpool_bwd + bn_bwd_reduce +
@@ -329,7 +331,8 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_reduce_kernel(const T* __re
                                                                    const T* __restrict__ y, int64_t y_gs, int64_t p_gs,
                                                                    RedGeom g, int Hi, int Wi, int Ho, int Wo,
                                                                    float* partial, int64_t partial_gs,
-                                                                   const float* __restrict__ stats, int64_t stats_gs) {
+                                                                   const float* __restrict__ stats, int64_t stats_gs,
+                                                                   PoolShifts ps) {
   constexpr int VEC = 16 / sizeof(T);
   const T* dd = dpool + blockIdx.y * p_gs;
   const uint8_t* aa = arg + blockIdx.y * p_gs;
@@ -337,8 +340,16 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_reduce_kernel(const T* __re
   const float* sc = stats + blockIdx.y * stats_gs + 2 * g.C;
   const float* sh = sc + g.C;
   reduce_channels<T, 2>(g, partial, partial_gs, [&](int64_t off, int c0, float (*acc)[VEC]) {
-    const int row = (int)(off / g.C);
-    const int w = row % Wi, h = (row / Wi) % Hi, b = row / (Wi * Hi);
+    // (fewer than 2^31 elements per group: 32-bit index math; shifts when every extent is a power of two -- the five
+    // 64- and 32-bit divisions per 16 bytes made these two kernels VALU-bound at 2.5-2.8 TB/s)
+    int row, w, h, b;
+    if (ps.pow2) {
+      row = (int)((uint32_t)off >> ps.lc);
+      w = row & (Wi - 1); h = (row >> ps.lw) & (Hi - 1); b = row >> (ps.lw + ps.lh);
+    } else {
+      row = (int)((uint32_t)off / (uint32_t)g.C);
+      w = row % Wi; h = (row / Wi) % Hi; b = row / (Wi * Hi);
+    }
     float d[VEC], v[VEC];
     const uint4 yv = *(const uint4*)(yy + off);
     pool_grad_gather<T>(dd, aa, b, h, w, c0 / VEC, Ho, Wo, g.C, d);
@@ -359,7 +370,8 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_apply_kernel(const T* __res
                                                                   const float* __restrict__ coef, int64_t coef_gs,
                                                                   int64_t total_chunks, int cprw, int C, int64_t y_gs,
                                                                   int64_t p_gs, int Hi, int Wi, int Ho, int Wo,
-                                                                  const float* __restrict__ stats, int64_t stats_gs) {
+                                                                  const float* __restrict__ stats, int64_t stats_gs,
+                                                                  PoolShifts ps) {
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
   const float* sc = stats + z * stats_gs + 2 * C;
@@ -371,13 +383,19 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_apply_kernel(const T* __res
   const uint8_t* aa = arg + z * p_gs;
   const T* yy = y + z * y_gs;
   T* oo = dy + z * y_gs;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % cprw);
-    const int row = (int)(i / cprw);
-    const int w = row % Wi, h = (row / Wi) % Hi, b = row / (Wi * Hi);
+  const uint32_t total = (uint32_t)total_chunks, stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int ch, row, w, h, b;
+    if (ps.pow2) {
+      ch = (int)(i & (uint32_t)(cprw - 1)); row = (int)(i >> ps.lq);
+      w = row & (Wi - 1); h = (row >> ps.lw) & (Hi - 1); b = row >> (ps.lw + ps.lh);
+    } else {
+      ch = (int)(i % (uint32_t)cprw); row = (int)(i / (uint32_t)cprw);
+      w = row % Wi; h = (row / Wi) % Hi; b = row / (Wi * Hi);
+    }
     const int c0 = ch * VEC;
     float d[VEC], v[VEC];
-    const uint4 yv = *(const uint4*)(yy + i * VEC);
+    const uint4 yv = *(const uint4*)(yy + (int64_t)i * VEC);
     pool_grad_gather<T>(dd, aa, b, h, w, ch, Ho, Wo, C, d);
     Vec16<T>::unpack(yv, v);
 #pragma unroll
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_apply_kernel(const T* __res
       const float m = (v[e] * sc[c0 + e] + sh[c0 + e]) > 0.f ? d[e] : 0.f;
       v[e] = k1[c0 + e] * m + k2[c0 + e] * v[e] + k3[c0 + e];
     }
-    *(uint4*)(oo + i * VEC) = Vec16<T>::pack(v);
+    *(uint4*)(oo + (int64_t)i * VEC) = Vec16<T>::pack(v);
   }
 }
 
@@ -535,12 +553,16 @@ extern "C" int ieee_bn2d_bwd_pooled(const void* dpool, const uint8_t* argmax, co
   RedGeom g = red_geom(M, (int)C, vec_of(dtype));
   const int64_t partial_gs = (int64_t)g.rblocks * 2 * C;
   dim3 rgrid(g.cblocks * g.rblocks, (unsigned)groups);
+  auto lg = [](int64_t v) { int l = 0; while ((1ll << l) < v) ++l; return ((1ll << l) == v) ? l : -1; };
+  PoolShifts ps;
+  ps.lw = lg(Wi); ps.lh = lg(Hi); ps.lc = lg(C); ps.lq = lg(g.cprw);
+  ps.pow2 = (ps.lw >= 0 && ps.lh >= 0 && ps.lc >= 0 && ps.lq >= 0) ? 1 : 0;
   if (dtype == IEEE_F32)
     bn_bwd_pooled_reduce_kernel<float><<<rgrid, 256, 0, st>>>((const float*)dpool, argmax, (const float*)y, y_gs, p_gs, g,
-                                                              (int)Hi, (int)Wi, Ho, Wo, partial, partial_gs, stats, 4 * C);
+                                                              (int)Hi, (int)Wi, Ho, Wo, partial, partial_gs, stats, 4 * C, ps);
   else
     bn_bwd_pooled_reduce_kernel<bf16><<<rgrid, 256, 0, st>>>((const bf16*)dpool, argmax, (const bf16*)y, y_gs, p_gs, g,
-                                                             (int)Hi, (int)Wi, Ho, Wo, partial, partial_gs, stats, 4 * C);
+                                                             (int)Hi, (int)Wi, Ho, Wo, partial, partial_gs, stats, 4 * C, ps);
   IEEE_TRY(launch_status("bn_bwd_pooled_reduce_kernel"));
   const int lpc = finalize_lpc(g.rblocks);
   bn_bwd_finalize_kernel<<<dim3(cdiv(C, 256 / lpc), (unsigned)groups), 256, 0, st>>>(
@@ -552,10 +574,10 @@ extern "C" int ieee_bn2d_bwd_pooled(const void* dpool, const uint8_t* argmax, co
   if (dtype == IEEE_F32)
     bn_bwd_pooled_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)dpool, argmax, (const float*)y, (float*)dy, coef,
                                                             3 * C, chunks, g.cprw, (int)C, y_gs, p_gs, (int)Hi, (int)Wi, Ho,
-                                                            Wo, stats, 4 * C);
+                                                            Wo, stats, 4 * C, ps);
   else
     bn_bwd_pooled_apply_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)dpool, argmax, (const bf16*)y, (bf16*)dy, coef,
                                                            3 * C, chunks, g.cprw, (int)C, y_gs, p_gs, (int)Hi, (int)Wi, Ho,
-                                                           Wo, stats, 4 * C);
+                                                           Wo, stats, 4 * C, ps);
   return launch_status("bn_bwd_pooled_apply_kernel");
 }

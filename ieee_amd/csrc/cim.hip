@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_bf16_kernel(const float* x0
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                           uint8_t* __restrict__ arg, int B, int Hi, int Wi, int C,
-                                                          int Ho, int Wo, int64_t x_gs, int64_t o_gs) {
+                                                          int Ho, int Wo, int64_t x_gs, int64_t o_gs, int lq, int lw,
+                                                          int lh) {
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
   const int cprw = C / VEC;
@@ -80,11 +81,18 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
   out += z * o_gs;
   arg += z * o_gs;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int ch = i % cprw;
-    int p = i / cprw;
-    const int q = p % Wo; p /= Wo;
-    const int pp = p % Ho;
-    const int b = p / Ho;
+    int ch, q, pp, b;
+    if (lq >= 0) {      // chunks per pixel, Wo and Ho are powers of two: shifts instead of three 32-bit divisions
+      ch = i & (cprw - 1);
+      const int p = i >> lq;
+      q = p & (Wo - 1); pp = (p >> lw) & (Ho - 1); b = p >> (lw + lh);
+    } else {
+      ch = i % cprw;
+      int p = i / cprw;
+      q = p % Wo; p /= Wo;
+      pp = p % Ho;
+      b = p / Ho;
+    }
     float best[VEC];
     int bi[VEC];
 #pragma unroll
@@ -707,8 +715,11 @@ extern "C" int ieee_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, 
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(ew_blocks2(B * Ho * Wo * C / vecw(dtype)), (unsigned)groups);
   const int64_t xgs = B * Hi * Wi * C, ogs = B * Ho * Wo * C;
-  DISPATCH_T(dtype, (maxpool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (float*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs)),
-             (maxpool_fwd_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)x, (bf16*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs)));
+  auto lg = [](int64_t v) { int l = 0; while ((1ll << l) < v) ++l; return ((1ll << l) == v) ? l : -1; };
+  int lq = lg(C / vecw(dtype)), lw = lg(Wo), lh = lg(Ho);
+  if (lq < 0 || lw < 0 || lh < 0) lq = -1;
+  DISPATCH_T(dtype, (maxpool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (float*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs, lq, lw, lh)),
+             (maxpool_fwd_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)x, (bf16*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs, lq, lw, lh)));
   return launch_status("maxpool_fwd_kernel");
 }
 

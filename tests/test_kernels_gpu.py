@@ -88,14 +88,15 @@ def test_bn2d_fwd_bwd(dtype, G, M, C, residual, relu):
                                                               else dict(rtol=1e-6, atol=1e-6)))
 
 
+@pytest.mark.parametrize("hw", [(14, 10), (16, 8)])    # general index math / the all-powers-of-two shift path
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_stem_pooled_bn_backward(dtype):
+def test_stem_pooled_bn_backward(dtype, hw):
     """ieee_bn2d_bwd_pooled (the stem: max-pool backward gathered inside the two passes of the BatchNorm backward) against
     the chain it replaces, maxpool_bwd -> bn2d_bwd(mask from y).  fp32: same numbers up to the contraction of one
     multiply-add; bf16: the chain rounds the un-pooled gradient to bf16 in between, the fused form does not"""
     L, lib = _lib()
     g = torch.Generator().manual_seed(5)
-    G, B, H, W, C = 3, 3, 14, 10, 64
+    G, B, (H, W), C = 3, 3 if hw[0] == 14 else 4, hw, 64
     dev = "cuda"
     y = (torch.randn(G, B, H, W, C, generator=g) * 1.5 + 0.2).to(dev, dtype)
     gam, bet = (torch.rand(G, C, generator=g) + 0.5).to(dev), (torch.randn(G, C, generator=g) * 0.3).to(dev)
@@ -132,11 +133,12 @@ def test_stem_pooled_bn_backward(dtype):
     torch.testing.assert_close(res[1][2], res[0][2], **gt)
 
 
+@pytest.mark.parametrize("hw", [(12, 10), (16, 8)])    # general index math / the all-powers-of-two shift path
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_maxpool_fwd_bwd(dtype):
+def test_maxpool_fwd_bwd(dtype, hw):
     L, lib = _lib()
     g = torch.Generator().manual_seed(0)
-    G, B, H, W, C = 3, 2, 12, 10, 64
+    G, B, (H, W), C = 3, 2, hw, 64
     x = torch.randn(G, B, C, H, W, generator=g)
     if dtype == torch.bfloat16:
         x = x.to(dtype).float()
