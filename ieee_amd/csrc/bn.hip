@@ -7,6 +7,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include "common.h"
 #include "pool_gather.h"
 
@@ -407,6 +408,119 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_apply_kernel(const T* __res
   }
 }
 
+// The same two passes with the pooled gradient staged in LDS: one workgroup per pair of input rows (2p, 2p + 1) of one image.
+// Those 2 x Wi pixels receive gradient from the pooled rows p and p + 1 only, which are brought into LDS once (values +
+// argmax bytes, contiguous in memory) instead of being gathered from L2 by every pixel (four 16-byte + four 8-byte loads per
+// 16 bytes of output: 2.8 TB/s on the last stretch of the step, where nothing else runs).  The windows are visited in the
+// order of pool_grad_gather, so pass 2 gives the same bits as the gathering form; pass 1 leaves one row of partial sums per
+// workgroup ([rblock][2][C], rblock = blockIdx.x).  Needs Hi = 2 Ho, Wi = 2 Wo, 256 % (C / VEC) == 0.
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_pooled_tiled_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ arg,
+                                                                  const T* __restrict__ y, T* __restrict__ dy,
+                                                                  const float* __restrict__ coef, int64_t coef_gs,
+                                                                  float* __restrict__ partial, int64_t partial_gs, int C,
+                                                                  int64_t y_gs, int64_t p_gs, int Hi, int Wi, int Ho, int Wo,
+                                                                  const float* __restrict__ stats, int64_t stats_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char pooled_lds[];
+  const int z = blockIdx.y, t = threadIdx.x;
+  const int hp = Hi >> 1;
+  const int b = blockIdx.x / hp, p = blockIdx.x - b * hp;
+  const int cprw = C / VEC, rowel = Wo * C;
+  T* sd = (T*)pooled_lds;                                        // [2][Wo][C]
+  uint8_t* sa = (uint8_t*)(pooled_lds + 2 * rowel * sizeof(T));  // [2][Wo][C]
+  const bool has2 = p + 1 < Ho;
+  {
+    const int64_t o = z * p_gs + ((int64_t)b * Ho + p) * rowel;
+    const uint4* dsrc = (const uint4*)(dpool + o);
+    const uint4* asrc = (const uint4*)(arg + o);
+    const int nd = (has2 ? 2 : 1) * rowel / VEC, na = (has2 ? 2 : 1) * rowel / 16;
+    for (int i = t; i < nd; i += 256) ((uint4*)sd)[i] = dsrc[i];
+    for (int i = t; i < na; i += 256) ((uint4*)sa)[i] = asrc[i];
+  }
+  __syncthreads();
+  const float* sc = stats + z * stats_gs + 2 * C;
+  const float* sh = sc + C;
+  const float* k1 = coef + z * coef_gs;
+  const float* k2 = k1 + C;
+  const float* k3 = k2 + C;
+  const T* yy = y + z * y_gs + (int64_t)b * Hi * Wi * C;
+  T* oo = APPLY ? dy + z * y_gs + (int64_t)b * Hi * Wi * C : nullptr;
+  const int ch = t % cprw, c0 = ch * VEC;    // fixed per thread: 256 % cprw == 0
+  float scl[VEC], shf[VEC], a1[VEC], a2[VEC], a3[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    scl[e] = sc[c0 + e]; shf[e] = sh[c0 + e];
+    if (APPLY) { a1[e] = k1[c0 + e]; a2[e] = k2[c0 + e]; a3[e] = k3[c0 + e]; } else { a1[e] = 0.f; a2[e] = 0.f; a3[e] = 0.f; }
+  }
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  const int ppr = 256 / cprw;                // pixels per pass of the block
+  for (int px = t / cprw; px < 2 * Wi; px += ppr) {
+    const int r = px >= Wi ? 1 : 0, w = px - r * Wi;
+    const int q0 = w >> 1, lr0 = r + 1, lc0 = (w & 1) + 1;
+    const bool c1 = (w & 1) && q0 + 1 < Wo, r1 = r == 1 && has2;
+    const int64_t off = ((int64_t)(2 * p + r) * Wi + w) * C + c0;
+    const uint4 yv = *(const uint4*)(yy + off);
+    float d[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) d[e] = 0.f;
+    auto window = [&](int lrow, int q, int local) {
+      const int o = (lrow * Wo + q) * C + c0;
+      float g[VEC];
+      Vec16<T>::unpack(*(const uint4*)(sd + o), g);
+      if constexpr (VEC == 8) {
+        const uint2 av = *(const uint2*)(sa + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if ((int)((av.x >> (8 * e)) & 0xff) == local) d[e] += g[e];
+          if ((int)((av.y >> (8 * e)) & 0xff) == local) d[4 + e] += g[4 + e];
+        }
+      } else {
+        const uint32_t av = *(const uint32_t*)(sa + o);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if ((int)((av >> (8 * e)) & 0xff) == local) d[e] += g[e];
+      }
+    };
+    window(0, q0, lr0 * 3 + lc0);
+    if (c1) window(0, q0 + 1, lr0 * 3);
+    if (r1) window(1, q0, lc0);
+    if (r1 && c1) window(1, q0 + 1, 0);
+    float v[VEC];
+    Vec16<T>::unpack(yv, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float m = (v[e] * scl[e] + shf[e]) > 0.f ? d[e] : 0.f;
+      if (APPLY) {
+        v[e] = a1[e] * m + a2[e] * v[e] + a3[e];
+      } else {
+        s1[e] += m;
+        s2[e] += m * v[e];
+      }
+    }
+    if (APPLY) *(uint4*)(oo + off) = Vec16<T>::pack(v);
+  }
+  if constexpr (!APPLY) {
+    float* red = (float*)pooled_lds;          // [256][VEC], one quantity at a time (the launcher sizes LDS for it)
+    float* out = partial + z * partial_gs + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) red[t * VEC + e] = qn == 0 ? s1[e] : s2[e];
+      __syncthreads();
+      for (int c = t; c < C; c += 256) {
+        const int cc = c / VEC, e = c - cc * VEC;
+        float s = 0.f;
+        for (int k = cc; k < 256; k += cprw) s += red[k * VEC + e];
+        out[qn * C + c] = s;
+      }
+    }
+  }
+}
+
 static int ew_blocks(int64_t chunks) {
   static const int64_t cap = getenv("IEEE_EW_BLOCKS") ? atoll(getenv("IEEE_EW_BLOCKS")) : 8192;   // 4096: +0.13 ms per step; 16384 and more: same as 8192 (scripts/scan_ew.sh)
   int64_t b = (chunks + 255) / 256;
@@ -423,7 +537,8 @@ static int vec_of(int dtype) { return dtype == IEEE_BF16 ? 8 : 4; }
 
 extern "C" int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C) {
   const RedGeom g = red_geom(M, (int)C, vec_of(dtype));
-  return (int64_t)g.rblocks * 2 * C;
+  const int64_t rb = std::max((int64_t)g.rblocks, (M + 127) / 128);   // (M + 127) / 128: the tiled pooled backward's row blocks
+  return rb * 2 * C;
 }
 
 extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
@@ -551,6 +666,37 @@ extern "C" int ieee_bn2d_bwd_pooled(const void* dpool, const uint8_t* argmax, co
   const int Ho = (int)((Hi + 2 - 3) / 2 + 1), Wo = (int)((Wi + 2 - 3) / 2 + 1);
   const int64_t y_gs = M * C, p_gs = B * Ho * Wo * C;
   RedGeom g = red_geom(M, (int)C, vec_of(dtype));
+  {
+    static const bool tiled_on = !(getenv("IEEE_POOLED_TILED") && atoi(getenv("IEEE_POOLED_TILED")) == 0);
+    const int vec = vec_of(dtype), es = dtype == IEEE_BF16 ? 2 : 4;
+    const int64_t cprw = C / vec, rowel = (int64_t)Wo * C;
+    const int64_t lds = std::max<int64_t>(2 * rowel * (es + 1), 256 * vec * 4);
+    const int64_t rbt = B * (Hi / 2);
+    if (tiled_on && Hi == 2 * Ho && Wi == 2 * Wo && Wi >= 64 && 256 % cprw == 0 && rowel % 16 == 0 && lds <= 64 * 1024 &&
+        rbt <= (M + 127) / 128) {
+      const int64_t partial_gs = rbt * 2 * C;
+      dim3 tgrid((unsigned)rbt, (unsigned)groups);
+      if (dtype == IEEE_F32)
+        bn_bwd_pooled_tiled_kernel<float, false><<<tgrid, 256, lds, st>>>((const float*)dpool, argmax, (const float*)y, nullptr,
+            coef, 3 * C, partial, partial_gs, (int)C, y_gs, p_gs, (int)Hi, (int)Wi, Ho, Wo, stats, 4 * C);
+      else
+        bn_bwd_pooled_tiled_kernel<bf16, false><<<tgrid, 256, lds, st>>>((const bf16*)dpool, argmax, (const bf16*)y, nullptr,
+            coef, 3 * C, partial, partial_gs, (int)C, y_gs, p_gs, (int)Hi, (int)Wi, Ho, Wo, stats, 4 * C);
+      IEEE_TRY(launch_status("bn_bwd_pooled_tiled_kernel(reduce)"));
+      const int lpc = finalize_lpc(rbt);
+      bn_bwd_finalize_kernel<<<dim3(cdiv(C, 256 / lpc), (unsigned)groups), 256, 0, st>>>(
+          partial, partial_gs, (int)rbt, (int)M, (int)C, gamma, param_gs, stats, 4 * C, dgamma, dbeta, grad_gs, coef, 3 * C,
+          accumulate, 0, lpc);
+      IEEE_TRY(launch_status("bn_bwd_finalize_kernel"));
+      if (dtype == IEEE_F32)
+        bn_bwd_pooled_tiled_kernel<float, true><<<tgrid, 256, lds, st>>>((const float*)dpool, argmax, (const float*)y, (float*)dy,
+            coef, 3 * C, nullptr, 0, (int)C, y_gs, p_gs, (int)Hi, (int)Wi, Ho, Wo, stats, 4 * C);
+      else
+        bn_bwd_pooled_tiled_kernel<bf16, true><<<tgrid, 256, lds, st>>>((const bf16*)dpool, argmax, (const bf16*)y, (bf16*)dy,
+            coef, 3 * C, nullptr, 0, (int)C, y_gs, p_gs, (int)Hi, (int)Wi, Ho, Wo, stats, 4 * C);
+      return launch_status("bn_bwd_pooled_tiled_kernel(apply)");
+    }
+  }
   const int64_t partial_gs = (int64_t)g.rblocks * 2 * C;
   dim3 rgrid(g.cblocks * g.rblocks, (unsigned)groups);
   auto lg = [](int64_t v) { int l = 0; while ((1ll << l) < v) ++l; return ((1ll << l) == v) ? l : -1; };

@@ -88,7 +88,8 @@ def test_bn2d_fwd_bwd(dtype, G, M, C, residual, relu):
                                                               else dict(rtol=1e-6, atol=1e-6)))
 
 
-@pytest.mark.parametrize("hw", [(14, 10), (16, 8)])    # general index math / the all-powers-of-two shift path
+# general index math / the all-powers-of-two shift path / the LDS-tiled form (even extents, >= 64 columns), also ragged in h
+@pytest.mark.parametrize("hw", [(14, 10), (16, 8), (8, 64), (6, 128)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_stem_pooled_bn_backward(dtype, hw):
     """ieee_bn2d_bwd_pooled (the stem: max-pool backward gathered inside the two passes of the BatchNorm backward) against
