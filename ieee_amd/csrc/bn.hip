@@ -13,7 +13,10 @@
 
 namespace ieee {
 
-constexpr int RED_MAX_BLOCKS = 768;
+#ifndef IEEE_RED_MAX_BLOCKS
+#define IEEE_RED_MAX_BLOCKS 768
+#endif
+constexpr int RED_MAX_BLOCKS = IEEE_RED_MAX_BLOCKS;
 
 struct RedGeom {
   int M, C;        // rows, channels
