@@ -67,15 +67,20 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_bf16_kernel(const float* x0
   }
 }
 
-// MaxPool2d(kernel 3, stride 2, pad 1) over NHWC; arg = window-local index (0..8) of the first maximum
-template <typename T>
+// MaxPool2d(kernel 3, stride 2, pad 1) over NHWC; arg = window-local index (0..8) of the first maximum.
+// AFFINE: x is the raw conv output y of the stem and the pooled tensor is max over relu(y * scale + shift) ROUNDED to T --
+// exactly the values bn_apply_kernel would have stored, so pool / argmax are the bits of the two-kernel form while the
+// full-resolution activation (written once, read 2.25 times) never exists (training forward of the stem: nothing else reads it)
+template <typename T, bool AFFINE>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                           uint8_t* __restrict__ arg, int B, int Hi, int Wi, int C,
                                                           int Ho, int Wo, int64_t x_gs, int64_t o_gs, int lq, int lw,
-                                                          int lh) {
+                                                          int lh, const float* __restrict__ stats, int64_t stats_gs) {
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
   const int cprw = C / VEC;
+  const float* sc = AFFINE ? stats + z * stats_gs + 2 * C : nullptr;
+  const float* sh = AFFINE ? sc + C : nullptr;
   const int total = B * Ho * Wo * cprw;   // < 2^31 (checked by the launcher): 32-bit index arithmetic
   x += z * x_gs;
   out += z * o_gs;
@@ -107,6 +112,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         if ((unsigned)w >= (unsigned)Wi) continue;
         float v[VEC];
         Vec16<T>::unpack(*(const uint4*)(x + (((int64_t)b * Hi + h) * Wi + w) * C + ch * VEC), v);
+        if constexpr (AFFINE) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e] * sc[ch * VEC + e] + sh[ch * VEC + e], 0.f);
+          Vec16<T>::unpack(Vec16<T>::pack(v), v);     // the rounding of the stored activation
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
           if (v[e] > best[e]) { best[e] = v[e]; bi[e] = r * 3 + s; }
@@ -115,6 +125,70 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     const int64_t o = (((int64_t)b * Ho + pp) * Wo + q) * C + ch * VEC;
     *(uint4*)(out + o) = Vec16<T>::pack(best);
     if constexpr (VEC == 8) {           // the 8 argmax bytes as one 8-byte store
+      uint2 pk = make_uint2(0u, 0u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pk.x |= (unsigned)bi[e] << (8 * e); pk.y |= (unsigned)bi[4 + e] << (8 * e); }
+      *(uint2*)(arg + o) = pk;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) arg[o + e] = (uint8_t)bi[e];
+    }
+  }
+}
+
+// The AFFINE form with the three input rows of one pooled row staged in LDS: one workgroup per (image, pooled row); every
+// element gets its scale / shift / ReLU / rounding once (each input row serves 1.5 pooled rows on average instead of being
+// fetched by 2.25 windows through L1), and the 3 x 3 windows are scanned out of LDS in the order of maxpool_fwd_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_tiled_kernel(const T* __restrict__ y, T* __restrict__ out,
+                                                                    uint8_t* __restrict__ arg, int Hi, int Wi, int C, int Ho,
+                                                                    int Wo, int64_t x_gs, int64_t o_gs,
+                                                                    const float* __restrict__ stats, int64_t stats_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char pool_lds[];
+  T* sa = (T*)pool_lds;                  // [3][Wi][C]
+  const int z = blockIdx.y, t = threadIdx.x;
+  const int b = blockIdx.x / Ho, p = blockIdx.x - b * Ho;
+  const int cprw = C / VEC, rowch = Wi * cprw;
+  const float* sc = stats + z * stats_gs + 2 * C;
+  const float* sh = sc + C;
+  const T* yy = y + z * x_gs + (int64_t)b * Hi * Wi * C;
+  for (int idx = t; idx < 3 * rowch; idx += 256) {
+    const int r = idx / rowch, rem = idx - r * rowch;
+    const int h = 2 * p - 1 + r;
+    if ((unsigned)h >= (unsigned)Hi) continue;
+    const int c0 = (rem % cprw) * VEC;
+    float v[VEC];
+    Vec16<T>::unpack(*(const uint4*)(yy + ((int64_t)h * Wi) * C + (int64_t)rem * VEC), v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = fmaxf(v[e] * sc[c0 + e] + sh[c0 + e], 0.f);
+    *(uint4*)(sa + (int64_t)idx * VEC) = Vec16<T>::pack(v);
+  }
+  __syncthreads();
+  for (int idx = t; idx < Wo * cprw; idx += 256) {
+    const int q = idx / cprw, ch = idx - q * cprw;
+    float best[VEC];
+    int bi[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int h = 2 * p - 1 + r;
+      if ((unsigned)h >= (unsigned)Hi) continue;
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) {
+        const int w = q * 2 - 1 + s2;
+        if ((unsigned)w >= (unsigned)Wi) continue;
+        float v[VEC];
+        Vec16<T>::unpack(*(const uint4*)(sa + ((int64_t)(r * Wi + w) * cprw + ch) * VEC), v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (v[e] > best[e]) { best[e] = v[e]; bi[e] = r * 3 + s2; }
+      }
+    }
+    const int64_t o = z * o_gs + (((int64_t)b * Ho + p) * Wo + q) * C + ch * VEC;
+    *(uint4*)(out + o) = Vec16<T>::pack(best);
+    if constexpr (VEC == 8) {
       uint2 pk = make_uint2(0u, 0u);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { pk.x |= (unsigned)bi[e] << (8 * e); pk.y |= (unsigned)bi[4 + e] << (8 * e); }
@@ -718,9 +792,36 @@ extern "C" int ieee_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, 
   auto lg = [](int64_t v) { int l = 0; while ((1ll << l) < v) ++l; return ((1ll << l) == v) ? l : -1; };
   int lq = lg(C / vecw(dtype)), lw = lg(Wo), lh = lg(Ho);
   if (lq < 0 || lw < 0 || lh < 0) lq = -1;
-  DISPATCH_T(dtype, (maxpool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (float*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs, lq, lw, lh)),
-             (maxpool_fwd_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)x, (bf16*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs, lq, lw, lh)));
+  DISPATCH_T(dtype, (maxpool_fwd_kernel<float, false><<<grid, 256, 0, st>>>((const float*)x, (float*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs, lq, lw, lh, nullptr, 0)),
+             (maxpool_fwd_kernel<bf16, false><<<grid, 256, 0, st>>>((const bf16*)x, (bf16*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs, lq, lw, lh, nullptr, 0)));
   return launch_status("maxpool_fwd_kernel");
+}
+
+extern "C" int ieee_bn_relu_maxpool3x3s2_fwd(const void* y, const float* stats, void* out, uint8_t* argmax, int dtype,
+                                             int64_t groups, int64_t B, int64_t Hi, int64_t Wi, int64_t C, void* stream) {
+  IEEE_REQUIRE(y && stats && out && argmax, "bn_relu_maxpool_fwd: null pointer");
+  IEEE_REQUIRE(C % vecw(dtype) == 0, "bn_relu_maxpool_fwd: C not a multiple of the vector width");
+  IEEE_REQUIRE(B * Hi * Wi * C < (1ll << 31), "bn_relu_maxpool_fwd: more than 2^31 elements per group");
+  const int Ho = (int)((Hi + 2 - 3) / 2 + 1), Wo = (int)((Wi + 2 - 3) / 2 + 1);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ew_blocks2(B * Ho * Wo * C / vecw(dtype)), (unsigned)groups);
+  const int64_t xgs = B * Hi * Wi * C, ogs = B * Ho * Wo * C;
+  {
+    static const bool tiled_on = !(getenv("IEEE_POOL_TILED") && atoi(getenv("IEEE_POOL_TILED")) == 0);
+    const int64_t lds = 3 * Wi * C * (dtype == IEEE_BF16 ? 2 : 4);
+    if (tiled_on && lds <= 64 * 1024 && Wi >= 32) {
+      dim3 tgrid((unsigned)(B * Ho), (unsigned)groups);
+      DISPATCH_T(dtype, (bn_relu_maxpool_tiled_kernel<float><<<tgrid, 256, lds, st>>>((const float*)y, (float*)out, argmax, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs, stats, 4 * C)),
+                 (bn_relu_maxpool_tiled_kernel<bf16><<<tgrid, 256, lds, st>>>((const bf16*)y, (bf16*)out, argmax, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs, stats, 4 * C)));
+      return launch_status("bn_relu_maxpool_tiled_kernel");
+    }
+  }
+  auto lg = [](int64_t v) { int l = 0; while ((1ll << l) < v) ++l; return ((1ll << l) == v) ? l : -1; };
+  int lq = lg(C / vecw(dtype)), lw = lg(Wo), lh = lg(Ho);
+  if (lq < 0 || lw < 0 || lh < 0) lq = -1;
+  DISPATCH_T(dtype, (maxpool_fwd_kernel<float, true><<<grid, 256, 0, st>>>((const float*)y, (float*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs, lq, lw, lh, stats, 4 * C)),
+             (maxpool_fwd_kernel<bf16, true><<<grid, 256, 0, st>>>((const bf16*)y, (bf16*)out, argmax, (int)B, (int)Hi, (int)Wi, (int)C, Ho, Wo, xgs, ogs, lq, lw, lh, stats, 4 * C)));
+  return launch_status("maxpool_fwd_kernel(affine)");
 }
 
 extern "C" int ieee_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int dtype, int64_t groups,

@@ -778,13 +778,22 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
   const ConvUnit& s = N.units[N.u_stem];
   static const bool fuse_eval = !(getenv("IEEE_EVAL_FUSE") && atoi(getenv("IEEE_EVAL_FUSE")) == 0);
   const bool fe = !training && fuse_eval;        // inference: BatchNorm folded into the conv epilogues
+  bool stem_pool_fused = false;
   if (fe) {
     IEEE_TRY(conv_bn_eval(s, P(N.x0), nullptr, P(s.a), 1));
   } else {
     IEEE_TRY(conv(s, P(N.x0), training != 0));
-    IEEE_TRY(bn(s, nullptr, P(s.a), 1, training));
+    // training: BatchNorm apply + ReLU + max-pool in one pass over y (IEEE_STEM_POOL_FUSE=0: two passes with the
+    // full-resolution activation written and read back).  Nothing else reads the stem's activation in a training step (its
+    // backward masks from y), so the tensor "<stem>.a" is NOT written then.
+    static const bool fuse_pool = !(getenv("IEEE_STEM_POOL_FUSE") && atoi(getenv("IEEE_STEM_POOL_FUSE")) == 0);
+    stem_pool_fused = training && fuse_pool;
+    IEEE_TRY(bn(s, nullptr, stem_pool_fused ? nullptr : P(s.a), 1, training));
   }
-  IEEE_TRY(ieee_maxpool3x3s2_fwd(P(s.a), P(N.pool), (uint8_t*)P(N.pool_arg), dt, 3, B, s.Ho, s.Wo, s.Co, st));
+  if (stem_pool_fused)
+    IEEE_TRY(ieee_bn_relu_maxpool3x3s2_fwd(P(s.y), F(s.stats), P(N.pool), (uint8_t*)P(N.pool_arg), dt, 3, B, s.Ho, s.Wo, s.Co, st));
+  else
+    IEEE_TRY(ieee_maxpool3x3s2_fwd(P(s.a), P(N.pool), (uint8_t*)P(N.pool_arg), dt, 3, B, s.Ho, s.Wo, s.Co, st));
   const void* x = P(N.pool);
   int ds_slot = 0;                    // branch event slots 0..3: forward, 4..7: backward
   for (const Block& b : N.blocks) {   // Bottleneck.forward, resnet.py:164-184

@@ -248,6 +248,13 @@ int ieee_nchw_to_nhwc3(const float* x_rgb, const float* x_ni, const float* x_ti,
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:501); argmax holds the window-local index of the first maximum */
 int ieee_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int dtype, int64_t groups, int64_t B,
                           int64_t Hi, int64_t Wi, int64_t C, void* stream);
+/* The stem's BatchNorm apply + ReLU + max-pool in one pass (training forward): pooled = maxpool(relu(y * scale + shift)) with
+ * scale / shift from `stats` ([groups][4][C]: mean, invstd, scale, shift, as ieee_bn2d_fwd leaves them) and the activation
+ * rounded to the storage type before the comparison -- out / argmax are bit-identical to ieee_bn2d_fwd(out = a, relu) followed
+ * by ieee_maxpool3x3s2_fwd(a), without the full-resolution activation ever being written (torchreid/models/resnet.py:622-626). */
+int ieee_bn_relu_maxpool3x3s2_fwd(const void* y, const float* stats, void* out, uint8_t* argmax, int dtype, int64_t groups,
+                                  int64_t B, int64_t Hi, int64_t Wi, int64_t C, void* stream);
+
 int ieee_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int dtype, int64_t groups,
                           int64_t B, int64_t Hi, int64_t Wi, int64_t C, void* stream);
 

@@ -172,7 +172,11 @@ def test_every_conv_bn_unit_of_the_b64_bf16_backward_matches_autograd_on_its_ope
         # ---- stem: max-pool backward (the stored arg-max) -> ReLU -> BatchNorm backward -> weight gradient
         dpool = net.tap("backbone.{m}.layer1.0.conv1.dx").view(3, B, 64, 32, 64)[mod].float()
         arg = net.tensor("pool.arg").view(3, B, 64, 32, 64)[mod].long()
-        a0 = net.tensor("backbone.{m}.conv1.a").view(3, B, 128, 64, 64)[mod]
+        # (the training forward does not write the stem's activation; its ReLU mask is [y * scale + shift > 0], which is what
+        # the fused backward recomputes too)
+        y0 = net.tensor("backbone.{m}.conv1.y").view(3, B, 128, 64, 64)[mod].float()
+        st0 = net.tensor("backbone.{m}.conv1.stats").view(3, 4, 64)[mod]
+        a0 = y0 * st0[2] + st0[3]
         pp = torch.arange(64, device="cuda").view(1, 64, 1, 1)
         qq = torch.arange(32, device="cuda").view(1, 1, 32, 1)
         hh, ww = 2 * pp - 1 + arg // 3, 2 * qq - 1 + arg % 3

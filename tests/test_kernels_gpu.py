@@ -134,6 +134,37 @@ def test_stem_pooled_bn_backward(dtype, hw):
     torch.testing.assert_close(res[1][2], res[0][2], **gt)
 
 
+@pytest.mark.parametrize("hw", [(12, 10), (16, 8), (7, 9), (9, 33), (8, 64)])    # >= 32 columns: the LDS-tiled form
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_relu_maxpool_in_one_pass_equals_the_two_kernel_form(dtype, hw):
+    """ieee_bn_relu_maxpool3x3s2_fwd (the stem's training forward: the full-resolution activation is never written) against
+    ieee_bn2d_fwd(out = a, relu) -> ieee_maxpool3x3s2_fwd(a): pooled values and argmax bytes must be the same bits."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(9)
+    G, B, (H, W), C = 3, 3, hw, 64
+    dt = L.IEEE_BF16 if dtype == torch.bfloat16 else L.IEEE_F32
+    y = (torch.randn(G, B, H, W, C, generator=g) * 1.3 - 0.1).cuda().to(dtype)
+    gam, bet = (torch.rand(G, C, generator=g) + 0.5).cuda(), (torch.randn(G, C, generator=g) * 0.3).cuda()
+    M = B * H * W
+    stats = torch.empty(G, 4, C, device="cuda")
+    part = torch.empty(G * lib.ieee_bn_partial_floats(dt, M, C) + 64, device="cuda")
+    a = torch.empty_like(y)
+    L.check(lib.ieee_bn2d_fwd(L.ptr(y), None, L.ptr(a), dt, G, M, C, M * C, L.ptr(gam), L.ptr(bet), C, None, None, 0,
+                              L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, 1, 0, None, L.stream()))
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    outs = []
+    for fused in (False, True):
+        out = torch.full((G, B, Ho, Wo, C), -7.0, device="cuda", dtype=dtype)
+        arg = torch.full((G, B, Ho, Wo, C), 77, device="cuda", dtype=torch.uint8)
+        if fused:
+            L.check(lib.ieee_bn_relu_maxpool3x3s2_fwd(L.ptr(y), L.ptr(stats), L.ptr(out), L.ptr(arg), dt, G, B, H, W, C, L.stream()))
+        else:
+            L.check(lib.ieee_maxpool3x3s2_fwd(L.ptr(a), L.ptr(out), L.ptr(arg), dt, G, B, H, W, C, L.stream()))
+        outs.append((out, arg))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[1][0].float().max()) > 0
+
+
 @pytest.mark.parametrize("hw", [(12, 10), (16, 8)])    # general index math / the all-powers-of-two shift path
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool_fwd_bwd(dtype, hw):

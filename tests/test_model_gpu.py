@@ -126,11 +126,13 @@ def test_bf16_mode_drift_not_worse_than_stock_bf16(G):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             o16 = om.forward({k: v.clone() for k, v in sd.items()}, xs, True, taps=t16)
     rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
-    stages = [("stem", "backbone.{m}.conv1.a")] + [("layer%d" % l, "backbone.{m}.layer%d.%d.conv3.a" % (l, last))
-                                                  for l, last in ((1, 2), (2, 3), (3, 5), (4, 2))]
+    # (the training forward never writes the stem's full-resolution activation: its max-pooled form is what exists)
+    stages = [("stem", "pool")] + [("layer%d" % l, "backbone.{m}.layer%d.%d.conv3.a" % (l, last))
+                                  for l, last in ((1, 2), (2, 3), (3, 5), (4, 2))]
+    pooled = lambda t, tap: torch.nn.functional.max_pool2d(t.float(), 3, 2, 1).to(t.dtype) if tap == "stem" else t
     for tap, name in stages:
-        ref = torch.stack([t32["backbone.%d.%s" % (i, tap)] for i in range(3)]).permute(0, 1, 3, 4, 2)
-        stock = torch.stack([t16["backbone.%d.%s" % (i, tap)] for i in range(3)]).permute(0, 1, 3, 4, 2)
+        ref = torch.stack([pooled(t32["backbone.%d.%s" % (i, tap)], tap) for i in range(3)]).permute(0, 1, 3, 4, 2)
+        stock = torch.stack([pooled(t16["backbone.%d.%s" % (i, tap)], tap) for i in range(3)]).permute(0, 1, 3, 4, 2)
         mine = net.tensor(name).view(ref.shape)
         e_mine, e_stock = rel(mine, ref), rel(stock, ref)
         print("%-8s native bf16 %.3e   stock torch bf16 %.3e" % (tap, e_mine, e_stock))
