@@ -1936,7 +1936,8 @@ static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups,
   // L2, few output tiles) gain 20-25 % from twice the workgroups; the 1x1 ones still lose (scripts/scan_wt.sh)
   static const int64_t f_small_taps = getenv("IEEE_WGRAD_TARGET_SMALL_TAPS") ? atoll(getenv("IEEE_WGRAD_TARGET_SMALL_TAPS")) : 896;
   const int64_t small = taps > 1 ? f_small_taps : f_small;
-  const int64_t target = f_target ? f_target : (per_split_bytes <= (1 << 20) ? small : 448);
+  static const int64_t f_big = getenv("IEEE_WGRAD_TARGET_BIG") ? atoll(getenv("IEEE_WGRAD_TARGET_BIG")) : 448;
+  const int64_t target = f_target ? f_target : (per_split_bytes <= (1 << 20) ? small : f_big);
   int64_t want = (target + tiles - 1) / tiles;               // aim at ~`target` workgroups per launch
   const int64_t maxsplit = (npix + 4 * bk - 1) / (4 * bk);   // at least 4 k-tiles per split
   if (want > maxsplit) want = maxsplit;
