@@ -1592,7 +1592,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   a.N = N;
   a.ldw = ldw;
   a.ktiles = cdiv(Ktrue, BK);
-  { static const int grp = getenv("IEEE_TILE_GROUP") ? atoi(getenv("IEEE_TILE_GROUP")) : 8; a.group = grp; }
+  { static const int grp = getenv("IEEE_TILE_GROUP") ? atoi(getenv("IEEE_TILE_GROUP")) : 4; a.group = grp; }
   a.src_gs = src_gs;
   a.w_gs = w_gs;
   a.dst_gs = dst_gs;
