@@ -205,17 +205,25 @@ for staged in (False, True):
 def test_batched_weight_gradient_reductions_leave_the_same_bits():
     """IEEE_WGRAD_BATCH=1 / 2 (one ieee_wgrad_reduce_batch per backward part / per bottleneck block over per-unit slabs)
     against the default (every gradient reduced at once): same partial sums, same fixed order -> the same flat gradient
-    buffer, bit for bit, through the one-call and the staged backward.  (The switch is read once per process.)"""
+    buffer, bit for bit, through the one-call and the staged backward.  (The switch is read once per process.)  The same
+    digest must also come out of the other scheduling-only switches: two instead of three gradient-buffer sets with one
+    cross-stream wait per buffer, XCD tile groups of 8, the stem's activation written and pooled in two passes, no
+    weight-gradient stream at all -- none of them changes a single product or the order of a sum, so a different digest
+    means a race or a wrong buffer."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variants = {"default": {}, "batch1": {"IEEE_WGRAD_BATCH": "1"}, "batch2": {"IEEE_WGRAD_BATCH": "2"},
+                "gbuf2": {"IEEE_GBUF_SETS": "2", "IEEE_GBUF_MERGE": "0"}, "group8": {"IEEE_TILE_GROUP": "8"},
+                "pool2pass": {"IEEE_STEM_POOL_FUSE": "0"}, "one_stream": {"IEEE_WGRAD_ASYNC": "0"}}
     digests = {}
-    for mode in ("0", "1", "2"):
-        env = dict(os.environ, IEEE_WGRAD_BATCH=mode)
+    for name, extra in variants.items():
+        env = dict(os.environ, **extra)
         out = subprocess.run([sys.executable, "-c", _GRAD_DIGEST % root], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         lines = [l.split() for l in out.stdout.splitlines() if l.startswith("DIGEST")]
         assert len(lines) == 2 and all(l[2] == "True" for l in lines), out.stdout
-        digests[mode] = [l[1] for l in lines]
-    assert digests["0"][0] == digests["0"][1]
-    assert digests["1"] == digests["0"] and digests["2"] == digests["0"]
+        digests[name] = [l[1] for l in lines]
+    assert digests["default"][0] == digests["default"][1]
+    for name in variants:
+        assert digests[name] == digests["default"], name
