@@ -113,6 +113,8 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
   int as_wl = 0, as_hl = 0;   // VAR 2: log2 of this map's width / height (powers of two on this path)
   BnFin fin;                  // MODE 1: finalize the BatchNorm statistics in this kernel (pointers already at this group)
   int tn = 0;                 // column-block index (ticket slot)
+  const T* by2 = nullptr;     // MODE 2: second BatchNorm input fed by the same g (BwdStats::y2) ...
+  float* bn_partial2 = nullptr;   // ... and this group's [2][N][tiles_m] block for it (sum g, sum g*y2)
   __device__ __forceinline__ int tile_pixel0(int m0) const {   // pixel of the tile's first row (class offsets included)
     const int per_img = phc * pwc, per_cls = pnimg * per_img;
     const int cls = m0 / per_cls, rc = m0 - cls * per_cls, n = rc / per_img, i0 = (rc - n * per_img) >> pwl;
@@ -143,9 +145,10 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
     __syncthreads();
     const int ch = t % CPRW, r0 = t / CPRW;
     const int n = n0 + ch * VEC;
-    float s1[VEC], s2[VEC];
+    float s1[VEC], s2[VEC], s3[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; s3[e] = 0.f; }
+    const bool has_y2 = MODE == 2 && by2 != nullptr;     // workgroup-uniform
     if (n < N) {
       // The global operands of the epilogue (residual / skip gradient, y and the ReLU mask of the BatchNorm behind this
       // dgrad) are fetched HP row passes at a time, all loads of a batch in flight before the first use: issued one pass
@@ -169,7 +172,7 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
       }
 #pragma unroll
       for (int p0 = 0; p0 < NP; p0 += HP) {
-        uint4 va[HP], vy[HP], vk[HP];
+        uint4 va[HP], vy[HP], vk[HP], vy2[HP];
         unsigned kb[HP];
         int off[HP];
 #pragma unroll
@@ -181,7 +184,7 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
           } else {   // (M is a whole number of tiles on this path)
             off[h] = (pix0 + 2 * (rr >> pwl) * pW + 2 * (rr & (pwc - 1))) * (int)ld + n;
           }
-          va[h] = vy[h] = vk[h] = make_uint4(0, 0, 0, 0);
+          va[h] = vy[h] = vk[h] = vy2[h] = make_uint4(0, 0, 0, 0);
           kb[h] = 0;
         }
         if (has_add) {
@@ -203,6 +206,10 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
         if constexpr (MODE == 2) {
 #pragma unroll
           for (int h = 0; h < HP; ++h) vy[h] = *(const uint4*)(by + off[h]);
+          if (has_y2) {
+#pragma unroll
+            for (int h = 0; h < HP; ++h) vy2[h] = *(const uint4*)(by2 + off[h]);
+          }
           if (has_bits) {
 #pragma unroll
             for (int h = 0; h < HP; ++h) kb[h] = bbits[(unsigned)off[h] >> 3];
@@ -269,6 +276,12 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
               }
 #pragma unroll
               for (int e = 0; e < VEC; ++e) { s1[e] += f[e]; s2[e] += f[e] * yv[e]; }
+              if (has_y2) {
+                float y2v[VEC];
+                Vec16<T>::unpack(vy2[h], y2v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s3[e] += f[e] * y2v[e];
+              }
             }
           }
           *(uint4*)(out + off[h]) = v;
@@ -299,6 +312,23 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
           float* dstp = bn_partial + ((int64_t)q * N + n0 + c) * tiles_m + tile_m;
           if (fuse) __hip_atomic_store(dstp, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
           else *dstp = s;
+          if (MODE == 2 && has_y2 && q == 0) bn_partial2[((int64_t)n0 + c) * tiles_m + tile_m] = s;   // sum g, for the second unit too
+        }
+      }
+      if constexpr (MODE == 2) {
+        if (has_y2) {   // third quantity, sum g*y2, through the same planes
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) red[e * PLANE + t] = s3[e];
+          __syncthreads();
+          for (int c = t; c < BN; c += 256) {
+            const int cc = c / VEC, e = c % VEC;
+            const float* col = red + e * PLANE + cc;
+            float s = 0.f;
+#pragma unroll
+            for (int y = 0; y < RPP; ++y) s += col[y * CPRW];
+            if (n0 + c < N && tile_m < tiles_m) bn_partial2[((int64_t)N + n0 + c) * tiles_m + tile_m] = s;
+          }
         }
       }
       if constexpr (MODE == 1) {
@@ -431,6 +461,11 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
   int mask_bits = 0;         // MODE 2: `mask` is the packed bit form (one byte per 8 channels)
   int addend_s2 = 0;         // MODE 2: the addend is compact at stride 2 (StagedStoreEpi VAR 2)
   BnFin fin;                 // MODE 1: fused BatchNorm finalize (group-0 pointers; the kernels step them by blockIdx.y)
+  // MODE 2, optional: a SECOND BatchNorm fed by the same gradient g (the downsample branch of the block whose output this
+  // dgrad differentiates): y2 = its input tensor (same shape and strides as y), partial2 = its own [2][N][tiles_m] block per
+  // group, which receives sum g (again) and sum g*y2 -- that unit's ieee_bn2d_bwd then skips its reduction pass too
+  const void* y2 = nullptr;
+  float* partial2 = nullptr;
 };
 
 // MODE 1: hand the epilogue its group's finalize operands
@@ -472,6 +507,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
   if constexpr (VAR == 2) { epi.as_wl = __ffs(a.g.Wo) - 1; epi.as_hl = __ffs(a.g.Ho) - 1; }
   if constexpr (MODE == 2) {
     if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
+    if (bs.y2) { epi.by2 = (decltype(epi.by2))bs.y2 + z * bs.act_gs; epi.bn_partial2 = bs.partial2 + (int64_t)z * a.tiles_m * 2 * a.N; }
   }
   if constexpr (PIPE > 0) {   // both operands through LDS-DMA
     static_assert(!SLOW && sizeof(T) == 2, "the LDS-DMA ring is the bf16 vector path");
@@ -564,6 +600,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const bf16* __res
   if constexpr (MODE == 1) set_fin(epi, bs, z, tn, a.tiles_n, a.N);
   if constexpr (MODE == 2) {
     if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
+    if (bs.y2) { epi.by2 = (decltype(epi.by2))bs.y2 + z * bs.act_gs; epi.bn_partial2 = bs.partial2 + (int64_t)z * a.tiles_m * 2 * a.N; }
   }
   constexpr int FM = 4, FN = BN / 32;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
@@ -1885,12 +1922,29 @@ extern "C" int ieee_conv2d_fwd_bn_eval(const void* x, const void* w_packed, void
   IEEE_REQUIRE(false, "conv2d_fwd_bn_eval: bad dtype %d", dtype);
 }
 
+extern "C" int ieee_conv2d_dgrad2(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
+                                  int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
+                                  int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
+                                  float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
+                                  int bn_mask_bits, int addend_stride, const void* bn_y2, float* bn_partial2, void* stream);
+
 extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
                                  int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
                                  int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
                                  float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
                                  int bn_mask_bits, int addend_stride, void* stream) {
+  return ieee_conv2d_dgrad2(dy, w_packed_d, dx, addend, dtype, groups, N, Hi, Wi, Ci, Co, R, S, stride, pad, dy_gs, w_gs, dx_gs,
+                            bn_partial, bn_y, bn_mask, bn_stats, bn_mask_bits, addend_stride, nullptr, nullptr, stream);
+}
+
+extern "C" int ieee_conv2d_dgrad2(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
+                                  int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
+                                  int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
+                                  float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
+                                  int bn_mask_bits, int addend_stride, const void* bn_y2, float* bn_partial2, void* stream) {
   IEEE_REQUIRE(dy && w_packed_d && dx, "conv2d_dgrad: null pointer");
+  IEEE_REQUIRE((bn_y2 == nullptr) == (bn_partial2 == nullptr) && (!bn_y2 || (bn_partial && dtype == IEEE_BF16)),
+               "conv2d_dgrad: the second BatchNorm's sums need its input AND its partial block, in the bf16 fused form");
   IEEE_REQUIRE(addend_stride == 1 || (addend_stride == 2 && addend && bn_partial && dtype == IEEE_BF16 && stride == 1 &&
                                       Hi > 1 && Wi > 1 && !(Hi & (Hi - 1)) && !(Wi & (Wi - 1))),
                "conv2d_dgrad: a stride-2 addend needs the bf16 fused form of a stride-1 conv over a power-of-two map");
@@ -1915,6 +1969,8 @@ extern "C" int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* d
         d.R * d.S <= 56)
       g.perm = 1;
     BwdStats bs{bn_y, bn_mask, bn_stats, dx_gs, 4 * Ci, 0, bn_mask_bits, addend_stride == 2 ? 1 : 0};
+    bs.y2 = bn_y2;
+    bs.partial2 = bn_partial2;
     return launch_gather<bf16>((const bf16*)dy, (const bf16*)w_packed_d, (bf16*)dx, (const bf16*)addend, g, g.npix,
                                d.Ci, d.R * d.S * d.Co, ldw, (int)groups, dy_gs, w_gs, dx_gs, false, st, bn_partial,
                                bn_partial ? &bs : nullptr);

@@ -675,20 +675,27 @@ struct Run {
   }
   // prev: the unit whose BN(+ReLU) output is this conv's input; when given (bf16), the dgrad epilogue also emits
   // that BN's backward sums so that the following bn_bwd(prev) skips its reduction pass
+  // prev_ds: the downsample unit of prev's block (its BatchNorm is fed by the same gradient): the epilogue then emits that
+  // unit's backward sums as well, into the second BN scratch, and its bn_bwd() skips the reduction pass (ds_sums_of)
+  const ConvUnit* ds_sums_of = nullptr;
   int dgrad(const ConvUnit& u, const void* dy, void* dx, const void* addend, const ConvUnit* prev = nullptr,
-            bool prev_mask_tensor = false, int addend_stride = 1) {
+            bool prev_mask_tensor = false, int addend_stride = 1, const ConvUnit* prev_ds = nullptr) {
     const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.S);
     const bool fuse = prev != nullptr && n.dtype == IEEE_BF16;
+    static const bool ds_sums = !(getenv("IEEE_DS_SUMS") && atoi(getenv("IEEE_DS_SUMS")) == 0);
+    const bool fuse2 = fuse && prev_ds != nullptr && ds_sums && !branch_enabled(2);
     fused_bwd = fuse;
+    if (fuse2) ds_sums_of = prev_ds;     // (consumed, and cleared, by that unit's bn_bwd in the next block)
     will_write(dx);
     prof_begin(0, u, "dgrad");
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
-    return ieee_conv2d_dgrad(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
-                             u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, fuse ? bnpart_cur : nullptr,
-                             fuse ? P(prev->y) : nullptr,
-                             (fuse && prev_mask_tensor) ? (prev->abits.numel ? P(prev->abits) : P(prev->a)) : nullptr,
-                             (fuse && !prev_mask_tensor) ? F(prev->stats) : nullptr,
-                             (fuse && prev_mask_tensor && prev->abits.numel) ? 1 : 0, addend_stride, st);
+    return ieee_conv2d_dgrad2(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
+                              u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, fuse ? bnpart_cur : nullptr,
+                              fuse ? P(prev->y) : nullptr,
+                              (fuse && prev_mask_tensor) ? (prev->abits.numel ? P(prev->abits) : P(prev->a)) : nullptr,
+                              (fuse && !prev_mask_tensor) ? F(prev->stats) : nullptr,
+                              (fuse && prev_mask_tensor && prev->abits.numel) ? 1 : 0, addend_stride,
+                              fuse2 ? P(prev_ds->y) : nullptr, fuse2 ? (float*)(ws + n.bnpart2.off) : nullptr, st);
   }
   // The gradient a stride-2 1x1 (downsample) conv sends to its input touches only the pixels with even row and column:
   // kept compact, [B, Ho, Wo, Ci], it is a dense 1x1 stride-1 dgrad over the output grid (the lean plain-matrix path) and the
@@ -1010,7 +1017,11 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
       if (par_ds) {
         branch_join(bslot);
       } else {
-        IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
+        if (ds_sums_of == &d)   // its sums came out of the dgrad that produced this block's d(out)
+          IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr, 0, (float*)(ws + N.bnpart2.off), (d.M(B) + 127) / 128));
+        else
+          IEEE_TRY(bn_bwd(d, Q, nullptr, Q, nullptr));
+        ds_sums_of = nullptr;
         IEEE_TRY(tap(d.name + ".dy", Q, out_numel(d)));
         IEEE_TRY(wgrad(d, Q, xin));
         if (compact) IEEE_TRY(dgrad_compact(d, Q, V));
@@ -1023,7 +1034,8 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     }
     // d(block input) = dgrad(conv1) + identity-branch gradient; it is d(out) of the previous block, whose bn3
     // backward sums (mask = that block's stored output) are emitted here too
-    IEEE_TRY(dgrad(c1, U, Xout, addend, pc3, true, addend_stride));
+    const ConvUnit* pds = (bi > 0 && N.blocks[bi - 1].ds >= 0) ? &N.units[N.blocks[bi - 1].ds] : nullptr;
+    IEEE_TRY(dgrad(c1, U, Xout, addend, pc3, true, addend_stride, pds));
     IEEE_TRY(tap(c1.name + ".dx", Xout, in_numel(c1)));
     if (wgrad_batch_mode() == 2 && bi > 0) IEEE_TRY(wgrad_flush(5 + bi));
     if (bi > 0)   // a layer is complete: reduce its weight gradients (layer1's go with the stem's below)

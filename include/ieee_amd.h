@@ -161,6 +161,16 @@ int ieee_conv2d_dgrad(const void* dy, const void* w_packed_d, void* dx, const vo
                       int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
                       float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
                       int bn_mask_bits, int addend_stride, void* stream);
+/* The same dgrad with the sums of a SECOND BatchNorm that is fed by the same gradient (the downsample branch of the block whose
+ * output this dgrad differentiates; torchreid/models/resnet.py:176-181): bn_y2 = that BatchNorm's input (shape and group stride of
+ * bn_y), bn_partial2 = its own partial block of ieee_conv2d_fwd_stats_rblocks(N, Hi, Wi) * 2 * Ci floats per group, which
+ * receives sum g and sum g*y2 -- its ieee_bn2d_bwd(stats_rblocks > 0) then needs no reduction pass either.  bf16 fused form only. */
+int ieee_conv2d_dgrad2(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
+                      int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
+                      int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
+                      float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
+                      int bn_mask_bits, int addend_stride, const void* bn_y2,
+                      float* bn_partial2, void* stream);
 /* bn_partial != NULL (bf16 only): dx is the gradient w.r.t. the output of a BN(+ReLU) whose input is bn_y; the
  * dgrad epilogue also emits that BN's backward sums [2][Ci][rblocks] (sum g, sum g*y; g = dx * [mask], mask from
  * bn_mask > 0, or from bn_y*scale+shift > 0 with bn_stats = that BN's [4][Ci] stats, or none), rblocks =

@@ -196,6 +196,55 @@ def test_fused_bn_partials_in_conv_epilogues():
         torch.testing.assert_close(p2[:, 1].sum(-1), (gq * yv).sum(1), rtol=1e-3, atol=5e-2)
 
 
+@pytest.mark.parametrize("Ci,Co,R", [(256, 64, 1), (64, 192, 3), (1024, 256, 1)])
+def test_dgrad_epilogue_sums_for_a_second_batchnorm(Ci, Co, R):
+    """ieee_conv2d_dgrad2: the gradient a block-input dgrad produces feeds TWO BatchNorms of the previous block (bn3 and the
+    downsample branch's); the epilogue emits sum g / sum g*y for the first as before and sum g / sum g*y2 for the second into
+    its own partial block.  Stores and the first block's sums must be the bits of ieee_conv2d_dgrad; the second block's sums
+    are checked against direct sums (and plane 0 against the first block's plane 0, bit for bit)."""
+    from ieee_amd import _lib as L, _ops
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(33 + Ci)
+    G, N, H, W = 3, 5, 12, 10            # M = 600 rows: 5 row tiles, the last one partial
+    dt = torch.bfloat16
+    pad = R // 2
+    w = (torch.randn(G, Co, Ci, R, R, generator=g) * 0.05).cuda()
+    wpd = _ops.pack_conv_weight(w, dt, 1)
+    M = N * H * W
+    rb = lib.ieee_conv2d_fwd_stats_rblocks(N, H, W)
+    dy = torch.randn(G, N, H, W, Co, generator=g).cuda().to(dt)
+    y1 = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
+    y2 = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
+    amask = (torch.randn(G, N, H, W, Ci, generator=g) > 0).cuda().to(dt)
+    mbits = ((amask > 0).view(-1, 8).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1).to(torch.uint8)
+    addend = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
+    args = (L.ptr(dy), L.ptr(wpd), None, L.ptr(addend), L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad, dy[0].numel(),
+            wpd.stride(0), addend[0].numel())
+    out = {}
+    for two in (False, True):
+        dx = torch.empty_like(addend)
+        p1 = torch.full((G, 2, Ci, rb), 7.0, device="cuda")
+        p2 = torch.full((G, 2, Ci, rb), 7.0, device="cuda")
+        a = list(args); a[2] = L.ptr(dx)
+        tail = (L.ptr(p1), L.ptr(y1), L.ptr(mbits), None, 1, 1)
+        if two:
+            L.check(lib.ieee_conv2d_dgrad2(*a, *tail, L.ptr(y2), L.ptr(p2), L.stream()))
+        else:
+            L.check(lib.ieee_conv2d_dgrad(*a, *tail, L.stream()))
+        torch.cuda.synchronize()
+        out[two] = (dx, p1, p2)
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    assert float(out[False][2].min()) == 7.0                       # the plain call never touches a second block
+    p2 = out[True][2]
+    assert torch.equal(p2[:, 0], out[True][1][:, 0])
+    gq = out[True][0].float().view(G, M, Ci)                        # the stored masked gradient
+    torch.testing.assert_close(p2[:, 1].sum(-1), (gq * y2.float().view(G, M, Ci)).sum(1), rtol=1e-3, atol=5e-2)
+    # one without the other is refused
+    dx = torch.empty_like(addend)
+    a = list(args); a[2] = L.ptr(dx)
+    assert lib.ieee_conv2d_dgrad2(*a, L.ptr(out[True][1]), L.ptr(y1), L.ptr(mbits), None, 1, 1, L.ptr(y2), None, L.stream()) != 0
+
+
 def test_dgrad_with_compact_stride2_addend():
     """the block-input dgrad whose identity-branch gradient comes from a stride-2 1x1 downsample conv: the compact
     [N, H/2, W/2, C] addend (addend_stride = 2) gives bit for bit the stores and BatchNorm sums of the full-size map that
