@@ -148,10 +148,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
   const int lane = threadIdx.x & (lpc - 1);
   const int c = blockIdx.x * (256 / lpc) + threadIdx.x / lpc;
   const int z = blockIdx.y;
+  // (per-channel operands fetched before the reduction: see bn_bwd_finalize_kernel)
+  const bool owner = c < C && lane == 0;
+  float ga = 0.f, be = 0.f, rm0 = 0.f, rv0 = 0.f;
+  if (owner) {
+    ga = gamma[z * param_gs + c]; be = beta[z * param_gs + c];
+    if (training && running_mean != nullptr) { rm0 = running_mean[z * buf_gs + c]; rv0 = running_var[z * buf_gs + c]; }
+  }
   double s1 = 0.0, s2 = 0.0;
   if (training) sum_partials(partial + z * partial_gs, rblocks, C, c, lpc, transposed, s1, s2);
-  if (c >= C || lane != 0) return;
-  const float ga = gamma[z * param_gs + c], be = beta[z * param_gs + c];
+  if (!owner) return;
   float* st = stats + z * stats_gs;
   float mean, invstd;
   if (training) {
@@ -164,8 +170,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partial, 
       float* rm = running_mean + z * buf_gs + c;
       float* rv = running_var + z * buf_gs + c;
       const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-      *rm = (1.f - momentum) * (*rm) + momentum * mean;
-      *rv = (1.f - momentum) * (*rv) + momentum * (float)unbiased;
+      *rm = (1.f - momentum) * rm0 + momentum * mean;
+      *rv = (1.f - momentum) * rv0 + momentum * (float)unbiased;
     }
   } else {
     mean = running_mean[z * buf_gs + c];
@@ -262,19 +268,28 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
   const int lane = threadIdx.x & (lpc - 1);
   const int c = blockIdx.x * (256 / lpc) + threadIdx.x / lpc;
   const int z = blockIdx.y;
+  // the per-channel operands do not depend on the sums: fetched BEFORE the reduction, so the kernel is two dependent memory
+  // round trips instead of three (each one costs 2-3 us beside the weight-gradient stream; 55 of these launches sit on the
+  // dependent chain of a step)
+  const float* st = stats + z * stats_gs;
+  const bool owner = c < C && lane == 0;
+  float pre_mean = 0.f, pre_invstd = 0.f, pre_gamma = 0.f, pre_dg = 0.f, pre_db = 0.f;
+  if (owner) {
+    pre_mean = st[c]; pre_invstd = st[C + c]; pre_gamma = gamma[z * param_gs + c];
+    if (dgamma && accumulate) { pre_dg = dgamma[z * grad_gs + c]; pre_db = dbeta[z * grad_gs + c]; }
+  }
   double s1, s2;
   sum_partials(partial + z * partial_gs, rblocks, C, c, lpc, transposed, s1, s2);
-  if (c >= C || lane != 0) return;
-  const float* st = stats + z * stats_gs;
-  const double mean = st[c], invstd = st[C + c];
+  if (!owner) return;
+  const double mean = pre_mean, invstd = pre_invstd;
   const double sgx = invstd * (s2 - mean * s1);   // sum g * xhat
   if (dgamma) {
     float* dg = dgamma + z * grad_gs + c;
     float* db = dbeta + z * grad_gs + c;
-    *dg = accumulate ? *dg + (float)sgx : (float)sgx;
-    *db = accumulate ? *db + (float)s1 : (float)s1;
+    *dg = accumulate ? pre_dg + (float)sgx : (float)sgx;
+    *db = accumulate ? pre_db + (float)s1 : (float)s1;
   }
-  const double A = (double)gamma[z * param_gs + c] * invstd;
+  const double A = (double)pre_gamma * invstd;
   const double c1 = s1 / M, c2 = sgx / M;
   float* k = coef + z * coef_gs;
   k[c] = (float)A;
