@@ -87,6 +87,7 @@ struct BnFin {
 // VAR 1: GEMM rows in parity-class order (stride-2 dgrad).  VAR 2: the addend is compact -- it holds only the pixels with even
 // row and column of this tile's map, (H/2) x (W/2) per image (the gradient a stride-2 1x1 branch sends back: every other
 // pixel gets none) -- so the branch's dgrad neither writes nor this epilogue reads the three quarters that are zero.
+// VAR 3 (MODE 2): the sums of a second BatchNorm fed by the same gradient are emitted too (by2 / bn_partial2).
 template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
   static constexpr bool PERM = VAR == 1;
   static constexpr bool kStaged = true;
@@ -148,14 +149,16 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
     float s1[VEC], s2[VEC], s3[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; s3[e] = 0.f; }
-    const bool has_y2 = MODE == 2 && by2 != nullptr;     // workgroup-uniform
+    constexpr bool has_y2 = MODE == 2 && VAR == 3;       // (its own instantiation: the extra operands cost the common form its
+                                                         //  128-VGPR budget -- 86 spilled registers when it was a run-time switch)
     if (n < N) {
       // The global operands of the epilogue (residual / skip gradient, y and the ReLU mask of the BatchNorm behind this
       // dgrad) are fetched HP row passes at a time, all loads of a batch in flight before the first use: issued one pass
       // at a time behind per-pass branches they cost a full memory round trip each (up to 24 per tile, the reason the
       // block-input dgrads ran 1.5x longer than the forward convs of the same GEMM shape).  Rows past M read row M-1.
       constexpr int NP = BM / RPP;
-      constexpr int HP = NP > 4 ? 4 : NP;
+      constexpr int HPMAX = (MODE == 2 && VAR == 3) ? 2 : 4;    // (four operand streams instead of three: two passes in flight fit the registers)
+      constexpr int HP = NP > HPMAX ? HPMAX : NP;
       const int pix0 = PERM ? tile_pixel0(m0) : 0;
       const bool has_add = addend != nullptr;
       const bool has_bits = MODE == 2 && sizeof(T) == 2 && bbits != nullptr;
@@ -206,7 +209,7 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
         if constexpr (MODE == 2) {
 #pragma unroll
           for (int h = 0; h < HP; ++h) vy[h] = *(const uint4*)(by + off[h]);
-          if (has_y2) {
+          if constexpr (has_y2) {
 #pragma unroll
             for (int h = 0; h < HP; ++h) vy2[h] = *(const uint4*)(by2 + off[h]);
           }
@@ -276,7 +279,7 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
               }
 #pragma unroll
               for (int e = 0; e < VEC; ++e) { s1[e] += f[e]; s2[e] += f[e] * yv[e]; }
-              if (has_y2) {
+              if constexpr (has_y2) {
                 float y2v[VEC];
                 Vec16<T>::unpack(vy2[h], y2v);
 #pragma unroll
@@ -312,11 +315,11 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
           float* dstp = bn_partial + ((int64_t)q * N + n0 + c) * tiles_m + tile_m;
           if (fuse) __hip_atomic_store(dstp, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
           else *dstp = s;
-          if (MODE == 2 && has_y2 && q == 0) bn_partial2[((int64_t)n0 + c) * tiles_m + tile_m] = s;   // sum g, for the second unit too
+          if constexpr (has_y2) { if (q == 0) bn_partial2[((int64_t)n0 + c) * tiles_m + tile_m] = s; }   // sum g, for the second unit too
         }
       }
-      if constexpr (MODE == 2) {
-        if (has_y2) {   // third quantity, sum g*y2, through the same planes
+      if constexpr (has_y2) {
+        {   // third quantity, sum g*y2, through the same planes
           __syncthreads();
 #pragma unroll
           for (int e = 0; e < VEC; ++e) red[e * PLANE + t] = s3[e];
@@ -1585,6 +1588,10 @@ static void launch_gather_mode(int mode, dim3 grid, size_t smem, hipStream_t st,
       launch_gather_inst<T, BN, false, 2, PIPE, 2>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
       return;
     }
+    if (bs.y2 != nullptr && mode == 2) {   // + the sums of a second BatchNorm (StagedStoreEpi VAR 3)
+      launch_gather_inst<T, BN, false, 2, PIPE, 3>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
+      return;
+    }
   }
   if (mode == 3) launch_gather_inst<T, BN, false, 3, PIPE>(grid, smem, st, src, w, dst, addend, nullptr, a, bs);
   else if (mode == 2) launch_gather_inst<T, BN, false, 2, PIPE>(grid, smem, st, src, w, dst, addend, bn_partial, a, bs);
@@ -1682,6 +1689,16 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
     return IEEE_ERR_UNSUPPORTED;
   }
   const int mode = affine ? 3 : ((stats && bwd) ? 2 : (stats ? 1 : 0));
+  if (bs.y2 != nullptr) {
+    // the second BatchNorm's sums exist as ONE instantiation (plain-row dgrad epilogue of the single-stage bf16 pipeline):
+    // force that pipeline, refuse the forms that have their own epilogue variants
+    if (!(sizeof(T) == 2 && !slow && mode == 2 && !a.g.perm && !bs.addend_s2 && plan.bn != 256 && !patch_eligible(a.g, M))) {
+      set_error(IEEE_ERR_UNSUPPORTED, "conv: the sums of a second BatchNorm need a plain bf16 dgrad (no stride-2 row order, no "
+                                      "compact addend, no 3x3 patch form)");
+      return IEEE_ERR_UNSUPPORTED;
+    }
+    plan.pipe = 1;
+  }
   if constexpr (sizeof(T) == 2) {
     if (!slow && stem_eligible(a.g, N, ldw, mode, addend)) {
       dim3 sgrid(a.tiles_m, groups);
