@@ -227,6 +227,75 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
   }
 }
 
+// VEC (4 or 8) consecutive floats from a 16-byte aligned address, as 16-byte loads
+template <int VEC> __device__ __forceinline__ void load_floats(const float* __restrict__ p, float* dst) {
+#pragma unroll
+  for (int e = 0; e < VEC; e += 4) {
+    const float4 v = *(const float4*)(p + e);
+    dst[e] = v.x; dst[e + 1] = v.y; dst[e + 2] = v.z; dst[e + 3] = v.w;
+  }
+}
+
+// The same pass with the per-channel constants in registers (round 4).  When the chunks of a row divide the block
+// (256 % cprw == 0: every channel count of this network), chunk i = blockIdx.x*256 + t + k*gridDim.x*256 lies in channel
+// chunk t % cprw for every k, so scale / shift are fetched ONCE per thread instead of two 32-byte loads per 16 bytes of
+// y; two chunks per thread are in flight per iteration (all their loads are issued before the first use).
+template <typename T, bool RES, bool BITS, int UNROLL>
+__global__ __launch_bounds__(256) void bn_apply_fixed_kernel(const T* __restrict__ y, const T* __restrict__ residual,
+                                                             T* __restrict__ out, const float* __restrict__ stats,
+                                                             int64_t stats_gs, int64_t total_chunks, int cprw, int C,
+                                                             int64_t gs, int relu, uint8_t* __restrict__ relu_bits) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  uint8_t* bb = BITS ? relu_bits + z * (gs / 8) : nullptr;
+  const int c0 = (threadIdx.x & (cprw - 1)) * VEC;
+  const float* scp = stats + z * stats_gs + 2 * C + c0;
+  float sc[VEC], sh[VEC];
+  load_floats<VEC>(scp, sc);
+  load_floats<VEC>(scp + C, sh);
+  const T* yy = y + z * gs;
+  const T* rr = RES ? residual + z * gs : nullptr;
+  T* oo = out + z * gs;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  auto finish = [&](int64_t i, const uint4& yv, const uint4& rv) {
+    float v[VEC], r[VEC];
+    Vec16<T>::unpack(yv, v);
+    if (RES) Vec16<T>::unpack(rv, r);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float x = v[e] * sc[e] + sh[e];
+      if (RES) x += r[e];
+      if (relu) x = fmaxf(x, 0.f);
+      v[e] = x;
+    }
+    const uint4 pv = Vec16<T>::pack(v);
+    *(uint4*)(oo + i * VEC) = pv;
+    if constexpr (BITS && VEC == 8) {
+      Vec16<T>::unpack(pv, v);   // the mask of the ROUNDED stored values, as a reader of `out` would see it
+      unsigned b = 0;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
+      bb[i] = (uint8_t)b;
+    }
+  };
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (UNROLL == 2)
+    for (; i + stride < total_chunks; i += 2 * stride) {
+      const uint4 y0 = *(const uint4*)(yy + i * VEC);
+      const uint4 y1 = *(const uint4*)(yy + (i + stride) * VEC);
+      uint4 r0 = y0, r1 = y1;
+      if (RES) { r0 = *(const uint4*)(rr + i * VEC); r1 = *(const uint4*)(rr + (i + stride) * VEC); }
+      finish(i, y0, r0);
+      finish(i + stride, y1, r1);
+    }
+  for (; i < total_chunks; i += stride) {
+    const uint4 y0 = *(const uint4*)(yy + i * VEC);
+    uint4 r0 = y0;
+    if (RES) r0 = *(const uint4*)(rr + i * VEC);
+    finish(i, y0, r0);
+  }
+}
+
 // ---- backward reductions: s1 = sum(g), s2 = sum(g*y) with g = da * [a > 0] (mask optional)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ a,
@@ -335,6 +404,74 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = k1[c0 + e] * d[e] + k2[c0 + e] * v[e] + k3[c0 + e];
     *(uint4*)(oo + i * VEC) = Vec16<T>::pack(v);
+  }
+}
+
+// dy = k1*g + k2*y + k3 with the per-channel constants in registers (see bn_apply_fixed_kernel): the plain kernel
+// fetches 3 (5 with the mask from y) x 32 bytes of coefficients per 16 bytes of each operand.  MASK: 0 none (g arrives
+// masked), 1 from the activation tensor `a`, 2 recomputed from y.  UNROLL: chunks in flight per thread (1 or 2).
+template <typename T, int MASK, bool GOUT, int UNROLL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fixed_kernel(const T* __restrict__ da, const T* __restrict__ a,
+                                                                 const T* __restrict__ y, T* __restrict__ dy,
+                                                                 T* __restrict__ gout, const float* __restrict__ coef,
+                                                                 int64_t coef_gs, int64_t total_chunks, int cprw, int C,
+                                                                 int64_t gs, const float* __restrict__ stats,
+                                                                 int64_t stats_gs) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  const int c0 = (threadIdx.x & (cprw - 1)) * VEC;
+  float k1[VEC], k2[VEC], k3[VEC], sc[VEC], sh[VEC];
+  {
+    const float* kp = coef + z * coef_gs + c0;
+    load_floats<VEC>(kp, k1);
+    load_floats<VEC>(kp + C, k2);
+    load_floats<VEC>(kp + 2 * C, k3);
+    if (MASK == 2) {
+      const float* sp = stats + z * stats_gs + 2 * C + c0;
+      load_floats<VEC>(sp, sc);
+      load_floats<VEC>(sp + C, sh);
+    }
+  }
+  const T* dd = da + z * gs;
+  const T* aa = MASK == 1 ? a + z * gs : nullptr;
+  const T* yy = y + z * gs;
+  T* oo = dy + z * gs;
+  T* go = GOUT ? gout + z * gs : nullptr;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  auto finish = [&](int64_t i, const uint4& dv, const uint4& yv, const uint4& av) {
+    float d[VEC], v[VEC], m[VEC];
+    Vec16<T>::unpack(dv, d);
+    Vec16<T>::unpack(yv, v);
+    if (MASK == 1) {
+      Vec16<T>::unpack(av, m);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d[e] = m[e] > 0.f ? d[e] : 0.f;
+    } else if (MASK == 2) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d[e] = (v[e] * sc[e] + sh[e]) > 0.f ? d[e] : 0.f;
+    }
+    if (GOUT) *(uint4*)(go + i * VEC) = Vec16<T>::pack(d);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = k1[e] * d[e] + k2[e] * v[e] + k3[e];
+    *(uint4*)(oo + i * VEC) = Vec16<T>::pack(v);
+  };
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (UNROLL == 2)
+    for (; i + stride < total_chunks; i += 2 * stride) {
+      const int64_t j = i + stride;
+      const uint4 d0 = *(const uint4*)(dd + i * VEC), d1 = *(const uint4*)(dd + j * VEC);
+      const uint4 y0 = *(const uint4*)(yy + i * VEC), y1 = *(const uint4*)(yy + j * VEC);
+      uint4 a0 = y0, a1 = y1;
+      if (MASK == 1) { a0 = *(const uint4*)(aa + i * VEC); a1 = *(const uint4*)(aa + j * VEC); }
+      finish(i, d0, y0, a0);
+      finish(j, d1, y1, a1);
+    }
+  for (; i < total_chunks; i += stride) {
+    const uint4 d0 = *(const uint4*)(dd + i * VEC);
+    const uint4 y0 = *(const uint4*)(yy + i * VEC);
+    uint4 a0 = y0;
+    if (MASK == 1) a0 = *(const uint4*)(aa + i * VEC);
+    finish(i, d0, y0, a0);
   }
 }
 
@@ -553,6 +690,21 @@ using namespace ieee;
 
 static int vec_of(int dtype) { return dtype == IEEE_BF16 ? 8 : 4; }
 
+// the *_fixed_kernel forms: a thread's channel chunk must not change along its grid-stride walk (the chunks of a row divide
+// the block) and the coefficient tables must take 16-byte loads.  IEEE_BN_FIXED: bit mask of the passes that use them
+// (1 forward apply, 2 / 4 / 8 backward apply with mask kind 0 / 1 / 2); IEEE_BN_UNROLL: chunks in flight per thread.
+// Measured alone at the B = 64 shapes (scripts/bn_probe.py, profiles/r04_bn_probe.txt): only the backward with the mask
+// recomputed from y gains -- 5 coefficient rows per chunk instead of 3: 4.55 -> 5.68 TB/s on the layer1 / layer2 maps;
+// the other passes already stream at 5.4-6.0 TB/s and lose a little at C = 2048 -- so that pass alone is on by default.
+static bool fixed_channel_ok(int which, int cprw, const void* p1, const void* p2) {
+  static const int on = getenv("IEEE_BN_FIXED") ? atoi(getenv("IEEE_BN_FIXED")) : 8;
+  return (on & which) && cprw >= 1 && cprw <= 256 && 256 % cprw == 0 && ((uintptr_t)p1 & 15) == 0 && ((uintptr_t)p2 & 15) == 0;
+}
+static int fixed_unroll() {
+  static const int u = getenv("IEEE_BN_UNROLL") ? atoi(getenv("IEEE_BN_UNROLL")) : 1;
+  return u == 2 ? 2 : 1;
+}
+
 extern "C" int64_t ieee_bn_partial_floats(int dtype, int64_t M, int64_t C) {
   const RedGeom g = red_geom(M, (int)C, vec_of(dtype));
   const int64_t rb = std::max((int64_t)g.rblocks, (M + 127) / 128);   // (M + 127) / 128: the tiled pooled backward's row blocks
@@ -590,6 +742,23 @@ extern "C" int ieee_bn2d_fwd(const void* y, const void* residual, void* out, int
   if (out == nullptr) return IEEE_OK;   // statistics only: the consumer applies scale/shift itself
   const int64_t chunks = M * C / vec_of(dtype);
   dim3 grid(ew_blocks(chunks), (unsigned)groups);
+  if (dtype == IEEE_BF16 && fixed_channel_ok(1, g.cprw, stats, nullptr)) {   // per-channel constants in registers
+    const bf16 *yb = (const bf16*)y, *rb = (const bf16*)residual;
+    bf16* ob = (bf16*)out;
+    uint8_t* bits = (uint8_t*)relu_bits;
+    const bool u2 = fixed_unroll() == 2;
+#define IEEE_BN_APPLY_FIXED(RES, BITS)                                                                                         \
+    do {                                                                                                                       \
+      if (u2) bn_apply_fixed_kernel<bf16, RES, BITS, 2><<<grid, 256, 0, st>>>(yb, rb, ob, stats, 4 * C, chunks, g.cprw, (int)C, act_gs, relu, bits); \
+      else bn_apply_fixed_kernel<bf16, RES, BITS, 1><<<grid, 256, 0, st>>>(yb, rb, ob, stats, 4 * C, chunks, g.cprw, (int)C, act_gs, relu, bits);    \
+    } while (0)
+    if (residual && bits) IEEE_BN_APPLY_FIXED(true, true);
+    else if (residual) IEEE_BN_APPLY_FIXED(true, false);
+    else if (bits) IEEE_BN_APPLY_FIXED(false, true);
+    else IEEE_BN_APPLY_FIXED(false, false);
+#undef IEEE_BN_APPLY_FIXED
+    return launch_status("bn_apply_fixed_kernel");
+  }
   if (dtype == IEEE_F32)
     bn_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)y, (const float*)residual, (float*)out, stats, 4 * C,
                                                  chunks, g.cprw, (int)C, act_gs, relu, nullptr);
@@ -612,6 +781,57 @@ extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void*
                              void* stream) {
   return ieee_bn2d_bwd_ev(dout, out_mask, y, dy, g_out, dtype, groups, M, C, act_gs, gamma, param_gs, stats, dgamma, dbeta,
                           grad_gs, partial, coef, accumulate, mask_from_y, stats_rblocks, nullptr, stream);
+}
+
+// ---- one-time self-check of the completion-signal event (see ieee_bn2d_bwd_ev below).  The executor orders a side-stream
+// weight gradient behind a BatchNorm backward ONLY through the stop event of hipExtLaunchKernelGGL + hipStreamWaitEvent;
+// the HIP documentation does not promise that a stop event that was never hipEventRecord-ed orders another stream, so
+// the first user measures it on this runtime: a kernel that spins ~300 us and then sets a flag carries the event, a second
+// stream waits on the event and reads the flag -- three times, with a pooled hipEventDisableTiming event like the
+// executor's.  0 = the waiter saw the flag every time (the event rides), anything else = use hipEventRecord.
+namespace ieee {
+__global__ void ride_spin_kernel(int* flag, long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  *flag = 1;
+}
+__global__ void ride_check_kernel(const int* flag, int* out) { *out = *flag; }
+}  // namespace ieee
+
+extern "C" int ieee_event_ride_selfcheck(void) {
+  static int cached = -1;
+  if (cached >= 0) return cached;
+  int result = 1;
+  int* dev = nullptr;
+  hipStream_t sa = nullptr, sb = nullptr;
+  hipEvent_t ev = nullptr;
+  do {
+    if (hipMalloc(&dev, 2 * sizeof(int)) != hipSuccess) break;
+    if (hipStreamCreateWithFlags(&sa, hipStreamNonBlocking) != hipSuccess) break;
+    if (hipStreamCreateWithFlags(&sb, hipStreamNonBlocking) != hipSuccess) break;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) break;
+    bool ok = true;
+    for (int rep = 0; rep < 3 && ok; ++rep) {
+      int host[2] = {-1, -1};
+      ok = hipMemsetAsync(dev, 0, 2 * sizeof(int), sa) == hipSuccess;
+      // wall_clock64 ticks at 100 MHz: 30 000 ticks = 300 us, far longer than a launch takes to reach the other queue
+      hipExtLaunchKernelGGL(ride_spin_kernel, dim3(1), dim3(1), 0, sa, nullptr, ev, 0, dev, (long long)30000);
+      ok = ok && hipGetLastError() == hipSuccess;
+      ok = ok && hipStreamWaitEvent(sb, ev, 0) == hipSuccess;
+      ride_check_kernel<<<1, 1, 0, sb>>>(dev, dev + 1);
+      ok = ok && hipGetLastError() == hipSuccess;
+      ok = ok && hipStreamSynchronize(sb) == hipSuccess && hipStreamSynchronize(sa) == hipSuccess;
+      ok = ok && hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess;
+      ok = ok && host[0] == 1 && host[1] == 1;
+    }
+    result = ok ? 0 : 2;
+  } while (false);
+  if (ev) (void)hipEventDestroy(ev);
+  if (sa) (void)hipStreamDestroy(sa);
+  if (sb) (void)hipStreamDestroy(sb);
+  if (dev) (void)hipFree(dev);
+  cached = result;
+  return result;
 }
 
 // done_event (a hipEvent_t, optional): signalled by the LAST kernel of the call itself -- it rides on that dispatch as its
@@ -649,6 +869,24 @@ extern "C" int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const vo
   const int64_t chunks = M * C / vec_of(dtype);
   dim3 grid(ew_blocks(chunks), (unsigned)groups);
   hipEvent_t ev = (hipEvent_t)done_event;
+  const int mask_kind = out_mask ? 1 : (mask_from_y ? 2 : 0);
+  if (dtype == IEEE_BF16 && fixed_channel_ok(2 << mask_kind, g.cprw, stats, coef)) {   // per-channel constants in registers
+    const int variant = mask_kind * 4 + (g_out ? 2 : 0) + (fixed_unroll() == 2 ? 1 : 0);
+#define IEEE_BN_BWD_FIXED(MASK, GOUT, UNROLL)                                                                               \
+    case MASK * 4 + (GOUT ? 2 : 0) + (UNROLL == 2 ? 1 : 0):                                                                \
+      hipExtLaunchKernelGGL((bn_bwd_apply_fixed_kernel<bf16, MASK, GOUT, UNROLL>), grid, dim3(256), 0, st, nullptr, ev, 0, \
+                            (const bf16*)dout, (const bf16*)out_mask, (const bf16*)y, (bf16*)dy, (bf16*)g_out,              \
+                            (const float*)coef, (int64_t)(3 * C), chunks, g.cprw, (int)C, act_gs, stats, (int64_t)(4 * C)); \
+      break;
+    switch (variant) {
+      IEEE_BN_BWD_FIXED(0, false, 1) IEEE_BN_BWD_FIXED(0, false, 2) IEEE_BN_BWD_FIXED(0, true, 1)
+      IEEE_BN_BWD_FIXED(0, true, 2) IEEE_BN_BWD_FIXED(1, false, 1) IEEE_BN_BWD_FIXED(1, false, 2)
+      IEEE_BN_BWD_FIXED(1, true, 1) IEEE_BN_BWD_FIXED(1, true, 2) IEEE_BN_BWD_FIXED(2, false, 1)
+      IEEE_BN_BWD_FIXED(2, false, 2) IEEE_BN_BWD_FIXED(2, true, 1) IEEE_BN_BWD_FIXED(2, true, 2)
+    }
+#undef IEEE_BN_BWD_FIXED
+    return launch_status("bn_bwd_apply_fixed_kernel");
+  }
   if (dtype == IEEE_F32) {
     if (ev)
       hipExtLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, nullptr, ev, 0, (const float*)dout,

@@ -106,6 +106,7 @@ struct Net {
   hipEvent_t pack_ev[2] = {nullptr, nullptr};
   const void* pack_uploaded_ws = nullptr;
   bool fused_bwd_state = false;   // survives between the staged ieee_net_backward_part calls
+  bool stem_a_valid = false;      // "<stem>.a" holds the activation of the LAST forward (a training forward does not write it)
   // inference: the packed weights and every BatchNorm's scale / shift only depend on the parameters and running
   // statistics; while the caller vouches that those have not changed (ieee_net_eval_cache) consecutive eval forwards
   // skip the packing launch and the 55 finalize launches
@@ -504,7 +505,9 @@ struct Run {
     fused_bwd = false;
     will_write(dy);
     if (gout) will_write(gout);
-    static const bool ride = !(getenv("IEEE_EVENT_RIDE") && atoi(getenv("IEEE_EVENT_RIDE")) == 0);
+    // (the first use checks once per process that a never-recorded stop event does order another stream on this runtime --
+    // ieee_event_ride_selfcheck, bn.hip -- and falls back to hipEventRecord in wgrad() if it does not)
+    static const bool ride = !(getenv("IEEE_EVENT_RIDE") && atoi(getenv("IEEE_EVENT_RIDE")) == 0) && ieee_event_ride_selfcheck() == 0;
     bn_done = (ride && side_enabled()) ? next_ready_event() : nullptr;
     return ieee_bn2d_bwd_ev(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
                             F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, bncoef_cur, 0, mask_from_y, rb,
@@ -661,10 +664,12 @@ struct Run {
     std::vector<ieee_wgrad_reduce_desc>& host = n.rtab_host[slot];
     const size_t bytes = tab.size() * sizeof(ieee_wgrad_reduce_desc);
     if (n.rtab_ws[slot] != (const void*)ws || host.size() != tab.size() || memcmp(host.data(), tab.data(), bytes) != 0) {
-      // the previous table may still be read by an upload in flight only if this stream has not drained; the copy below is
-      // ordered behind it on the same stream and hipMemcpyAsync stages pageable memory before it returns
+      // (content changes on the first step and after a re-plan only.)  The table is pageable host memory: a blocking copy
+      // from the issuing stream's point of view -- drain that stream (an earlier launch may still read the old table),
+      // then copy synchronously; nothing relies on how the runtime stages an asynchronous copy from a std::vector
       host = tab;
-      IEEE_HIP(hipMemcpyAsync(dev, host.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)st));
+      IEEE_HIP(hipStreamSynchronize((hipStream_t)st));
+      IEEE_HIP(hipMemcpy(dev, host.data(), bytes, hipMemcpyHostToDevice));
       n.rtab_ws[slot] = (const void*)ws;
     }
     prof_begin(1, n.reduce_unit, "wgrad_reduce");
@@ -727,6 +732,8 @@ struct Run {
   bool late_pack_pending = false;
   int forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out) {
     const int rc = forward_impl(xr, xn, xt, training, logits_out, feats_out);
+    if (rc != IEEE_OK && training)   // an aborted fused-finalize launch may have left arrival tickets behind
+      (void)hipMemsetAsync(P(n.tickets), 0, 512 * 4, (hipStream_t)st);
     if (late_pack_pending) {   // error before layer3: still order the side-stream packing before anything later
       (void)hipStreamWaitEvent((hipStream_t)st, n.pack_ev[1], 0);
       late_pack_pending = false;
@@ -797,6 +804,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
     stem_pool_fused = training && fuse_pool;
     IEEE_TRY(bn(s, nullptr, stem_pool_fused ? nullptr : P(s.a), 1, training));
   }
+  N.stem_a_valid = !stem_pool_fused;
   if (stem_pool_fused)
     IEEE_TRY(ieee_bn_relu_maxpool3x3s2_fwd(P(s.y), F(s.stats), P(N.pool), (uint8_t*)P(N.pool_arg), dt, 3, B, s.Ho, s.Wo, s.Co, st));
   else
@@ -953,7 +961,12 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
 int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
   Net& N = n;
   const int dt = N.dtype;
-  N.rpend.clear();   // (a failed call may have left entries behind)
+  if (!N.rpend.empty()) {   // a failed / partial call left reductions unflushed: their gradients were never written
+    N.rpend.clear();
+    for (int i = 0; i < Net::RT_SLOTS; ++i) N.rtab_ws[i] = nullptr;
+    IEEE_REQUIRE(false, "net_backward: the previous backward ended with unflushed weight-gradient reductions (a failed call?); "
+                        "its gradients are incomplete -- run the step again");
+  }
   if (part <= 0) IEEE_TRY(backward_head(dlogits, dfeats));
   if (part == 0) return IEEE_OK;
   static const int first_block[5] = {0, 3, 7, 13, 16};   // layer1..4 start indices ([3,4,6,3] blocks)
@@ -1464,6 +1477,9 @@ extern "C" int ieee_net_tensor(void* handle, const char* name, int64_t* byte_off
   IEEE_REQUIRE(n && name && byte_offset && numel && dtype, "net_tensor: null pointer");
   auto it = n->tensors.find(name);
   IEEE_REQUIRE(it != n->tensors.end(), "net_tensor: unknown tensor '%s'", name);
+  IEEE_REQUIRE(n->stem_a_valid || n->u_stem < 0 || n->units[n->u_stem].name + ".a" != name,
+               "net_tensor: '%s' was not produced by the last forward (a training forward pools straight from the stem's conv "
+               "output; IEEE_STEM_POOL_FUSE=0 materialises it)", name);
   *byte_offset = (int64_t)it->second.off;
   *numel = it->second.numel;
   *dtype = it->second.dtype;

@@ -60,11 +60,22 @@ class DeviceLoader(object):
         return len(self.loader)
 
     def __iter__(self):
+        sampler = getattr(self.loader, "sampler", None)
+        if hasattr(sampler, "prepare"):          # rank-sharded identity sampler: draw / exchange the epoch's order here, in
+            sampler.prepare()                    # the main process, not at the DataLoader's first prefetch
+        lo, hi = getattr(sampler, "lo", None), getattr(sampler, "hi", None)
         for k, batch in enumerate(self.loader):
             raw = batch['img']
             n, mods = len(raw), len(raw[0])
             # the reference transforms sample by sample, modality by modality: draw the flips in that order
-            flips = self.transform.draw_flips(n * mods).reshape(n, mods)
+            if self.global_rows is not None and lo is not None and hi - lo == n:
+                # a shard of a global batch: draw the flips of the WHOLE global batch -- every rank consumes the same
+                # torch RNG stream, as the single-process loop would -- and keep this shard's rows; ranks seeded alike
+                # (torch.manual_seed, as the reference's set_random_seed does) then augment the global batch exactly
+                # like the single-process sequence instead of every shard repeating rank 0's pattern
+                flips = self.transform.draw_flips(int(self.global_rows) * mods).reshape(int(self.global_rows), mods)[lo:hi]
+            else:
+                flips = self.transform.draw_flips(n * mods).reshape(n, mods)
             batch['img'] = [self.transform([raw[i][m] for i in range(n)], flips=flips[:, m]) for m in range(mods)]
             if self._owned is not None:
                 batch['batch_index'] = self._owned[k]

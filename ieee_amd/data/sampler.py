@@ -86,23 +86,59 @@ class ShardedIdentitySampler(Sampler):
         if self.local_batch == 0:
             raise ValueError('{} identities per batch cannot feed {} ranks'.format(base.ids_per_batch, world))
 
-    def global_order(self):
+        self._prepared = None      # the order drawn by prepare(), consumed by the next __iter__
+        self._last_len = None      # samples the last drawn epoch really yielded on this rank
+
+    def _live_group(self):
         import torch.distributed as dist
         live = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if not live:
+        if live and (dist.get_world_size() != self.world or dist.get_rank() != self.rank):
+            # the shard bounds were computed for (self.rank, self.world): a group of another shape would make rank 0 of
+            # the group draw for a sampler that slices by a different rank / world -- refuse instead of disagreeing silently
+            raise RuntimeError('ShardedIdentitySampler(rank={}, world={}) inside a process group of rank {} / world {}'.format(
+                self.rank, self.world, dist.get_rank(), dist.get_world_size()))
+        return live
+
+    def global_order(self):
+        """the epoch's global index sequence: drawn by rank 0 and broadcast when a process group is live (a COLLECTIVE:
+        every rank must call it, from its main process, with its device already selected under NCCL), else drawn locally"""
+        import torch.distributed as dist
+        if not self._live_group():
             return list(iter(self.base))
-        box = [list(iter(self.base)) if dist.get_rank() == 0 else None]
+        box = [list(iter(self.base)) if self.rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         return box[0]
 
-    def __iter__(self):
-        order, B = self.global_order(), self.global_batch
+    def prepare(self):
+        """Draw (and, with a live process group, exchange) the next epoch's order NOW, in the caller's context, instead of
+        inside __iter__ -- where a DataLoader would trigger the collective at its first prefetch.  DeviceLoader calls this
+        at the start of every epoch; set_epoch() is the torch DistributedSampler spelling of the same call."""
+        self._prepared = self._slice(self.global_order())
+        return self
+
+    def set_epoch(self, epoch=None):
+        return self.prepare()
+
+    def _slice(self, order):
+        B = self.global_batch
         mine = []
         for start in range(0, len(order) - len(order) % B, B):
             mine += order[start + self.lo:start + self.hi]
+        self._last_len = len(mine)
+        return mine
+
+    def __iter__(self):
+        mine, self._prepared = self._prepared, None
+        if mine is None:
+            mine = self._slice(self.global_order())
         return iter(mine)
 
     def __len__(self):
+        """samples of the epoch drawn last (exact); before any draw, the base sampler's figure -- an UPPER bound: the
+        identity sampler stops when fewer than P identities have a group left (the reference's __len__ over-reports the
+        same way, sampler.py:81-84)"""
+        if self._last_len is not None:
+            return self._last_len
         return len(self.base) // self.global_batch * self.local_batch
 
 

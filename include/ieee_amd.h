@@ -246,6 +246,14 @@ int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void
                   int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
                   const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, float* partial,
                   float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks, void* done_event, void* stream);
+/* `done_event` above is never hipEventRecord-ed: it is the stop event of hipExtLaunchKernelGGL, and a consumer orders
+ * another stream behind it with hipStreamWaitEvent.  HIP does not document that such an event orders a second stream, so
+ * the dependency is MEASURED once per process before it is relied on: a ~300 us spinning kernel carries a pooled
+ * hipEventDisableTiming event, a second stream waits on it and reads the flag the kernel sets last (three rounds; two
+ * private streams, one 8-byte allocation, host-synchronous -- the only place the library waits for the device).
+ * Returns 0 when the event rides, non-zero otherwise; the executor then falls back to hipEventRecord (IEEE_EVENT_RIDE=0
+ * forces that).  Autograd-free: this replaces nothing in the reference (its streams are torch's). */
+int ieee_event_ride_selfcheck(void);
 
 /* ---- stem plumbing ----------------------------------------------------------- */
 /* three fp32 NCHW image tensors (batch dict 'img' = [RGB, NI, TI], dataset.py:338-351) ->

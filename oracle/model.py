@@ -3,7 +3,7 @@ IEEE3modalPart train / eval step in stock torch fp32 ops, arranged as the refere
 
   bottleneck / resnet50_trunk   <- torchreid/models/resnet.py:164-184, 496-523, 622-635
   cim / channel_attention       <- torchreid/models/ieee3modalPart.py:266-282, 427-435
-  forward                       <- torchreid/models/ieee3modalPart.py:439-523
+  forward = trunks + tail       <- torchreid/models/ieee3modalPart.py:439-523
   rem (closed form)             <- torchreid/models/ieee3modalPart.py:60-80
   cross_entropy_ls              <- torchreid/losses/cross_entropy_loss.py:36-50
   margin3m                      <- torchreid/losses/multi_modal_margin_loss_new.py:19-40
@@ -60,6 +60,12 @@ def dim_reduce(x, sd, p, training):
 def forward(sd, xs, training, loss="margin", interaction=True, attention=True, using_rem=True, taps=None):
     """xs = [RGB, NI, TI]; sd's running stats are updated in place when training (pass clones)."""
     f = [resnet50_trunk(xs[m], sd, "backbone.%d." % m, training, taps) for m in range(3)]
+    return tail(sd, f, training, loss, interaction, attention, using_rem, taps)
+
+
+def tail(sd, f, training, loss="margin", interaction=True, attention=True, using_rem=True, taps=None):
+    """everything behind the three trunks (ieee3modalPart.py:445-523): f = the three [B, 2048, 16, 8] trunk maps.  Split
+    out of forward() so that a test can hand it the trunk maps of another implementation and differentiate from there."""
     pooled, glob = [], []
     if interaction:
         for m in range(3):

@@ -40,12 +40,13 @@ for M, C in shapes:
     fwd = lambda r: L.check(lib.ieee_bn2d_fwd(L.ptr(y), L.ptr(res) if r else None, L.ptr(out), 1, G, M, C, M * C, L.ptr(gam),
                                               L.ptr(bet), C, L.ptr(rm), L.ptr(rv), C, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, 1,
                                               RB, None, st))
-    bwd = lambda m, go: L.check(lib.ieee_bn2d_bwd(L.ptr(dd), L.ptr(out) if m else None, L.ptr(y), L.ptr(dy),
-                                                  L.ptr(gout) if go else None, 1, G, M, C, M * C, L.ptr(gam), C, L.ptr(stats),
-                                                  L.ptr(dg), L.ptr(db), C, L.ptr(part), L.ptr(coef), 0, 0 if m else 1, RB, st))
+    bwd = lambda kind, go: L.check(lib.ieee_bn2d_bwd(L.ptr(dd), L.ptr(out) if kind == 1 else None, L.ptr(y), L.ptr(dy),
+                                                     L.ptr(gout) if go else None, 1, G, M, C, M * C, L.ptr(gam), C, L.ptr(stats),
+                                                     L.ptr(dg), L.ptr(db), C, L.ptr(part), L.ptr(coef), 0, 1 if kind == 2 else 0, RB, st))
     n = G * M * C * 2
     t1 = timeit(lambda: fwd(False)); t2 = timeit(lambda: fwd(True))
-    t3 = timeit(lambda: bwd(False, False)); t4 = timeit(lambda: bwd(True, True))
-    print("M=%7d C=%4d  %5.1f MB | fwd %6.1f us %4.2f TB/s | fwd+res %6.1f us %4.2f | bwd(mask from y) %6.1f us %4.2f | "
-          "bwd(mask,gout) %6.1f us %4.2f" % (M, C, n / 1e6, t1, 2 * n / t1 / 1e6, t2, 3 * n / t2 / 1e6, t3, 3 * n / t3 / 1e6,
-                                            t4, 5 * n / t4 / 1e6))
+    t0 = timeit(lambda: bwd(0, False)); t3 = timeit(lambda: bwd(2, False)); t4 = timeit(lambda: bwd(1, True))
+    print("M=%7d C=%4d  %5.1f MB | fwd %6.1f us %4.2f TB/s | fwd+res %6.1f us %4.2f | bwd(g masked) %6.1f us %4.2f | "
+          "bwd(mask from y) %6.1f us %4.2f | bwd(mask,gout) %6.1f us %4.2f" % (
+              M, C, n / 1e6, t1, 2 * n / t1 / 1e6, t2, 3 * n / t2 / 1e6, t0, 3 * n / t0 / 1e6, t3, 3 * n / t3 / 1e6,
+              t4, 5 * n / t4 / 1e6))

@@ -173,6 +173,65 @@ def test_sharded_sampler_is_a_slice_of_the_reference_sequence():
             assert mine[g * 8:(g + 1) * 8] == want[g * 16 + 8 * r:g * 16 + 8 * r + 8]
 
 
+class _FlipStub(object):
+    """stand-in device transform that draws flips like DeviceTransform (one torch.rand(1) per image) and records them"""
+
+    def __init__(self):
+        self.seen = []
+
+    def draw_flips(self, n):
+        return np.asarray([1 if float(torch.rand(1)) < 0.5 else 0 for _ in range(n)], dtype=np.uint8)
+
+    def __call__(self, images, flips=None):
+        self.seen.append(np.asarray(flips).copy())
+        return torch.zeros(len(images), 1)
+
+
+def test_rank_shards_flip_like_the_single_process_sequence(tmp_path):
+    """The reference draws one flip per image, sample by sample over the GLOBAL batch (data/transforms.py:259-262 inside
+    the dataset's __getitem__).  A rank-sharded loader draws the global batch's flips on every rank and keeps its rows, so
+    ranks seeded alike reproduce that sequence -- not rank 0's pattern repeated in every shard."""
+    from ieee_amd.data.loader import DeviceLoader
+    names = ["%06d_cam%d_0_%02d.jpg" % (pid, 1 + (j % 4), j) for pid in (3, 8, 11, 20) for j in range(2)]
+    _make_tree(str(tmp_path), names, size=(20, 12))
+    ds = datasets.RGBNT201(root=str(tmp_path))
+    B, K, world = 8, 2, 2
+    random.seed(4); np.random.seed(4)
+    single = _FlipStub()                                          # the single-process loader over the same global batches
+    one = DeviceLoader(ds.train, single, B, sampler=smp.build_train_sampler(ds.train, 'RandomIdentitySampler', batch_size=B,
+                                                                           num_instances=K), workers=0, drop_last=True)
+    torch.manual_seed(9)
+    whole = next(iter(one))
+    want = np.stack(single.seen[:3], axis=1)                      # [sample, modality] of global batch 0
+    got, pids = [], []
+    for r in range(world):
+        random.seed(4); np.random.seed(4)
+        samp = smp.build_train_sampler(ds.train, 'RandomIdentitySampler', batch_size=B, num_instances=K, rank=r, world=world)
+        stub = _FlipStub()
+        loader = DeviceLoader(ds.train, stub, samp.local_batch, sampler=samp, workers=0, drop_last=True, global_rows=B)
+        torch.manual_seed(9)
+        first = next(iter(loader))
+        assert len(first['pid']) == B // world and len(stub.seen) == 3
+        got.append(np.stack(stub.seen[:3], axis=1))               # [rows, modality]
+        pids.append(first['pid'])
+    assert torch.equal(torch.cat(pids), whole['pid'])             # the shards are the single-process batch ...
+    assert np.array_equal(np.concatenate(got, 0), want)           # ... and flip like it, row for row
+    assert not np.array_equal(got[0], got[1])                     # (the shards do differ under this seed)
+
+
+def test_sharded_sampler_prepares_outside_iter_and_reports_its_real_length():
+    data = _source(n_pid=17)
+    s = smp.ShardedIdentitySampler(smp.RandomIdentitySampler(data, 16, 4), 1, 2)
+    upper = len(s)                                                # before any draw: the base sampler's upper bound
+    random.seed(2); np.random.seed(2)
+    assert s.set_epoch(0) is s and s._prepared is not None
+    drawn = list(s._prepared)
+    state = random.getstate()
+    assert list(iter(s)) == drawn and random.getstate() == state  # __iter__ consumed the prepared order: no new draw
+    assert len(s) == len(drawn) <= upper
+    assert s._prepared is None and len(list(iter(s))) == len(s)   # the next epoch draws again
+
+
 class _CountingStub(object):
     """stand-in device transform: counts the images it is handed (= decoded and transformed rows)"""
 
@@ -240,6 +299,10 @@ def _shard_worker(rank, world, port, root, ret):
     loss_of(whole, 1.0).backward()
     torch.testing.assert_close(flat[:W.numel()].view_as(W), W.grad, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(flat[W.numel():].view_as(Wf), Wf.grad, rtol=1e-5, atol=1e-7)
+    # a sampler built for another (rank, world) than the live group refuses to draw instead of disagreeing with its bounds
+    wrong = smp.ShardedIdentitySampler(smp.RandomIdentitySampler(ds.train, B, K), (rank + 1) % world, world)
+    with pytest.raises(RuntimeError):
+        wrong.prepare()
     # --- evaluation loader: every world-th batch is decoded, the labels of ALL batches come from the records
     stub2 = _CountingStub()
     q = DeviceLoader(ds.query, stub2, 3, workers=0, rank=rank, world=world)

@@ -33,14 +33,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret, B=16):
+def _worker(rank, world, port, ret, B=16, C=11, D=32):
     from oracle import model as om
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
                       LOCAL_RANK=str(rank))
     w, r, _ = ddp.init_from_env(backend="gloo")
     assert (w, r) == (world, rank) and ddp.world_size() == world and ddp.rank() == rank
     torch.manual_seed(0)                      # same global batch on every rank
-    K, C, D = 4, 11, 32
+    K = 4
     logits = torch.randn(6, B, C)
     feats = torch.nn.functional.normalize(torch.randn(3, B, D), dim=2)
     pids = torch.arange(B) // K
@@ -81,11 +81,13 @@ def _worker(rank, world, port, ret, B=16):
     ret[rank] = 1
 
 
-@pytest.mark.parametrize("world,B", [(2, 16), (3, 32)])      # (3, 32): 8 identities over 3 ranks = shards of 12, 12, 8 rows
-def test_gloo_allreduce_and_loss_scaling(world, B):
+# (3, 32): 8 identities over 3 ranks = shards of 12, 12, 8 rows.  (4, 128, 750, 768): BASELINE config 5's shape -- 4 ranks x 32
+# triples, the 750 identities of Market1501-multimodal, the 768-wide per-modality descriptors the 3M loss sees
+@pytest.mark.parametrize("world,B,C,D", [(2, 16, 11, 32), (3, 32, 11, 32), (4, 128, 750, 768)])
+def test_gloo_allreduce_and_loss_scaling(world, B, C, D):
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), ret, B), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), ret, B, C, D), nprocs=world, join=True)
         assert dict(ret) == {r: 1 for r in range(world)}
 
 
@@ -149,11 +151,18 @@ def _sync_worker(rank, world, port, ret):
     local = {b: full[starts[b]:starts[b] + rows[b]].clone() for b in range(rank, len(rows), world)}
     out = ddp.gather_feature_batches(local, rows, 6, torch.device("cpu"))
     assert torch.equal(out, full)
+    # ... and a gallery-sized walk: 157 ragged batches (the index-tensor plan, no per-batch copies)
+    g = torch.Generator().manual_seed(5)
+    rows = torch.randint(1, 65, (157,), generator=g).tolist()
+    full = torch.arange(sum(rows) * 3, dtype=torch.float32).view(-1, 3)
+    starts = [sum(rows[:b]) for b in range(len(rows))]
+    local = {b: full[starts[b]:starts[b] + rows[b]].clone() for b in range(rank, len(rows), world)}
+    assert torch.equal(ddp.gather_feature_batches(local, rows, 3, torch.device("cpu")), full)
     dist.destroy_process_group()
     ret[rank] = 1
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_replica_sync_and_sharded_feature_gather(world):
     with mp.Manager() as mgr:
         ret = mgr.dict()
