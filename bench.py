@@ -88,6 +88,40 @@ def committed_traffic(key, field="hbm_bytes_per_launch"):
     return None, None
 
 
+FWD_DGRAD_KERNELS = ("conv_gather_kernel", "conv3x3_patch_kernel", "stem_conv_kernel")
+WGRAD_KERNELS = ("conv_wgrad_kernel", "conv3x3_wgrad_patch_kernel", "stem_wgrad_kernel", "wgrad_reduce")
+
+
+def committed_kernel_stats(train_gflop_per_triple):
+    """The same two families from the newest committed `rocprofv3 --kernel-trace --stats` summary of a PLAIN run of this
+    bench (profiles/rNN_kernel_stats_in_situ.csv + .json naming its command, build and step count: no event passes in the
+    trace, every step is a two-stream step): total duration of the family / steps -> TFLOP/s inside the step.  Read from
+    the committed file -- the tracer cannot run inside this process -- and labelled as such."""
+    import csv
+    import glob
+    for meta_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_in_situ.json")), reverse=True):
+        try:
+            meta = json.load(open(meta_path))
+            rows = list(csv.DictReader(open(meta_path[:-5] + ".csv")))
+            steps = float(meta["steps_in_trace"])
+            def fam(names):
+                ns = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in names))
+                calls = sum(int(r["Calls"]) for r in rows if any(k in r["Name"] for k in names))
+                return ns / steps * 1e-6, calls / steps
+            g_ms, g_calls = fam(FWD_DGRAD_KERNELS)
+            w_ms, w_calls = fam(WGRAD_KERNELS)
+            fl = float(meta["fwd_dgrad_flops_per_step"])
+            return {"source": os.path.relpath(meta_path[:-5] + ".csv", ROOT), "build": meta.get("build"), "command": meta.get("command"),
+                    "steps_in_trace": steps, "fwd_dgrad_ms_per_step": g_ms, "fwd_dgrad_launches_per_step": g_calls,
+                    "fwd_dgrad_TFLOPs": fl / (g_ms * 1e-3) / 1e12, "fwd_dgrad_frac": fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                    "wgrad_incl_reduce_ms_per_step": w_ms,
+                    "wgrad_incl_reduce_TFLOPs": float(meta["wgrad_flops_per_step"]) / (w_ms * 1e-3) / 1e12,
+                    "wgrad_incl_reduce_frac": float(meta["wgrad_flops_per_step"]) / (w_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline_train(seconds_budget=25.0):
     """oracle (stock torch CPU ops arranged like the reference) on a bounded sample: B=8 steps"""
     from ieee_amd import detgen
@@ -114,6 +148,55 @@ def cpu_baseline_train(seconds_budget=25.0):
             "host_physical_cores": phys, "host_logical_cpus": logical,
             "sample": "%d oracle train steps at batch %d (fp32, torch CPU ops, %d threads of a host with %s physical cores / "
                       "%d logical CPUs), %.2f s/step" % (n, B, threads, phys, logical, dt)}
+
+
+def dp_path_leg(engine, batch, model, rounds=3, steps=12):
+    """staged data-parallel step (IEEE_FORCE_DP_PATH=1, 1-rank "nccl" = RCCL group) against the plain step, interleaved"""
+    import socket
+    import torch.distributed as dist
+    made = False
+    try:
+        if not dist.is_initialized():
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+            made = True
+
+        def run(forced, n):
+            os.environ["IEEE_FORCE_DP_PATH"] = "1" if forced else "0"
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(n):
+                engine.forward_backward(batch)
+            torch.cuda.synchronize()
+            return (time.time() - t0) / n * 1e3
+        # communicator set-up is not a step: RCCL registers the gradient buffer at its first collectives (the first ~20
+        # staged steps run 1.3-1.6x slower)
+        for ranges in model.grad_part_ranges():
+            for a, b in ranges:
+                dist.all_reduce(model._flat_grads[a:b], op=dist.ReduceOp.SUM)
+        run(True, 25)
+        plain, staged = [], []
+        for _ in range(rounds):
+            plain.append(run(False, steps))
+            staged.append(run(True, steps))
+        p, st = sorted(plain)[len(plain) // 2], sorted(staged)[len(staged) // 2]
+        return {"plain_ms_per_step": p, "staged_ms_per_step": st, "dp_path_overhead_ms": st - p, "backend": dist.get_backend(),
+                "ranks": dist.get_world_size(), "rounds": rounds, "steps_per_round": steps,
+                "what": "the N > 1 step (5 backward parts, 13 gradient slices all-reduced from a communication stream, optimizer "
+                        "slices behind them) run over a 1-rank RCCL group on this GPU, interleaved with the plain step: the fixed "
+                        "per-rank cost of the data-parallel code path without any wire time"}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        os.environ["IEEE_FORCE_DP_PATH"] = "0"
+        if made:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
 
 
 def bench_distmat(device):
@@ -154,17 +237,21 @@ def bench_distmat(device):
                      "mfma_frac_of_16bit_peak": terms * 2.0 * Q * G * D / ms / 1e9 / PEAK_BF16_TFLOPS,
                      "note": "includes the piece-splitting pre-pass; GFLOP/s counts the 2*Q*G*D of the fp32 problem"}
     del dm
-    # the model's real descriptor width (2304 = 3 x 768, ieee3modalPart.py:502), fp32, smaller gallery
+    # the model's real descriptor width (2304 = 3 x 768, ieee3modalPart.py:502), fp32, the full 10 k x 100 k problem
     g2 = torch.Generator(device="cpu").manual_seed(2)
-    q3, g3 = torch.randn(10000, 2304, generator=g2).abs().to(device), torch.randn(50000, 2304, generator=g2).abs().to(device)
-    compute_distance_matrix(q3, g3)
+    q3, g3 = torch.randn(Q, 2304, generator=g2).abs().to(device), torch.randn(G, 2304, generator=g2).abs().to(device)
+    d3 = compute_distance_matrix(q3, g3)
     torch.cuda.synchronize()
-    t0 = time.time()
-    compute_distance_matrix(q3, g3)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        d3 = compute_distance_matrix(q3, g3)
+    e1.record()
     torch.cuda.synchronize()
-    ms = (time.time() - t0) * 1e3
-    out["fp32_d2304"] = {"ms": ms, "GFLOP/s": 2.0 * 10000 * 50000 * 2304 / ms / 1e6, "workload": "10000 x 50000 x 2304"}
-    del q3, g3
+    ms = e0.elapsed_time(e1) / 3
+    out["fp32_d2304"] = {"ms": ms, "GFLOP/s": 2.0 * Q * G * 2304 / ms / 1e6, "workload": "%d x %d x 2304" % (Q, G),
+                         "frac_of_fp32_mfma_peak": 2.0 * Q * G * 2304 / ms / 1e9 / PEAK_F32_TFLOPS}
+    del q3, g3, d3
     dm = compute_distance_matrix(qf, gf)
     evaluate_rank(dm, qp, gp, qc, gc)
     torch.cuda.synchronize()
@@ -225,8 +312,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-distmat", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the short fp32 parity-mode throughput leg")
+    ap.add_argument("--no-roofline-pass", action="store_true", help="plain timed steps only (the command rocprofv3 traces for "
+                    "profiles/rNN_kernel_stats_in_situ.csv: every step in the trace is a two-stream step)")
+    ap.add_argument("--no-dp-path", action="store_true", help="skip the staged data-parallel step over a 1-rank RCCL group (N = 1)")
+    ap.add_argument("--no-loader", action="store_true", help="skip the input-pipeline leg (JPEG tree -> loader -> train step)")
+    ap.add_argument("--loader-workers", default="8,16,32", help="worker counts of the input-pipeline leg")
     args = ap.parse_args()
 
+    # Only the JSON line may reach the caller's stdout: RCCL prints a version banner (through C stdio, flushed at exit) when
+    # a communicator is created, and other libraries chat too.  From here on file descriptor 1 IS stderr; the line is written
+    # to the saved descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     from ieee_amd import _lib, dist as ddp
     world, rank, local = ddp.init_from_env()
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torchrun for --gpus > 1"
@@ -282,31 +380,52 @@ def main():
     dt = float(tmax.item())
     value = args.steps * B * world / dt
 
-    # ---- roofline pass: same steps with a HIP event pair around every conv launch (launch stream)
+    # ---- roofline passes: the same steps with a HIP event pair around every conv launch.  IN SITU (mode 2): the executor's
+    # streams stay on -- forward / dgrad pairs on the launch stream, weight-gradient pairs on the side stream -- so a pair
+    # times its launch beside the other stream's kernels: what the launch takes inside the step that `value` measures, and
+    # what `rocprofv3 --kernel-trace --stats` of the same command reports (profiles/).  SERIALIZED (mode 1): everything
+    # on one ordered stream, every launch alone on the machine.
     import ctypes
     net = model.native_net(B, 256, 128)
     lib = _lib.load()
-    _lib.check(lib.ieee_net_profile(net.handle, 1, None))
-    for _ in range(args.steps):
-        engine.forward_backward(batch)
-    out6 = (ctypes.c_double * 6)()
-    _lib.check(lib.ieee_net_profile(net.handle, 0, out6))
-    g_ms, g_fl, g_n, w_ms, w_fl, w_n = list(out6)
+
+    def event_pass(mode):
+        _lib.check(lib.ieee_net_profile(net.handle, mode, None))
+        for _ in range(args.steps):
+            engine.forward_backward(batch)
+        o = (ctypes.c_double * 6)()
+        _lib.check(lib.ieee_net_profile(net.handle, 0, o))
+        return list(o)
+    if args.no_roofline_pass:
+        g_ms = g_fl = g_n = w_ms = w_fl = w_n = sg_ms = sg_fl = sg_n = sw_ms = sw_fl = sw_n = 0.0
+    else:
+        g_ms, g_fl, g_n, w_ms, w_fl, w_n = event_pass(2)
+        sg_ms, sg_fl, sg_n, sw_ms, sw_fl, sw_n = event_pass(1)
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    ser = sg_fl / (sg_ms * 1e-3) / 1e12 if sg_ms > 0 else 0.0
     traffic = traffic_src = None
     if args.dtype == "bf16" and B == 64:
         traffic, traffic_src = committed_traffic("conv_fwd_dgrad")          # gather + LDS-patch + direct-stem launches (round 3)
         if traffic is None:
             traffic, traffic_src = committed_traffic("conv_gather")
+    stats_line = committed_kernel_stats(TRAIN_GFLOP_PER_TRIPLE) if args.dtype == "bf16" and B == 64 else None
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "measured": "in situ: HIP event pairs around every launch of the family inside the two-stream step",
+                "in_situ_frac": ach / peak, "serialized_achieved": ser, "serialized_frac": ser / peak,
+                "serialized_avg_launch_us": sg_ms * 1e3 / max(sg_n, 1),
+                "in_situ_from_committed_rocprof_stats": stats_line,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "conv forward + dgrad launches: conv_gather_kernel (implicit GEMM), conv3x3_patch_kernel (3x3 from an "
                           "LDS-resident patch), stem_conv_kernel",
                 "launches": int(g_n), "avg_launch_us": g_ms * 1e3 / max(g_n, 1),
-                "flops_per_launch": g_fl / max(g_n, 1),
+                "flops_per_launch": g_fl / max(g_n, 1), "fwd_dgrad_flops_per_step": g_fl / args.steps,
+                "wgrad_flops_per_step": w_fl / args.steps,
                 "wgrad": {"achieved": (w_fl / (w_ms * 1e-3) / 1e12) if w_ms > 0 else 0.0, "launches": int(w_n),
-                          "avg_launch_us": w_ms * 1e3 / max(w_n, 1)},
+                          "avg_launch_us": w_ms * 1e3 / max(w_n, 1), "frac": (w_fl / (w_ms * 1e-3) / 1e12 / peak) if w_ms > 0 else 0.0,
+                          "serialized_achieved": (sw_fl / (sw_ms * 1e-3) / 1e12) if sw_ms > 0 else 0.0,
+                          "note": "weight-gradient kernels incl. their slab reductions; in situ = on the side stream, beside the "
+                                  "launch stream's kernels"},
                 "conv_ms_per_step": (g_ms + w_ms) / args.steps,
                 "whole_step_frac_of_peak": value / world * TRAIN_GFLOP_PER_TRIPLE * 1e9 / (peak * 1e12)}
 
@@ -324,6 +443,13 @@ def main():
                     "floor_TBps_at_this_step_time": floor / step_s / 1e12,
                     "floor": "3 passes x (conv outputs written + read once, bf16) + SGD 20 B/param + packed operands "
                              "written + read once (DESIGN.md section 5)"}
+
+    # N = 1: the fixed cost of the N > 1 code path.  The SAME engine runs the staged data-parallel step -- backward in 5
+    # parts, every part's gradient slices all-reduced over a 1-rank RCCL group from the communication stream, the
+    # optimizer slices behind them (engine.py: _fused_step, `staged`) -- interleaved with the plain step.
+    dp_path = None
+    if world == 1 and not args.no_dp_path and args.dtype == "bf16":
+        dp_path = dp_path_leg(engine, batch, model)
 
     # N > 1: what RCCL saw -- rank count and the time of each backward part's gradient all-reduce (a short extra leg
     # with event pairs on the communication stream; not part of the timed region)
@@ -367,6 +493,8 @@ def main():
         line["step_hbm"] = step_hbm
     if rccl is not None:
         line["rccl"] = rccl
+    if dp_path is not None:
+        line["dp_path"] = dp_path
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train()
@@ -395,9 +523,20 @@ def main():
                                         (PEAK_F32_TFLOPS * 1e12)}
             del e32, m32
             torch.cuda.empty_cache()
+        if world == 1 and not args.no_loader and args.dtype == "bf16":
+            # input pipeline at step rate: JPEG tree -> worker decode -> device transform -> real steps
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import loader_probe
+                line["loader"] = loader_probe.measure(tuple(int(w) for w in args.loader_workers.split(",")), steps=30, B=B,
+                                                      device=device)
+            except Exception as e:      # informative leg: never costs the headline line
+                line["loader"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_distmat:
             line["distmat"] = bench_distmat(device)
-        print(json.dumps(line))
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    os.close(real_stdout)
     if world > 1:
         torch.distributed.destroy_process_group()
 

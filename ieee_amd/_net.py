@@ -92,6 +92,10 @@ class NativeNet:
             _lib.check(self.lib.ieee_net_side_wait(self.handle, _lib.ptr(self.workspace),
                                                    ctypes.c_void_p(stream.cuda_stream), 0))
 
+    def set_frozen(self, mask):
+        """children whose BatchNorms run on their running statistics in a training forward (ieee_net_set_frozen)"""
+        _lib.check(self.lib.ieee_net_set_frozen(self.handle, int(mask)))
+
     def debug_taps(self, nbytes):
         """parity tests: allocate a tap buffer of nbytes and make the backward copy its gradient tensors into it
         (include/ieee_amd.h: ieee_net_debug_taps); nbytes = 0 switches the taps off"""

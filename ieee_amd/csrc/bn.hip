@@ -787,8 +787,9 @@ extern "C" int ieee_bn2d_bwd(const void* dout, const void* out_mask, const void*
 // weight gradient behind a BatchNorm backward ONLY through the stop event of hipExtLaunchKernelGGL + hipStreamWaitEvent;
 // the HIP documentation does not promise that a stop event that was never hipEventRecord-ed orders another stream, so
 // the first user measures it on this runtime: a kernel that spins ~300 us and then sets a flag carries the event, a second
-// stream waits on the event and reads the flag -- three times, with a pooled hipEventDisableTiming event like the
-// executor's.  0 = the waiter saw the flag every time (the event rides), anything else = use hipEventRecord.
+// stream waits on the event and reads the flag -- three times, with a hipEventDisableTiming event like the executor's,
+// on the two streams the caller hands in.  0 = the waiter saw the flag every time (the event rides), anything else = use
+// hipEventRecord.
 namespace ieee {
 __global__ void ride_spin_kernel(int* flag, long long ticks) {
   const long long t0 = wall_clock64();
@@ -798,17 +799,19 @@ __global__ void ride_spin_kernel(int* flag, long long ticks) {
 __global__ void ride_check_kernel(const int* flag, int* out) { *out = *flag; }
 }  // namespace ieee
 
-extern "C" int ieee_event_ride_selfcheck(void) {
+extern "C" int ieee_event_ride_selfcheck(void* stream_a, void* stream_b) {
   static int cached = -1;
   if (cached >= 0) return cached;
+  IEEE_REQUIRE(stream_a != stream_b, "event_ride_selfcheck: needs two different streams");
+  // The check runs on the CALLER's two streams (the executor passes its launch and side stream): creating and destroying
+  // streams of its own in the middle of a step re-shuffled the runtime's hardware-queue assignment on this pool -- the
+  // weight-gradient stream stopped overlapping the launch stream afterwards (22.5 instead of 14.9 ms per step, round 4).
   int result = 1;
   int* dev = nullptr;
-  hipStream_t sa = nullptr, sb = nullptr;
+  hipStream_t sa = (hipStream_t)stream_a, sb = (hipStream_t)stream_b;
   hipEvent_t ev = nullptr;
   do {
     if (hipMalloc(&dev, 2 * sizeof(int)) != hipSuccess) break;
-    if (hipStreamCreateWithFlags(&sa, hipStreamNonBlocking) != hipSuccess) break;
-    if (hipStreamCreateWithFlags(&sb, hipStreamNonBlocking) != hipSuccess) break;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) break;
     bool ok = true;
     for (int rep = 0; rep < 3 && ok; ++rep) {
@@ -827,8 +830,6 @@ extern "C" int ieee_event_ride_selfcheck(void) {
     result = ok ? 0 : 2;
   } while (false);
   if (ev) (void)hipEventDestroy(ev);
-  if (sa) (void)hipStreamDestroy(sa);
-  if (sb) (void)hipStreamDestroy(sb);
   if (dev) (void)hipFree(dev);
   cached = result;
   return result;
@@ -840,32 +841,11 @@ extern "C" int ieee_event_ride_selfcheck(void) {
 // one has drained AND the packet has been processed (+5 us per record on the dgrad / BatchNorm chain of the backward,
 // 49 per step: found in the round-3 kernel trace as a 7.5 us gap behind every bn_bwd_apply that a weight gradient
 // forks from).
-extern "C" int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
-                                int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma,
-                                int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
-                                float* partial, float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks,
-                                void* done_event, void* stream) {
-  IEEE_REQUIRE(dout && y && dy && gamma && stats && partial && coef, "bn2d_bwd: null pointer");
-  IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_bwd: bad dtype");
-  IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_bwd: C not a multiple of the vector width");
-  hipStream_t st = (hipStream_t)stream;
+// the apply pass of the BatchNorm backward (dy = k1*g + k2*y + k3), shared by the train-mode and the frozen form
+static int launch_bwd_apply(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                            int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* stats, const float* coef,
+                            int mask_from_y, void* done_event, hipStream_t st) {
   RedGeom g = red_geom(M, (int)C, vec_of(dtype));
-  if (stats_rblocks > 0) g.rblocks = (int)stats_rblocks;   // sums already emitted by the producing dgrad
-  const int64_t partial_gs = (int64_t)g.rblocks * 2 * C;
-  dim3 rgrid(g.cblocks * g.rblocks, (unsigned)groups);
-  if (stats_rblocks > 0) {
-  } else if (dtype == IEEE_F32)
-    bn_bwd_reduce_kernel<float><<<rgrid, 256, 0, st>>>((const float*)dout, (const float*)out_mask, (const float*)y,
-                                                       act_gs, g, partial, partial_gs, stats, 4 * C, mask_from_y);
-  else
-    bn_bwd_reduce_kernel<bf16><<<rgrid, 256, 0, st>>>((const bf16*)dout, (const bf16*)out_mask, (const bf16*)y, act_gs,
-                                                      g, partial, partial_gs, stats, 4 * C, mask_from_y);
-  IEEE_TRY(launch_status("bn_bwd_reduce_kernel"));
-  const int lpc = finalize_lpc(g.rblocks);
-  bn_bwd_finalize_kernel<<<dim3(cdiv(C, 256 / lpc), (unsigned)groups), 256, 0, st>>>(
-      partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, param_gs, stats, 4 * C, dgamma, dbeta, grad_gs, coef,
-      3 * C, accumulate, stats_rblocks > 0 ? 1 : 0, lpc);
-  IEEE_TRY(launch_status("bn_bwd_finalize_kernel"));
   const int64_t chunks = M * C / vec_of(dtype);
   dim3 grid(ew_blocks(chunks), (unsigned)groups);
   hipEvent_t ev = (hipEvent_t)done_event;
@@ -907,6 +887,60 @@ extern "C" int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const vo
                                                       act_gs, stats, 4 * C, mask_from_y);
   }
   return launch_status("bn_bwd_apply_kernel");
+}
+
+extern "C" int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                                int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma,
+                                int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
+                                float* partial, float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks,
+                                void* done_event, void* stream) {
+  IEEE_REQUIRE(dout && y && dy && gamma && stats && partial && coef, "bn2d_bwd: null pointer");
+  IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_bwd: bad dtype");
+  IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_bwd: C not a multiple of the vector width");
+  hipStream_t st = (hipStream_t)stream;
+  RedGeom g = red_geom(M, (int)C, vec_of(dtype));
+  if (stats_rblocks > 0) g.rblocks = (int)stats_rblocks;   // sums already emitted by the producing dgrad
+  const int64_t partial_gs = (int64_t)g.rblocks * 2 * C;
+  dim3 rgrid(g.cblocks * g.rblocks, (unsigned)groups);
+  if (stats_rblocks > 0) {
+  } else if (dtype == IEEE_F32)
+    bn_bwd_reduce_kernel<float><<<rgrid, 256, 0, st>>>((const float*)dout, (const float*)out_mask, (const float*)y,
+                                                       act_gs, g, partial, partial_gs, stats, 4 * C, mask_from_y);
+  else
+    bn_bwd_reduce_kernel<bf16><<<rgrid, 256, 0, st>>>((const bf16*)dout, (const bf16*)out_mask, (const bf16*)y, act_gs,
+                                                      g, partial, partial_gs, stats, 4 * C, mask_from_y);
+  IEEE_TRY(launch_status("bn_bwd_reduce_kernel"));
+  const int lpc = finalize_lpc(g.rblocks);
+  bn_bwd_finalize_kernel<<<dim3(cdiv(C, 256 / lpc), (unsigned)groups), 256, 0, st>>>(
+      partial, partial_gs, g.rblocks, (int)M, (int)C, gamma, param_gs, stats, 4 * C, dgamma, dbeta, grad_gs, coef,
+      3 * C, accumulate, stats_rblocks > 0 ? 1 : 0, lpc);
+  IEEE_TRY(launch_status("bn_bwd_finalize_kernel"));
+  return launch_bwd_apply(dout, out_mask, y, dy, g_out, dtype, groups, M, C, act_gs, stats, coef, mask_from_y, done_event, st);
+}
+
+namespace ieee {
+// frozen BatchNorm (eval-mode statistics): y -> y * scale + shift is a fixed affine map, so dy = scale * g
+__global__ void bn_frozen_coef_kernel(const float* __restrict__ stats, int64_t stats_gs, float* __restrict__ coef,
+                                      int64_t coef_gs, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float* k = coef + blockIdx.y * coef_gs;
+  k[c] = stats[blockIdx.y * stats_gs + 2 * C + c];
+  k[C + c] = 0.f;
+  k[2 * C + c] = 0.f;
+}
+}  // namespace ieee
+
+extern "C" int ieee_bn2d_bwd_frozen(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                                    int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* stats, float* coef,
+                                    int mask_from_y, void* done_event, void* stream) {
+  IEEE_REQUIRE(dout && y && dy && stats && coef, "bn2d_bwd_frozen: null pointer");
+  IEEE_REQUIRE(dtype == IEEE_F32 || dtype == IEEE_BF16, "bn2d_bwd_frozen: bad dtype");
+  IEEE_REQUIRE(C % vec_of(dtype) == 0, "bn2d_bwd_frozen: C not a multiple of the vector width");
+  hipStream_t st = (hipStream_t)stream;
+  bn_frozen_coef_kernel<<<dim3(cdiv(C, 256), (unsigned)groups), 256, 0, st>>>(stats, 4 * C, coef, 3 * C, (int)C);
+  IEEE_TRY(launch_status("bn_frozen_coef_kernel"));
+  return launch_bwd_apply(dout, out_mask, y, dy, g_out, dtype, groups, M, C, act_gs, stats, coef, mask_from_y, done_event, st);
 }
 
 extern "C" int ieee_bn2d_bwd_pooled(const void* dpool, const uint8_t* argmax, const void* y, void* dy, int dtype,

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwdArgs a) {
 #pragma unroll 4
     for (int r = ty; r < a.R; r += RB_TY) {
       float gq = dout[(int64_t)r * a.lddo + c];
-      if (a.relu && !(out[(int64_t)r * a.ldo + c] > 0.f)) gq = 0.f;
+      if ((a.relu & 1) && !(out[(int64_t)r * a.ldo + c] > 0.f)) gq = 0.f;
       s1 += gq;
       s2 += gq * (x[(int64_t)r * a.ldx + c] - mean) * invstd;
     }
@@ -314,18 +314,19 @@ __global__ __launch_bounds__(256) void rowbn_bwd_kernel(RowBnBwdArgs a) {
   s2 = rb_sum(red[1], tx);
   if (!ok) return;
   const float ga = ((const float*)a.gamma.p[g])[c];
-  if (ty == 0) {
+  const bool frozen = (a.relu & 2) != 0;      // eval-mode statistics: a fixed affine map, dx = gamma * invstd * g
+  if (ty == 0 && !frozen) {
     float* dg = (float*)a.dgamma.p[g] + c;
     float* db = (float*)a.dbeta.p[g] + c;
     *dg = a.accumulate ? *dg + s2 : s2;
     *db = a.accumulate ? *db + s1 : s1;
   }
   float* dx = (float*)a.dx.p[g];
-  const float c1 = s1 / a.R, c2 = s2 / a.R;
+  const float c1 = frozen ? 0.f : s1 / a.R, c2 = frozen ? 0.f : s2 / a.R;
 #pragma unroll 4
   for (int r = ty; r < a.R; r += RB_TY) {
     float gq = dout[(int64_t)r * a.lddo + c];
-    if (a.relu && !(out[(int64_t)r * a.ldo + c] > 0.f)) gq = 0.f;
+    if ((a.relu & 1) && !(out[(int64_t)r * a.ldo + c] > 0.f)) gq = 0.f;
     const float xh = (x[(int64_t)r * a.ldx + c] - mean) * invstd;
     dx[(int64_t)r * a.lddx + c] = ga * invstd * (gq - c1 - xh * c2);
   }

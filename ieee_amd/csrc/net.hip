@@ -34,6 +34,7 @@ struct ConvUnit {
   Tensor abits;                    // bf16 block outputs: the ReLU mask of `a` as packed bits (bn_apply writes it, the next block's conv1 dgrad reads it)
   bool want_bits = false;
   bool need_dgrad = true;
+  int child = IEEE_FROZEN_BACKBONE;   // which freezable child of the model owns this unit (ieee_net_set_frozen bits)
   int64_t M(int B) const { return (int64_t)B * Ho * Wo; }
 };
 
@@ -69,6 +70,7 @@ struct Net {
   static constexpr int NGBUF = 15;   // three sets of five activation-sized gradient buffers (IEEE_GBUF_SETS=2: two of them used)
   // config
   int B, H, W, num_classes, dtype, interaction, attention, using_rem;
+  int frozen = 0;                    // ieee_net_set_frozen: children whose BatchNorms run on their running statistics
   int parts = 6, rdim = 768, cdim = 128, fdim = 2048, hid = 128;
   float bn_eps = 1e-5f, bn_mom = 0.1f;
   // slots
@@ -153,7 +155,8 @@ struct Net {
   std::map<std::string, Tensor> taps;
   // optional per-launch timing of the conv kernels (bench.py's roofline leg): category 0 = forward +
   // dgrad (conv_gather_kernel), 1 = wgrad (conv_wgrad_kernel)
-  bool profiling = false;
+  int profiling = 0;   // 1: per-launch events on ONE ordered stream (the serialized roofline pass); 2: the same events with the
+                       // weight-gradient / branch streams left on (what a launch takes inside the real two-stream step)
   std::vector<hipEvent_t> ev_pool;
   std::vector<int> ev_cat;
   std::vector<std::string> ev_name;
@@ -248,6 +251,8 @@ void Net::build() {
   }
   u_one = add_unit("convOne.{m}.layers.0", "convOne.{m}.layers.1", fdim, fdim, 1, 1, 0, h, w);
   u_rest = add_unit("convAvgRest.{m}.layers.0", "convAvgRest.{m}.layers.1", fdim, fdim, 1, 1, 0, h, w);
+  units[u_one].child = IEEE_FROZEN_CONV_ONE;
+  units[u_rest].child = IEEE_FROZEN_CONV_REST;
   s_ca1 = slot3("CA.{m}.fc.0.weight");
   s_ca2 = slot3("CA.{m}.fc.2.weight");
   s_rw = slot3("reduce_layer.{m}.layers.0.weight");
@@ -445,9 +450,10 @@ struct Run {
   // fused_stats: the conv epilogue emits the BN partial sums (bf16 training path) -> bn() skips its stats pass
   bool fused_stats = false;
   bool fused_fin = false;    // ... and finalized them too (ieee_conv2d_fwd_bn_train): bn() only applies
+  bool frz(const ConvUnit& u) const { return (n.frozen & u.child) != 0; }
   int conv(const ConvUnit& u, const void* in, bool want_stats = false) {
     const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
-    fused_stats = want_stats && n.dtype == IEEE_BF16;
+    fused_stats = want_stats && n.dtype == IEEE_BF16 && !frz(u);
     // (off by default: correct and bit-reproducible, but measured SLOWER -- 15.40 -> 15.91 ms per step: every workgroup of the
     // conv has to drain its output stores before it may take its ticket, which costs the conv more than the launch saves)
     static const bool f_fin = getenv("IEEE_BN_FIN_FUSE") && atoi(getenv("IEEE_BN_FIN_FUSE")) != 0;
@@ -462,6 +468,7 @@ struct Run {
                            (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, fused_stats ? bnpart_cur : nullptr, st);
   }
   int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training, void* relu_bits = nullptr) {
+    if (frz(u)) training = 0;      // frozen child: running statistics, no update (module.eval() in the reference)
     const int64_t rb = (training && fused_fin) ? -1 : ((training && fused_stats) ? ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) : 0);
     fused_stats = false;
     fused_fin = false;
@@ -507,8 +514,12 @@ struct Run {
     if (gout) will_write(gout);
     // (the first use checks once per process that a never-recorded stop event does order another stream on this runtime --
     // ieee_event_ride_selfcheck, bn.hip -- and falls back to hipEventRecord in wgrad() if it does not)
-    static const bool ride = !(getenv("IEEE_EVENT_RIDE") && atoi(getenv("IEEE_EVENT_RIDE")) == 0) && ieee_event_ride_selfcheck() == 0;
-    bn_done = (ride && side_enabled()) ? next_ready_event() : nullptr;
+    static const bool ride_wanted = !(getenv("IEEE_EVENT_RIDE") && atoi(getenv("IEEE_EVENT_RIDE")) == 0);
+    const bool ride = ride_wanted && side_enabled() && ieee_event_ride_selfcheck(st, (void*)n.side) == 0;   // (cached after the first call)
+    bn_done = ride ? next_ready_event() : nullptr;
+    if (frz(u))
+      return ieee_bn2d_bwd_frozen(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, F(u.stats), bncoef_cur,
+                                  mask_from_y, (void*)bn_done, st);
     return ieee_bn2d_bwd_ev(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
                             F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, bncoef_cur, 0, mask_from_y, rb,
                             (void*)bn_done, st);
@@ -520,7 +531,7 @@ struct Run {
   }
   bool side_enabled() {
     static const bool on = !(getenv("IEEE_WGRAD_ASYNC") && atoi(getenv("IEEE_WGRAD_ASYNC")) == 0);
-    if (!on || n.profiling) return false;   // the per-launch timing table needs one ordered stream
+    if (!on || n.profiling == 1) return false;   // the per-launch timing table needs one ordered stream
     if (n.side == nullptr) {
       int least = 0, greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -899,8 +910,9 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
       ga[m] = par(N.s_rg + m); be[m] = par(N.s_rb + m); rm[m] = buf(N.s_rrm + m); rv[m] = buf(N.s_rrv + m);
       s1[m] = F(N.sv_g) + m * 2 * R; s2[m] = F(N.sv_p) + m * 2 * R;
     }
-    IEEE_TRY(ieee_rowbn_fwd(3, x1, o1, ga, be, rm, rv, s1, B, R, R, R, N.bn_mom, N.bn_eps, training, 1, st));
-    IEEE_TRY(ieee_rowbn_fwd(3, x2, o2, ga, be, rm, rv, s2, PB, R, R, R, N.bn_mom, N.bn_eps, training, 1, st));
+    const int tr_red = (training && !(N.frozen & IEEE_FROZEN_REDUCE)) ? 1 : 0;
+    IEEE_TRY(ieee_rowbn_fwd(3, x1, o1, ga, be, rm, rv, s1, B, R, R, R, N.bn_mom, N.bn_eps, tr_red, 1, st));
+    IEEE_TRY(ieee_rowbn_fwd(3, x2, o2, ga, be, rm, rv, s2, PB, R, R, R, N.bn_mom, N.bn_eps, tr_red, 1, st));
   }
   // REM (nonLocal) closed form: part + 2*param*(W_p global + b_p)   :60-80, :484-488
   const float* p2 = F(N.part);
@@ -928,7 +940,15 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
       }
     IEEE_TRY(ieee_sgemm_grouped_ws(18, a, w, c, bi, B, D, R, (int64_t)N.parts * R, 1, R, 1, D, 1.0f, 0, 0, P(N.gemm_work),
                                    (int64_t)N.gemm_work.numel * 4, st));
-    IEEE_TRY(ieee_rowbn_fwd(18, xs, o, ga, be, rm, rv, sv, B, D, D, training ? R : 3 * R, N.bn_mom, N.bn_eps, training, 1, st));
+    const int fz = (N.frozen / IEEE_FROZEN_FC_R) & 7;      // per-modality frozen bits of the fc heads
+    if (!training || fz == 0 || fz == 7) {
+      IEEE_TRY(ieee_rowbn_fwd(18, xs, o, ga, be, rm, rv, sv, B, D, D, training ? R : 3 * R, N.bn_mom, N.bn_eps,
+                              (training && fz == 0) ? 1 : 0, 1, st));
+    } else {
+      for (int m = 0; m < 3; ++m)
+        IEEE_TRY(ieee_rowbn_fwd(6, xs + 6 * m, o + 6 * m, ga + 6 * m, be + 6 * m, rm + 6 * m, rv + 6 * m, sv + 6 * m, B, D, D, R,
+                                N.bn_mom, N.bn_eps, (fz >> m) & 1 ? 0 : 1, 1, st));
+    }
   }
   if (!training) {
     IEEE_HIP(hipMemcpyAsync(feats_out, F(N.fcall), sizeof(float) * (size_t)B * 3 * R, hipMemcpyDeviceToDevice, (hipStream_t)st));
@@ -1063,7 +1083,7 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
   // the max-pool backward is gathered inside the two passes of the BatchNorm backward (IEEE_STEM_BWD_FUSE=0: three passes
   // with the un-pooled gradient written and read back twice)
   static const bool fuse_stem = !(getenv("IEEE_STEM_BWD_FUSE") && atoi(getenv("IEEE_STEM_BWD_FUSE")) == 0);
-  if (fuse_stem) {
+  if (fuse_stem && !frz(s)) {
     fused_bwd = false;
     IEEE_TRY(ieee_bn2d_bwd_pooled(X, (const uint8_t*)P(N.pool_arg), P(s.y), Q, dt, 3, B, s.Ho, s.Wo, s.Co, par(s.s_g),
                                   gs(s.s_g), F(s.stats), grd(s.s_g), grd(s.s_b), gs(s.s_g), bnpart_cur, bncoef_cur, 0, st));
@@ -1114,7 +1134,14 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
     IEEE_TRY(ieee_sgemm_grouped_ws(18, dl, w, dfc, nullptr, B, D, NC, NC, 1, 1, D, R, 1.0f, 0, 1, P(N.gemm_work),
                                    (int64_t)N.gemm_work.numel * 4, st));
     // fc: BN1d+ReLU backward, then Linear backward
-    IEEE_TRY(ieee_rowbn_bwd(18, (const void* const*)dfc, fe, xs, ga, sv, dx, dg, dbe, B, D, R, R, D, D, 1, 0, st));
+    const int fz = (N.frozen / IEEE_FROZEN_FC_R) & 7;
+    if (fz == 0 || fz == 7) {
+      IEEE_TRY(ieee_rowbn_bwd(18, (const void* const*)dfc, fe, xs, ga, sv, dx, dg, dbe, B, D, R, R, D, D, fz ? 3 : 1, 0, st));
+    } else {
+      for (int m = 0; m < 3; ++m)
+        IEEE_TRY(ieee_rowbn_bwd(6, (const void* const*)dfc + 6 * m, fe + 6 * m, xs + 6 * m, ga + 6 * m, sv + 6 * m, dx + 6 * m,
+                                dg + 6 * m, dbe + 6 * m, B, D, R, R, D, D, (fz >> m) & 1 ? 3 : 1, 0, st));
+    }
     IEEE_TRY(ieee_sgemm_grouped_ws(18, dfr, pp, dwf, nullptr, D, R, B, 1, D, 1, (int64_t)N.parts * R, R, 1.0f, 0, 0, P(N.gemm_work),
                                    (int64_t)N.gemm_work.numel * 4, st));
     IEEE_TRY(ieee_colsum_grouped(18, dfr, dbf, B, D, D, 0, st));
@@ -1158,8 +1185,9 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
       dx2[m] = F(N.dZg) + (int64_t)m * B * R; s2[m] = F(N.sv_g) + m * 2 * R;
       ga[m] = par(N.s_rg + m); dg[m] = grd(N.s_rg + m); db[m] = grd(N.s_rb + m);
     }
-    IEEE_TRY(ieee_rowbn_bwd(3, d1, o1, x1, ga, s1, dx1, dg, db, PB, R, R, R, R, R, 1, 0, st));
-    if (have_dglob) IEEE_TRY(ieee_rowbn_bwd(3, d2, o2, x2, ga, s2, dx2, dg, db, B, R, R, R, R, R, 1, 1, st));
+    const int rl = (N.frozen & IEEE_FROZEN_REDUCE) ? 3 : 1;
+    IEEE_TRY(ieee_rowbn_bwd(3, d1, o1, x1, ga, s1, dx1, dg, db, PB, R, R, R, R, R, rl, 0, st));
+    if (have_dglob) IEEE_TRY(ieee_rowbn_bwd(3, d2, o2, x2, ga, s2, dx2, dg, db, B, R, R, R, R, R, rl, 1, st));
   }
   // reduce conv: dWr = dZp^T Pp (+ dZg^T Gp); dPp = dZp Wr; dGp = dZg Wr
   IEEE_TRY(gemm3(F(N.dZp), (int64_t)PB * R, F(N.Pp), (int64_t)PB * C, grd(N.s_rw), gs(N.s_rw), nullptr, 0, R, C, PB, 1, R, 1,
@@ -1405,6 +1433,13 @@ extern "C" int ieee_net_sync_streams(void* handle, void* stream) {
   return IEEE_OK;
 }
 
+extern "C" int ieee_net_set_frozen(void* handle, int mask) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && mask >= 0 && mask < 128, "net_set_frozen: bad arguments");
+  n->frozen = mask;
+  return IEEE_OK;
+}
+
 extern "C" int ieee_net_eval_cache(void* handle, int keep) {
   Net* n = as_net(handle);
   IEEE_REQUIRE(n, "net_eval_cache: null handle");
@@ -1416,7 +1451,7 @@ extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {
   Net* n = as_net(handle);
   IEEE_REQUIRE(n, "net_profile: null handle");
   if (enable) {
-    n->profiling = true;
+    n->profiling = enable == 2 ? 2 : 1;
     n->ev_used = 0;
     n->ev_cat.clear();
     n->ev_name.clear();
@@ -1427,7 +1462,7 @@ extern "C" int ieee_net_profile(void* handle, int enable, double* out6) {
     return IEEE_OK;
   }
   IEEE_REQUIRE(out6, "net_profile: null output");
-  n->profiling = false;
+  n->profiling = 0;
   IEEE_HIP(hipDeviceSynchronize());   // host-side query, outside any timed region
   double ms[2] = {0, 0};
   for (size_t i = 0; i + 1 < n->ev_used; i += 2) {

@@ -1,5 +1,5 @@
-"""RGBNT201 directory parser and the 3-modal dataset (reference data/datasets/image/RGBNT201.py:13-79,
-data/datasets/dataset.py:320-351, utils/tools.py:98-119).  On-disk format: <root>/RGBNT201/{train_171,test}/{RGB,NI,TI}/
+"""RGBNT201 / Market1501-multimodal directory parsers and the 3-modal dataset (reference data/datasets/image/RGBNT201.py:13-79,
+data/datasets/image/market_to_RGBNT201.py:14-78, data/datasets/dataset.py:320-351, utils/tools.py:98-119).  On-disk format: <root>/RGBNT201/{train_171,test}/{RGB,NI,TI}/
 <pid6>_cam<X>_....jpg, the same file name in the three modality folders.  __getitem__ returns the DECODED uint8 images
 (PIL 'RGB'); resize / flip / normalisation happen on the device for the whole batch (transforms.DeviceTransform)."""
 import glob
@@ -83,3 +83,40 @@ class RGBNT201(object):
             paths = [rgb_path] + [osp.join(dir_path, folder, name) for folder in ('NI', 'TI')]
             records.append((paths, label_of[pid] if relabel else pid, cam, 0))
         return records
+
+
+class Market1501MM(RGBNT201):
+    """The multi-modal version of Market1501 (BASELINE config 5; reference data/datasets/image/market_to_RGBNT201.py:14-78):
+    <root>/<dataset_dir>/{train,query,gallery}/{RGB,NI,TI}/<pid>_c<cam>s<seq>_<frame>_<box>.jpg -- Market1501's own file
+    names, the same name in the three modality folders.  pid -1 marks junk detections, which are skipped (:54-55, :70-71);
+    0 <= pid <= 1501 and cameras 1..6 are asserted like the reference does (:72-73); the training identities are
+    relabelled to 0..n-1 (750 of them in the published split).  The reference hard-codes its author's Windows path as
+    `dataset_dir` (:15); here it is a folder name under `root`, overridable by keyword."""
+    dataset_dir = 'market1501_to_RGBNT201_dark'
+    splits = (('train', 'train', True), ('query', 'query', False), ('gallery', 'gallery', False))
+
+    def __init__(self, root='', dataset_dir=None, **kwargs):
+        if dataset_dir is not None:
+            self.dataset_dir = dataset_dir
+        super(Market1501MM, self).__init__(root=root, **kwargs)
+
+    @staticmethod
+    def _parse(name):
+        fields = name.split('_')
+        return int(fields[0]), int(fields[1][1])
+
+    def process_dir(self, dir_path, relabel=False):
+        names = [(_file_name(p), p) for p in glob.glob(osp.join(dir_path, 'RGB', '*.jpg'))]
+        names = [(n, p) for n, p in names if self._parse(n)[0] != -1]           # junk images are just ignored
+        label_of = {pid: label for label, pid in enumerate({self._parse(n)[0] for n, _ in names})}
+        records = []
+        for name, rgb_path in names:
+            pid, cam = self._parse(name)
+            assert 0 <= pid <= 1501      # pid == 0 means background
+            assert 1 <= cam <= 6
+            paths = [rgb_path] + [osp.join(dir_path, folder, name) for folder in ('NI', 'TI')]
+            records.append((paths, label_of[pid] if relabel else pid, cam - 1, 0))
+        return records
+
+
+market_to_RGBNT201 = Market1501MM        # the reference's class name

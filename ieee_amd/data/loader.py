@@ -2,6 +2,10 @@
 process with workers=0, configs/RGBNT_ieee_part_margin.yaml:13); the decoded bytes are resized / flipped / normalised on
 the GPU per batch.  Yields the reference's batch dict: {'img': [RGB, NI, TI] float tensors [B,3,H,W] (on the device),
 'pid', 'camid', 'impath', 'timeid'} (data/datasets/dataset.py:344-351)."""
+import queue
+import threading
+
+import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
@@ -11,11 +15,71 @@ from .transforms import build_transforms
 
 
 def _collate(items):
-    return {'img': [it['img'] for it in items],                       # [sample][modality] uint8 arrays
+    """Runs in the WORKER.  When the batch's images of a modality all have one size (every dataset of the 3-modal configs:
+    RGBNT201 is 256x128 throughout) they leave the worker as ONE uint8 tensor [B, H, W, 3] per modality -- torch tensors
+    cross the worker pipe through shared memory, a list of 192 numpy arrays is pickled and copied -- else as the list."""
+    raw = [it['img'] for it in items]                                 # [sample][modality] uint8 arrays
+    mods = len(raw[0]) if raw else 0
+    if raw and all(len(set(r[m].shape for r in raw)) == 1 for m in range(mods)):
+        raw = [torch.from_numpy(np.stack([r[m] for r in raw])) for m in range(mods)]       # [modality] -> [B, H, W, 3]
+    return {'img': raw,
             'pid': torch.as_tensor([it['pid'] for it in items], dtype=torch.int64),
             'camid': torch.as_tensor([it['camid'] for it in items], dtype=torch.int64),
             'impath': [it['impath'] for it in items],
             'timeid': torch.as_tensor([it['timeid'] for it in items], dtype=torch.int64)}
+
+
+class _SlotDataset(torch.utils.data.Dataset):
+    """Ring path (DeviceLoader(prefetch > 0, workers > 0)): a worker decodes a WHOLE batch straight into slot `slot` of a
+    shared uint8 ring [slots][modality][B][H][W][3] -- one mapping, inherited by the forked workers and registered with the
+    HIP runtime as pinned host memory by the parent -- and sends back only the labels.  What the tensor path pays per batch
+    in the parent (three file descriptors received and mapped, a 19 MB copy into pinned memory by the DataLoader's pin
+    thread, all under the interpreter lock the train step also needs) disappears: measured on the GPU box with the B = 64
+    step running beside it, scripts/loader_probe.py.  A batch whose images do not all have the ring's size travels as the
+    list (`img` not None) and takes the general path."""
+
+    def __init__(self, base, ring):
+        self.base, self.ring = base, ring
+        self.view = ring.numpy()               # shares the mapping
+
+    def __len__(self):
+        return len(self.base)
+
+    def __getitem__(self, key):
+        slot, indices = key
+        items = [self.base[i] for i in indices]
+        mods, (H, W) = self.view.shape[1], self.view.shape[3:5]
+        fits = len(items) <= self.view.shape[2] and all(len(it['img']) == mods and all(im.shape == (H, W, 3) for im in it['img'])
+                                                         for it in items)
+        if fits:
+            for j, it in enumerate(items):
+                for m in range(mods):
+                    self.view[slot, m, j] = it['img'][m]
+        return {'slot': slot, 'rows': len(items), 'img': None if fits else [it['img'] for it in items],
+                'pid': torch.as_tensor([it['pid'] for it in items], dtype=torch.int64),
+                'camid': torch.as_tensor([it['camid'] for it in items], dtype=torch.int64),
+                'impath': [it['impath'] for it in items],
+                'timeid': torch.as_tensor([it['timeid'] for it in items], dtype=torch.int64)}
+
+
+class _SlotSampler(object):
+    """(slot, dataset indices) per batch; the slot counter runs on across epochs, so a slot is rewritten only after
+    `slots` further batches have been handed out"""
+
+    def __init__(self, batches, slots):
+        self.batches, self.slots, self.k = batches, slots, 0
+
+    def __iter__(self):
+        for idx in self.batches:
+            yield (self.k % self.slots, list(idx))
+            self.k += 1
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def _identity(x):
+    return x
 
 
 class DeviceLoader(object):
@@ -27,9 +91,14 @@ class DeviceLoader(object):
     shards of, stamped on every batch so the engine needs no collective to scale the cross entropy."""
 
     def __init__(self, data, transform, batch_size, sampler=None, shuffle=False, workers=4, drop_last=False, rank=0, world=1,
-                 global_rows=None):
+                 global_rows=None, prefetch=0):
         self.dataset = MultiModalImageDataset(data)
         self.transform = transform
+        # prefetch = k > 0: a background thread keeps up to k batches READY ON THE DEVICE -- it takes the decoded batch from
+        # the workers (pinned), draws the flips, and runs the copy + resize / flip / normalise kernel on its own HIP stream
+        # while the caller's stream runs the previous train step; the consumer only waits on an event.  Same batches, same
+        # flips, same bits as prefetch = 0 (the thread is then the only drawer of flips, in batch order).
+        self.prefetch = int(prefetch)
         self.rank, self.world = int(rank), int(world)
         self.global_rows = global_rows
         self.batch_size = int(batch_size)
@@ -41,10 +110,52 @@ class DeviceLoader(object):
                 self._all.pop()
             self._owned = list(range(self.rank, len(self._all), self.world))
             self.loader = DataLoader(self.dataset, batch_sampler=[self._all[b] for b in self._owned], num_workers=workers,
-                                     collate_fn=_collate, pin_memory=False)
+                                     collate_fn=_collate, pin_memory=self._pin(), persistent_workers=workers > 0)
+        elif self.prefetch > 0 and workers > 0 and torch.cuda.is_available() and self._make_ring(sampler, shuffle, drop_last, workers):
+            pass                                                         # self.loader / self.ring set by _make_ring
         else:
             self.loader = DataLoader(self.dataset, batch_size=batch_size, sampler=sampler, shuffle=shuffle and sampler is None,
-                                     num_workers=workers, collate_fn=_collate, drop_last=drop_last, pin_memory=False)
+                                     num_workers=workers, collate_fn=_collate, drop_last=drop_last, pin_memory=self._pin(),
+                                     persistent_workers=workers > 0)     # (an epoch of RGBNT201 is a few hundred batches:
+                                     # respawning W processes that import torch at every epoch costs seconds)
+
+    ring = None
+
+    def _make_ring(self, sampler, shuffle, drop_last, workers):
+        """the shared pinned ring + a DataLoader whose workers fill it (see _SlotDataset); False: keep the tensor path"""
+        if len(self.dataset) == 0:
+            return False
+        first = self.dataset[0]['img']
+        shapes = set(np.asarray(im).shape for im in first)
+        if len(shapes) != 1 or len(next(iter(shapes))) != 3 or next(iter(shapes))[2] != 3:
+            return False
+        H, W, _ = next(iter(shapes))
+        slots = workers * 2 + self.prefetch + 3          # in flight: 2 per worker (prefetch_factor) + the ready queue + 1 in use
+        ring = torch.empty((slots, len(first), self.batch_size, H, W, 3), dtype=torch.uint8).share_memory_()
+        try:                                             # hipHostRegister: async H2D copies straight out of the shared mapping
+            rc = torch.cuda.cudart().cudaHostRegister(ring.data_ptr(), ring.numel(), 0)
+            if int(rc) != 0:
+                return False
+        except Exception:
+            return False
+        self.ring, self._ring_registered = ring, True
+        base = torch.utils.data.RandomSampler(self.dataset) if (shuffle and sampler is None) else (
+            sampler if sampler is not None else torch.utils.data.SequentialSampler(self.dataset))
+        batches = torch.utils.data.BatchSampler(base, self.batch_size, drop_last)
+        self._slot_sampler = _SlotSampler(batches, slots)
+        self.loader = DataLoader(_SlotDataset(self.dataset, ring), batch_size=None, sampler=self._slot_sampler, num_workers=workers,
+                                 collate_fn=_identity, pin_memory=False, persistent_workers=True)
+        self.loader_base_sampler = base
+        return True
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ring_registered", False):
+                self.loader = None                       # stop the workers before the mapping goes away
+                torch.cuda.cudart().cudaHostUnregister(self.ring.data_ptr())
+                self._ring_registered = False
+        except Exception:
+            pass
 
     @property
     def sharded(self):
@@ -59,14 +170,91 @@ class DeviceLoader(object):
     def __len__(self):
         return len(self.loader)
 
+    def _pin(self):
+        return self.prefetch > 0 and torch.cuda.is_available()
+
     def __iter__(self):
-        sampler = getattr(self.loader, "sampler", None)
+        if self.prefetch <= 0:
+            return self._batches()
+        return self._prefetched()
+
+    def _prefetched(self):
+        """the batches of _batches(), produced `prefetch` ahead by a thread on its own stream"""
+        cuda = torch.cuda.is_available()
+        dev = torch.cuda.current_device() if cuda else None
+        # high priority: the copy + transform of a batch is ~0.1 ms of GPU work that must not queue behind a 15 ms step
+        side = torch.cuda.Stream(device=dev, priority=-1) if cuda else None
+        box = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    box.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def work():
+            try:
+                if cuda:
+                    torch.cuda.set_device(dev)
+                    with torch.cuda.stream(side):
+                        recent = []
+                        for batch in self._batches():
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                            # ring path: a slot is rewritten `slots` batches later; never leave more than prefetch + 2 copies
+                            # unfinished, so the copy out of a slot is long complete when a worker writes to it again
+                            recent.append(ev)
+                            if len(recent) > self.prefetch + 2:
+                                recent.pop(0).synchronize()
+                            if not put((batch, ev)):
+                                return
+                else:
+                    for batch in self._batches():
+                        if not put((batch, None)):
+                            return
+                put(None)
+            except BaseException as e:          # hand the failure to the consumer instead of dying silently
+                put(e)
+
+        th = threading.Thread(target=work, name="ieee-loader-prefetch", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = box.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                batch, ev = item
+                if ev is not None:
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(ev)                    # the consumer's stream, not the host, waits for the transform
+                    for t in batch['img']:
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(cur)          # allocated on the side stream, used (and later freed) on this one
+                yield batch
+        finally:
+            stop.set()
+            th.join(timeout=5.0)
+
+    def _batches(self):
+        sampler = getattr(self, "loader_base_sampler", None) if self.ring is not None else getattr(self.loader, "sampler", None)
         if hasattr(sampler, "prepare"):          # rank-sharded identity sampler: draw / exchange the epoch's order here, in
             sampler.prepare()                    # the main process, not at the DataLoader's first prefetch
         lo, hi = getattr(sampler, "lo", None), getattr(sampler, "hi", None)
         for k, batch in enumerate(self.loader):
             raw = batch['img']
-            n, mods = len(raw), len(raw[0])
+            if raw is None:                                          # ring path: the images sit in the pinned ring slot
+                rows = int(batch.pop('rows'))
+                raw = [self.ring[int(batch.pop('slot')), m, :rows] for m in range(self.ring.shape[1])]
+            elif 'slot' in batch:                                    # ring path, odd-sized batch: the list travelled
+                batch.pop('slot'), batch.pop('rows')
+            stacked = bool(raw) and torch.is_tensor(raw[0])          # [modality] -> [B, H, W, 3] (see _collate)
+            n, mods = (int(raw[0].shape[0]), len(raw)) if stacked else (len(raw), len(raw[0]))
             # the reference transforms sample by sample, modality by modality: draw the flips in that order
             if self.global_rows is not None and lo is not None and hi - lo == n:
                 # a shard of a global batch: draw the flips of the WHOLE global batch -- every rank consumes the same
@@ -76,7 +264,8 @@ class DeviceLoader(object):
                 flips = self.transform.draw_flips(int(self.global_rows) * mods).reshape(int(self.global_rows), mods)[lo:hi]
             else:
                 flips = self.transform.draw_flips(n * mods).reshape(n, mods)
-            batch['img'] = [self.transform([raw[i][m] for i in range(n)], flips=flips[:, m]) for m in range(mods)]
+            batch['img'] = [self.transform(raw[m] if stacked else [raw[i][m] for i in range(n)], flips=flips[:, m])
+                            for m in range(mods)]
             if self._owned is not None:
                 batch['batch_index'] = self._owned[k]
             if self.global_rows is not None:
@@ -86,11 +275,12 @@ class DeviceLoader(object):
 
 def build_loaders(dataset, height=256, width=128, transforms='random_flip', batch_size_train=8, batch_size_test=100,
                   train_sampler='RandomIdentitySampler', num_instances=4, workers=4, norm_mean=None, norm_std=None,
-                  rank=None, world=None):
+                  rank=None, world=None, prefetch=2):
     """train / query / gallery loaders for an RGBNT201-style dataset object (reference data/datamanager.py:158-245).
     rank / world default to the process group's (ieee_amd.dist).  With several ranks batch_size_train is the GLOBAL batch:
     the train loader yields this rank's identity-aligned shard of every global batch (ShardedIdentitySampler; the engine
-    sees `global_rows` in the batch and skips its own slicing), and the query / gallery loaders decode every world-th batch."""
+    sees `global_rows` in the batch and skips its own slicing), and the query / gallery loaders decode every world-th batch.
+    prefetch: batches the train loader keeps ready on the device ahead of the step (DeviceLoader; 0 = synchronous)."""
     from .. import dist as ddp
     world = ddp.world_size() if world is None else int(world)
     rank = ddp.rank() if rank is None else int(rank)
@@ -99,9 +289,10 @@ def build_loaders(dataset, height=256, width=128, transforms='random_flip', batc
                                   rank=rank, world=world)
     if world > 1:
         train = DeviceLoader(dataset.train, tr, sampler.local_batch, sampler=sampler, workers=workers, drop_last=True,
-                             global_rows=sampler.global_batch)
+                             global_rows=sampler.global_batch, prefetch=prefetch)
     else:
-        train = DeviceLoader(dataset.train, tr, batch_size_train, sampler=sampler, workers=workers, drop_last=True)
+        train = DeviceLoader(dataset.train, tr, batch_size_train, sampler=sampler, workers=workers, drop_last=True,
+                             prefetch=prefetch)
     query = DeviceLoader(dataset.query, te, batch_size_test, workers=workers, rank=rank, world=world)
     gallery = DeviceLoader(dataset.gallery, te, batch_size_test, workers=workers, rank=rank, world=world)
     return train, query, gallery

@@ -106,6 +106,31 @@ class DeviceTransform(object):
         if n == 0:
             return out
         flips = self.draw_flips(n) if flips is None else np.asarray(flips, dtype=np.uint8)
+        if torch.is_tensor(images):
+            # a whole batch of same-size images already stacked [N, H, W, 3] uint8 by the loader's workers (pinned when the
+            # DataLoader pins): one asynchronous copy, no per-image work on this thread
+            if images.dim() != 4 or images.shape[3] != 3 or images.dtype != torch.uint8:
+                raise ValueError("expected a uint8 [N, H, W, 3] batch, got %s %s" % (images.dtype, tuple(images.shape)))
+            hs, ws = int(images.shape[1]), int(images.shape[2])
+            t, bh, kh, bv, kv = self._tables_on(dev, hs, ws)
+            src = images.to(dev, non_blocking=True)
+            # the flip flags through a small ring of pinned buffers: a pageable source would make this copy synchronous --
+            # the prefetch thread would stall until its stream has drained behind the train step's kernels
+            ring = self.__dict__.setdefault("_flip_ring", {"at": 0, "bufs": [None] * 8})
+            slot = ring["at"] = (ring["at"] + 1) % 8
+            if ring["bufs"][slot] is None or ring["bufs"][slot].numel() < n:
+                ring["bufs"][slot] = torch.empty(max(n, 256), dtype=torch.uint8).pin_memory()
+            ring["bufs"][slot][:n].copy_(torch.from_numpy(flips))
+            fl = ring["bufs"][slot][:n].to(dev, non_blocking=True)
+            tmp = torch.empty((n, t["tmp_rows"], self.width, 3), dtype=torch.uint8, device=dev) if t["need_h"] else None
+            mean = (_lib.ctypes.c_float * 3)(*self.mean.tolist())
+            std = (_lib.ctypes.c_float * 3)(*self.std.tolist())
+            _lib.check(lib.ieee_resize_flip_normalize(
+                _lib.ptr(src), _lib.ptr(out), _lib.ptr(tmp) if tmp is not None else None, n, hs, ws, self.height,
+                self.width, _lib.ptr(bh) if t["need_h"] else None, _lib.ptr(kh) if t["need_h"] else None, t["ksize_h"],
+                _lib.ptr(bv) if t["need_v"] else None, _lib.ptr(kv) if t["need_v"] else None, t["ksize_v"],
+                t["ybox_first"], t["tmp_rows"], _lib.ptr(fl), mean, std, _lib.stream()))
+            return out
         groups = {}
         for i, im in enumerate(images):
             im = np.asarray(im)

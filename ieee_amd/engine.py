@@ -292,26 +292,32 @@ class Engine(object):
 
     def two_stepped_transfer_learning(self, epoch, fixbase_epoch, open_layers, model=None):
         """Freeze everything but `open_layers` for the first fixbase_epoch epochs, then train all (engine.py:507-529,
-        utils/torchtools.py:183-221).  The shipped configuration has fixbase_epoch = 0.  Frozen children stop
-        receiving optimizer updates; their BatchNorms keep running in batch mode inside the native forward (the
-        reference also puts them in eval() mode) -- said once when it happens."""
+        utils/torchtools.py:160-221: open_specified_layers puts every other child in eval() mode and stops its gradients,
+        open_all_layers undoes both).  The shipped configuration has fixbase_epoch = 0.  A native model takes the frozen
+        children through set_frozen_children: their BatchNorms then run on the running statistics inside the native
+        training forward and the backward differentiates through them as fixed affine maps."""
         model = self.model if model is None else model
         if model is None:
             return
         freezing = (epoch + 1) <= fixbase_epoch and open_layers is not None
+        keep = []
         if freezing:
             keep = [open_layers] if isinstance(open_layers, str) else list(open_layers)
             for layer in keep:
                 assert hasattr(model, layer), \
                     '"{}" is not an attribute of the model, please provide the correct name'.format(layer)
             print('* Only train {} (epoch: {}/{})'.format(keep, epoch + 1, fixbase_epoch))
-            if not getattr(self, "_warned_fixbase", False) and _is_native(model):
-                print('  (note: frozen children keep batch-mode BatchNorm statistics in the native forward)')
-                self._warned_fixbase = True
+        frozen = []
         for child_name, child in model.named_children():
             flag = (child_name in keep) if freezing else True
+            if not flag:
+                frozen.append(child_name)
+            if not _is_native(model):
+                child.train(flag)                     # a plain nn.Module: eval() mode for the frozen children
             for p in child.parameters():
                 p.requires_grad = flag
+        if _is_native(model):
+            model.set_frozen_children(frozen)
 
     # ---- data parallel helpers ---------------------------------------------------------------------------------------
     def _local_batch(self, data):

@@ -238,6 +238,24 @@ class IEEE3modalPart(nn.Module):
             self._part_runs, self._part_runs_key = out, key
         return self._part_runs
 
+    _FROZEN_BITS = {"backbone": 1, "convOne": 2, "convAvgRest": 4, "reduce_layer": 8, "fc_R": 16, "fc_N": 32, "fc_T": 64}
+
+    def set_frozen_children(self, names):
+        """The children that `open_specified_layers` puts in eval() mode (reference utils/torchtools.py:183-221: every child
+        outside `open_layers` during the first fixbase_epoch epochs): their BatchNorms use the running statistics in a
+        training forward and leave them (and num_batches_tracked) alone; the backward sees fixed affine maps
+        (include/ieee_amd.h: ieee_net_set_frozen).  names = None / empty: nothing is frozen (open_all_layers).  Whether a
+        frozen parameter is updated is the optimizer's business (requires_grad, Engine.two_stepped_transfer_learning)."""
+        names = set(names or ())
+        unknown = names - set(n for n, _ in self.named_children())
+        assert not unknown, "not children of the model: %s" % sorted(unknown)
+        self._frozen_children = names
+        self._frozen_mask = sum(bit for n, bit in self._FROZEN_BITS.items() if n in names)
+        for net in self._nets.values():
+            net.set_frozen(self._frozen_mask)
+        if hasattr(self, "_counter_inc"):
+            del self._counter_inc                # rebuilt with the frozen children's counters standing still
+
     def invalidate_eval_cache(self):
         """call after writing parameters or running statistics in a way torch's version counters do not see
         (e.g. through `.data`): the next eval forward re-packs the weights and re-derives the BatchNorm scale / shift"""
@@ -276,6 +294,7 @@ class IEEE3modalPart(nn.Module):
         if net is None:
             self._nets.clear()       # one live workspace at a time
             net = NativeNet(self, batch, height, width, self.compute_dtype)
+            net.set_frozen(getattr(self, "_frozen_mask", 0))
             self._nets[key] = net
         return net
 
@@ -293,6 +312,8 @@ class IEEE3modalPart(nn.Module):
                     top = key.split(".")[0]
                     u = True
                     if top in ("convOne", "convAvgRest") and not self.interaction:
+                        u = False
+                    if top in getattr(self, "_frozen_children", ()):     # eval() mode: num_batches_tracked stands still
                         u = False
                     used.append(1 if u else 0)
             self._counter_inc = self._counter_inc * torch.tensor(used, dtype=torch.int64,

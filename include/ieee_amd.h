@@ -246,14 +246,22 @@ int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void
                   int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
                   const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, float* partial,
                   float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks, void* done_event, void* stream);
+/* backward through a FROZEN BatchNorm2d (module.eval() while the rest trains: open_specified_layers, utils/torchtools.py:
+ * 183-221): `stats` holds the running-statistics scale / shift of the forward (ieee_bn2d_fwd with training = 0), the map
+ * is a fixed affine one and dy = scale * g, g = dout * mask as in ieee_bn2d_bwd; no parameter gradient is produced. */
+int ieee_bn2d_bwd_frozen(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                         int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* stats, float* coef,
+                         int mask_from_y, void* done_event, void* stream);
 /* `done_event` above is never hipEventRecord-ed: it is the stop event of hipExtLaunchKernelGGL, and a consumer orders
  * another stream behind it with hipStreamWaitEvent.  HIP does not document that such an event orders a second stream, so
  * the dependency is MEASURED once per process before it is relied on: a ~300 us spinning kernel carries a pooled
- * hipEventDisableTiming event, a second stream waits on it and reads the flag the kernel sets last (three rounds; two
- * private streams, one 8-byte allocation, host-synchronous -- the only place the library waits for the device).
- * Returns 0 when the event rides, non-zero otherwise; the executor then falls back to hipEventRecord (IEEE_EVENT_RIDE=0
- * forces that).  Autograd-free: this replaces nothing in the reference (its streams are torch's). */
-int ieee_event_ride_selfcheck(void);
+ * hipEventDisableTiming event on stream_a, stream_b waits on it and reads the flag the kernel sets last (three rounds, one
+ * 8-byte allocation, host-synchronous on both streams -- the only place the library waits for the device).  The executor
+ * passes its launch and side stream; the check creates no streams of its own (doing so in the middle of a step disturbed
+ * the runtime's hardware-queue assignment: the side stream stopped overlapping the launch stream).  Returns 0 when the
+ * event rides (cached for the process), non-zero otherwise; the executor then falls back to hipEventRecord
+ * (IEEE_EVENT_RIDE=0 forces that).  Replaces nothing in the reference (its streams are torch's). */
+int ieee_event_ride_selfcheck(void* stream_a, void* stream_b);
 
 /* ---- stem plumbing ----------------------------------------------------------- */
 /* three fp32 NCHW image tensors (batch dict 'img' = [RGB, NI, TI], dataset.py:338-351) ->
@@ -337,6 +345,9 @@ int ieee_rowbn_fwd(int64_t groups, const void* const* x, void* const* out, const
                    const void* const* beta, void* const* running_mean, void* const* running_var,
                    void* const* save, int64_t R, int64_t C, int64_t ldx, int64_t ldo, float momentum,
                    float eps, int training, int relu, void* stream);
+/* backward: relu bit 0 = the forward applied ReLU; bit 1 = FROZEN BatchNorm (the forward ran with training = 0, e.g. a
+ * child outside `open_layers` during the fixbase epochs, utils/torchtools.py:183-221): dx = gamma * invstd * g and
+ * dgamma / dbeta are left untouched */
 int ieee_rowbn_bwd(int64_t groups, const void* const* dout, const void* const* out, const void* const* x,
                    const void* const* gamma, const void* const* save, void* const* dx, void* const* dgamma,
                    void* const* dbeta, int64_t R, int64_t C, int64_t lddo, int64_t ldo, int64_t ldx,
@@ -454,15 +465,33 @@ int ieee_net_side_wait(void* handle, void* workspace, void* waiting_stream, int 
  * launch stream) where the Python engine calls ieee_net_side_wait(launch_stream, 1); it is a no-op when nothing is
  * pending.  Does not block the host. */
 int ieee_net_sync_streams(void* handle, void* stream);
+/* Frozen children (Engine.two_stepped_transfer_learning -> open_specified_layers, torchreid/utils/torchtools.py:183-221: the
+ * children outside `open_layers` are put in eval() mode and stop requiring gradients for the first fixbase_epoch epochs).
+ * mask: bit 0 backbone, 1 convOne, 2 convAvgRest, 3 reduce_layer, 4 fc_R, 5 fc_N, 6 fc_T (the children that own a
+ * BatchNorm).  A frozen child's BatchNorms use their running statistics in a TRAINING forward, do not update them, and
+ * the backward treats them as the fixed affine maps they then are (ieee_bn2d_bwd_frozen); gradients still flow through a
+ * frozen child to whatever trains below it.  The caller keeps frozen parameters out of the optimizer step. */
+#define IEEE_FROZEN_BACKBONE 1
+#define IEEE_FROZEN_CONV_ONE 2
+#define IEEE_FROZEN_CONV_REST 4
+#define IEEE_FROZEN_REDUCE 8
+#define IEEE_FROZEN_FC_R 16
+#define IEEE_FROZEN_FC_N 32
+#define IEEE_FROZEN_FC_T 64
+int ieee_net_set_frozen(void* handle, int mask);
 /* Inference cache: after an eval-mode ieee_net_forward the workspace holds the packed weights and every BatchNorm's
  * scale / shift; the next eval forward on the same workspace reuses them (no packing launch, no finalize launches)
  * unless ieee_net_eval_cache(handle, 0) was called in between.  The CALLER must call it whenever parameters or
  * running statistics may have changed outside ieee_net_forward(training = 1) (optimizer steps, state loading, ...). */
 int ieee_net_eval_cache(void* handle, int keep);
-/* measurement: enable=1 starts recording a HIP event pair (on the launch stream) around every conv
- * launch of subsequent forward/backward calls; enable=0 stops, synchronises the device and returns
- * out6 = {ms, algorithmic FLOPs, launches} for [0] forward+dgrad (conv_gather_kernel) and
- * [1] wgrad (conv_wgrad_kernel + its slab reduce) */
+/* measurement: enable=1 starts recording a HIP event pair around every conv launch of subsequent forward/backward
+ * calls with ALL work on one ordered stream (the serialized pass: what each launch takes alone); enable=2 records the
+ * same pairs with the executor's own streams left on -- forward / dgrad pairs on the launch stream, weight-gradient
+ * pairs on the side stream they run on: what a launch takes INSIDE the two-stream step, beside the other stream's
+ * kernels (every pair adds two barrier packets to its queue, so a step measured this way is a little slower than a
+ * plain one); enable=0 stops, synchronises the device and returns
+ * out6 = {ms, algorithmic FLOPs, launches} for [0] forward+dgrad (conv_gather / conv3x3_patch / stem_conv kernels) and
+ * [1] wgrad (conv_wgrad / conv3x3_wgrad_patch / stem_wgrad kernels + their slab reductions) */
 int ieee_net_profile(void* handle, int enable, double* out6);
 /* debugging / parity tests: location of a named intermediate inside the workspace */
 int ieee_net_tensor(void* handle, const char* name, int64_t* byte_offset, int64_t* numel, int* dtype);

@@ -8,7 +8,8 @@ IEEE3modalPart train / eval step in stock torch fp32 ops, arranged as the refere
   cross_entropy_ls              <- torchreid/losses/cross_entropy_loss.py:36-50
   margin3m                      <- torchreid/losses/multi_modal_margin_loss_new.py:19-40
   train_step                    <- torchreid/engine/image/margin.py:94-154 (engine="margin") or
-                                   engine/image/softmax.py:81-132 (engine="softmax") + optim/optimizer.py:130-138
+                                   engine/image/softmax.py:81-132 (engine="softmax") + optim/optimizer.py:130-138;
+                                   frozen=... <- engine/engine.py:507-529 + utils/torchtools.py:183-221
 
 Works on a plain dict name -> tensor with the reference's state_dict keys.  Pinned against the imported
 reference by tests/test_model_oracle.py (here) and tests/golden/model_golden.npz / model_golden_r2.npz (everywhere).
@@ -17,11 +18,19 @@ import torch
 import torch.nn.functional as F
 
 EPS, MOM = 1e-5, 0.1
+# top-level children in eval() mode while the rest trains (open_specified_layers, torchreid/utils/torchtools.py:183-221);
+# set through train_step(frozen=...)
+FROZEN = ()
+
+
+def _live(p, training):
+    """train-mode statistics for the BatchNorm at state-dict prefix p?  (False inside a frozen child)"""
+    return bool(training) and p.split(".")[0] not in FROZEN
 
 
 def _bn(x, sd, p, training):
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
-                        training, MOM, EPS)
+                        _live(p, training), MOM, EPS)
 
 
 def bottleneck(x, sd, p, stride, has_ds, training):
@@ -63,15 +72,22 @@ def forward(sd, xs, training, loss="margin", interaction=True, attention=True, u
     return tail(sd, f, training, loss, interaction, attention, using_rem, taps)
 
 
-def tail(sd, f, training, loss="margin", interaction=True, attention=True, using_rem=True, taps=None):
+def tail(sd, f, training, loss="margin", interaction=True, attention=True, using_rem=True, taps=None, conv_out=None):
     """everything behind the three trunks (ieee3modalPart.py:445-523): f = the three [B, 2048, 16, 8] trunk maps.  Split
-    out of forward() so that a test can hand it the trunk maps of another implementation and differentiate from there."""
+    out of forward() so that a test can hand it the trunk maps of another implementation and differentiate from there.
+    conv_out = {"one": [3 maps], "rest": [3 maps]} (optional): the OUTPUTS of the convOne / convAvgRest convolutions, used
+    instead of computing them -- a test of a reduced-precision implementation starts behind its rounded conv outputs, so
+    that the ReLU masks of both sides are taken from the same numbers."""
     pooled, glob = [], []
     if interaction:
         for m in range(3):
             a, b = [k for k in range(3) if k != m]
-            one = dim_reduce(f[m], sd, "convOne.%d." % m, training)
-            rest = dim_reduce(f[a] + f[b], sd, "convAvgRest.%d." % m, training)
+            if conv_out is not None:
+                one = F.relu(_bn(conv_out["one"][m], sd, "convOne.%d.layers.1" % m, training))
+                rest = F.relu(_bn(conv_out["rest"][m], sd, "convAvgRest.%d.layers.1" % m, training))
+            else:
+                one = dim_reduce(f[m], sd, "convOne.%d." % m, training)
+                rest = dim_reduce(f[a] + f[b], sd, "convAvgRest.%d." % m, training)
             if attention:
                 rest = channel_attention(rest, sd, "CA.%d." % m) * rest + rest
             pooled.append(one + rest)
@@ -96,7 +112,7 @@ def tail(sd, f, training, loss="margin", interaction=True, attention=True, using
                                sd["fc_%s.%d.1.running_mean" % (letters[m], i)],
                                sd["fc_%s.%d.1.running_var" % (letters[m], i)],
                                sd["fc_%s.%d.1.weight" % (letters[m], i)], sd["fc_%s.%d.1.bias" % (letters[m], i)],
-                               training, MOM, EPS)) for i in range(6)] for m in range(3)]
+                               _live("fc_%s" % letters[m], training), MOM, EPS)) for i in range(6)] for m in range(3)]
     cat = [torch.cat(fc[m], 1) for m in range(3)]
     if not training:
         return torch.cat([cat[2], cat[0], cat[1]], 1)          # T, R, N   (:502)
@@ -172,15 +188,22 @@ def calibrate_running_stats(sd, xs, **flags):
 
 
 def train_step(sd, xs, pids, num_classes, lr=1e-3, momentum=0.9, wd=5e-4, mom_state=None, margin=1.0, engine="margin",
-               **flags):
+               frozen=(), **flags):
     """one engine step on CPU: returns (summary, grads, new_state, new_momentum).  SGD with nesterov
     (hard-coded in the reference, optim/optimizer.py:137), dampening 0.  engine = "margin" (Image3MEngine) or
     "softmax" (MultiModalImageSoftmaxEngine: CE only, model built with loss='softmax')."""
+    global FROZEN
     sd = {k: v.clone() for k, v in sd.items()}
     params, _ = split_state(sd)
+    # frozen children (two-stepped transfer learning, engine.py:507-529): eval()-mode BatchNorms, no gradient, no update
+    params = {k: v for k, v in params.items() if k.split(".")[0] not in frozen}
     for p in params.values():
         p.requires_grad_(True)
-    out = forward(sd, xs, True, engine, **flags)
+    keep, FROZEN = FROZEN, tuple(frozen)
+    try:
+        out = forward(sd, xs, True, engine, **flags)
+    finally:
+        FROZEN = keep
     if engine == "softmax":
         loss, summary = softmax_losses(out, pids, num_classes)
     else:

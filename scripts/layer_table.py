@@ -6,7 +6,8 @@ WRITE_SIZE per dispatch).  Launches and dispatches are matched by their order in
 order); a weight gradient's row includes its slab-reduction dispatches.  Output per (layer shape, kind): launches per step,
 mean us, GFLOP, TFLOP/s, fraction of the 2.5 PFLOP/s bf16 MFMA peak, HBM bytes per launch from the counters
 (2 * FETCH_SIZE + WRITE_SIZE, KiB -> bytes), algorithmic bytes per launch (operands read once + result written once, 3
-modalities), achieved TB/s on the PMC bytes."""
+modalities; for dgrad launches including the operands of their fused BatchNorm-backward epilogue: mean over the launches
+of the shape), achieved TB/s on the PMC bytes."""
 import collections
 import csv
 import glob
@@ -65,7 +66,12 @@ if pmc is None:
           (per_step, [len(s) for s in fetch][-3:], [len(s) for s in write][-3:]))
 
 
-def algorithmic_bytes(unit, kind):
+def algorithmic_bytes(unit, kind, name=""):
+    """operands read once + result written once, 3 modalities.  Round 4: a dgrad launch also carries the BatchNorm-backward
+    sums of the unit in front of it in its epilogue, and those operands are part of what the launch MUST move: the previous
+    unit's pre-BatchNorm output y (2 B per input element) for conv2 / conv3 / conv1, and at a block input (conv1 of every
+    block but the first) the identity-branch gradient it adds (2 B; a quarter of that behind a stride-2 downsample branch,
+    which hands its gradient back compact) and the packed ReLU bits of the previous block's output (1/8 B)."""
     m = re.search(r"(\d+)->(\d+) k(\d+) s(\d+) (\d+)x(\d+)", unit)
     ci, co, k, s, ho, wo = (int(x) for x in m.groups())
     B = 64
@@ -74,15 +80,29 @@ def algorithmic_bytes(unit, kind):
     w_e = co * ci * k * k
     if kind == "wgrad":
         return 3 * (2 * (out_e + in_e) + 4 * w_e)
-    return 3 * (2 * (out_e + in_e) + 2 * w_e)
+    extra = 0.0
+    if kind == "dgrad" and ".layer" in name:
+        leaf = name.rsplit(".", 1)[-1]
+        blk = re.search(r"layer(\d)\.(\d+)\.", name)
+        first_of_net = blk is not None and blk.group(1) == "1" and blk.group(2) == "0"
+        if leaf in ("conv2", "conv3"):
+            extra = 2.0 * in_e                                  # y of conv1 / conv2 for the fused BatchNorm-backward sums
+        elif leaf == "conv1":
+            has_ds = blk.group(2) == "0"
+            compact = has_ds and blk.group(1) in ("2", "3")     # stride-2 stages: the downsample gradient comes back compact
+            extra = 2.0 * in_e * (0.25 if compact else 1.0)     # the identity-branch gradient added in the epilogue
+            if not first_of_net:
+                extra += 2.0 * in_e + in_e / 8.0                # previous block's y3 + its packed ReLU bits
+    return 3 * (2 * (out_e + in_e) + 2 * w_e + extra)
 
 
 agg = collections.OrderedDict()
 nrep = len(rows) // per_step
 for i, r in enumerate(rows):
-    shape, kind = r["unit"].split(" ", 1)[1], r["kind"]
-    a = agg.setdefault((shape, kind), dict(us=0.0, n=0, gflop=0.0, bytes=0.0, nb=0))
-    a["us"] += float(r["us"]); a["n"] += 1; a["gflop"] += float(r["gflop"])
+    name, shape = r["unit"].split(" ", 1)
+    kind = r["kind"]
+    a = agg.setdefault((shape, kind), dict(us=0.0, n=0, gflop=0.0, bytes=0.0, nb=0, alg=0.0))
+    a["us"] += float(r["us"]); a["n"] += 1; a["gflop"] += float(r["gflop"]); a["alg"] += algorithmic_bytes(shape, kind, name)
 for i, r in enumerate(last):
     if pmc is not None:
         a = agg[(r["unit"].split(" ", 1)[1], r["kind"])]
@@ -95,5 +115,5 @@ with open(out, "w", newline="") as f:
         us, gf = a["us"] / a["n"], a["gflop"] / a["n"]
         pb = a["bytes"] / a["nb"] if a["nb"] else None
         w.writerow([shape, kind, a["n"] // nrep, "%.1f" % us, "%.2f" % gf, "%.0f" % (gf / us * 1e3), "%.3f" % (gf / us * 1e3 / 2500.0),
-                    "%.0f" % pb if pb else "", "%.0f" % algorithmic_bytes(shape, kind), "%.2f" % (pb / us / 1e6) if pb else ""])
+                    "%.0f" % pb if pb else "", "%.0f" % (a["alg"] / a["n"]), "%.2f" % (pb / us / 1e6) if pb else ""])
 print("wrote", out, "(%d rows, %d launches per step, %d steps%s)" % (len(agg), per_step, nrep, "" if pmc is None else ", PMC bytes joined"))

@@ -7,7 +7,7 @@ import torch
 from tests.util_trajectory import run_training, tamed_state, smooth
 
 kw = dict(epochs=int(os.environ.get("EPOCHS", 12)), batches_per_epoch=10, milestones=(8, 10),
-          noise=float(os.environ.get("NOISE", 0.5)), eval_noise={"easy": 0.5, "n2": 2.0, "n3": 3.0, "n4": 4.0},
+          noise=float(os.environ.get("NOISE", 0.5)), eval_noise={"easy": 0.5, "n4": 4.0, "n6": 6.0, "n8": 8.0, "n10": 10.0, "n14": 14.0},
           lr=float(os.environ.get("LR", 1e-3)))
 t0 = time.time()
 st = tamed_state(171)

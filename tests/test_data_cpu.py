@@ -130,6 +130,39 @@ def test_rgbnt201_parser_and_decode_loader(tmp_path):
     assert np.array_equal(first['img'][1][0].numpy(), want)
 
 
+def test_market1501_multimodal_parser(tmp_path):
+    """reference data/datasets/image/market_to_RGBNT201.py:14-78: train / query / gallery folders, Market1501 file names,
+    junk (-1) skipped, cameras 1..6 -> 0..5, training identities relabelled"""
+    from PIL import Image
+    split_names = {"train": ["0002_c1s1_000451_03.jpg", "0002_c3s1_000551_01.jpg", "0007_c2s3_071052_01.jpg", "-1_c1s1_000401_03.jpg"],
+                   "query": ["0001_c6s1_001051_00.jpg", "0003_c4s6_015641_02.jpg"],
+                   "gallery": ["0001_c1s1_001051_00.jpg", "0000_c2s1_000301_00.jpg", "-1_c5s1_000401_03.jpg", "1501_c6s4_001877_01.jpg"]}
+    base = tmp_path / "mm"
+    for split, names in split_names.items():
+        for mod in ("RGB", "NI", "TI"):
+            d = base / split / mod
+            d.mkdir(parents=True)
+            for n in names:
+                Image.fromarray(np.zeros((8, 4, 3), dtype=np.uint8), "RGB").save(str(d / n))
+    ds = datasets.Market1501MM(root=str(tmp_path), dataset_dir="mm")
+    assert datasets.market_to_RGBNT201 is datasets.Market1501MM
+    assert len(ds.train) == 3 and ds.num_train_pids == 2 and sorted({r[1] for r in ds.train}) == [0, 1]
+    by = {os.path.basename(r[0][0]): r for r in ds.train + ds.query + ds.gallery}
+    assert "-1_c1s1_000401_03.jpg" not in by and "-1_c5s1_000401_03.jpg" not in by
+    assert by["0002_c3s1_000551_01.jpg"][2] == 2 and by["0001_c6s1_001051_00.jpg"][2] == 5
+    assert by["0002_c1s1_000451_03.jpg"][1] == by["0002_c3s1_000551_01.jpg"][1] != by["0007_c2s3_071052_01.jpg"][1]
+    assert sorted(r[1] for r in ds.gallery) == [0, 1, 1501] and sorted(r[1] for r in ds.query) == [1, 3]     # raw pids
+    for r in ds.gallery:
+        assert [os.path.basename(os.path.dirname(p)) for p in r[0]] == ["RGB", "NI", "TI"]
+    item = datasets.MultiModalImageDataset(ds.query)[0]
+    assert len(item["img"]) == 3 and item["img"][0].shape == (8, 4, 3)
+    with pytest.raises(RuntimeError):
+        datasets.Market1501MM(root=str(tmp_path))                     # the default folder name is not there
+    (base / "train" / "RGB" / "0003_c7s1_000001_00.jpg").write_bytes(b"x")
+    with pytest.raises(AssertionError):
+        datasets.Market1501MM(root=str(tmp_path), dataset_dir="mm")   # camera 7 does not exist in Market1501
+
+
 # ---- shard-aware sampler / loader (SURVEY.md §8e rows 1-2, §8f N2)
 def test_sharded_sampler_slices_the_single_process_batches():
     data = _source(n_pid=17)
@@ -327,3 +360,24 @@ def test_two_ranks_decode_half_the_rows_and_sum_to_the_serial_gradient(tmp_path)
         out = dict(ret)
         assert len(out) == 2 and out[0][0] == out[1][0]            # both ranks decoded the same (halved) number of files
         assert sorted(out[0][1] + out[1][1]) == list(range(len(out[0][1]) + len(out[1][1])))
+
+
+def test_prefetch_thread_yields_the_synchronous_batches_and_propagates_errors(tmp_path):
+    from ieee_amd.data.loader import DeviceLoader
+    names = ["%06d_cam%d_0_%02d.jpg" % (pid, 1 + (j % 4), j) for pid in (3, 8, 11, 20) for j in range(4)]
+    _make_tree(str(tmp_path), names, size=(20, 12))
+    ds = datasets.RGBNT201(root=str(tmp_path))
+    got = {}
+    for prefetch in (0, 3):
+        random.seed(4); np.random.seed(4); torch.manual_seed(4)
+        stub = _FlipStub()
+        samp = smp.build_train_sampler(ds.train, 'RandomIdentitySampler', batch_size=8, num_instances=2)
+        loader = DeviceLoader(ds.train, stub, 8, sampler=samp, workers=0, drop_last=True, prefetch=prefetch)
+        got[prefetch] = ([b['pid'].tolist() for b in loader], [f.tolist() for f in stub.seen])
+    assert got[0] == got[3] and len(got[0][0]) >= 2
+
+    class Boom(_FlipStub):
+        def __call__(self, images, flips=None):
+            raise RuntimeError("transform failed")
+    with pytest.raises(RuntimeError, match="transform failed"):
+        list(DeviceLoader(ds.train, Boom(), 4, workers=0, prefetch=2))

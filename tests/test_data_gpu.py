@@ -81,3 +81,33 @@ def test_decode_loader_end_to_end(tmp_path):
             assert np.array_equal(batch['img'][m][i].cpu().numpy(), want)
     q = next(iter(query))
     assert q['img'][2].shape == (5, 3, 256, 128)
+
+
+def test_prefetched_loader_yields_the_same_batches_bit_for_bit(tmp_path):
+    """DeviceLoader(prefetch = 2): a background thread copies + transforms on its own stream while the consumer works; the
+    batches (rows, flips, pixels) are those of the synchronous loader under the same seeds"""
+    import random
+    from PIL import Image
+    from ieee_amd import data as D
+    rng = np.random.RandomState(2)
+    names = ["%06d_cam%d_0_%02d.jpg" % (pid, 1 + k % 4, k) for pid in (3, 9, 20, 31) for k in range(4)]
+    for split in ("train_171", "test"):
+        for mod in ("RGB", "NI", "TI"):
+            d = os.path.join(str(tmp_path), "RGBNT201", split, mod)
+            os.makedirs(d)
+            for nme in names:
+                Image.fromarray(rng.randint(0, 256, size=(64, 32, 3)).astype(np.uint8), "RGB").save(os.path.join(d, nme), quality=92)
+    ds = D.RGBNT201(root=str(tmp_path))
+    seen = {}
+    for prefetch in (0, 2):
+        random.seed(3); np.random.seed(3); torch.manual_seed(3)
+        train, _, _ = D.build_loaders(ds, 256, 128, "random_flip", batch_size_train=8, workers=2, prefetch=prefetch)
+        out = []
+        for b in train:
+            junk = torch.randn(512, 512, device="cuda") @ torch.randn(512, 512, device="cuda")    # the consumer's own work
+            out.append((b['pid'].clone(), [x.clone() for x in b['img']], junk.sum()))
+        torch.cuda.synchronize()
+        seen[prefetch] = out
+    assert len(seen[0]) == len(seen[2]) >= 2
+    for (p0, x0, _), (p2, x2, _) in zip(seen[0], seen[2]):
+        assert torch.equal(p0, p2) and all(torch.equal(a, b) for a, b in zip(x0, x2))

@@ -26,7 +26,7 @@ def _dev(a, b):
 
 def test_bf16_training_trajectory_tracks_the_fp32_parity_mode():
     st = tamed_state(171)
-    kw = dict(epochs=12, batches_per_epoch=10, milestones=(8, 10), eval_noise={"easy": 0.5, "hard": 3.0})
+    kw = dict(epochs=12, batches_per_epoch=10, milestones=(8, 10), eval_noise={"easy": 0.5, "hard": 6.0, "harder": 8.0})
     runs = {}
     for name, dt, pert in (("fp32", torch.float32, 0.0), ("control", torch.float32, 2.0 ** -12), ("bf16", torch.bfloat16, 0.0)):
         r = run_training(dt, st, perturb=pert, **kw)
@@ -55,13 +55,15 @@ def test_bf16_training_trajectory_tracks_the_fp32_parity_mode():
     assert abs(b16["loss"][0] - ref["loss"][0]) < 2e-3 * ref["loss"][0]
     # 3. same final training accuracy (within 2 points over the last 10 steps; the control moves it by as much)
     assert abs(b16["acc"][-10:].mean() - ref["acc"][-10:].mean()) < 2.0
-    # 4. Engine.test(): mAP within 0.1 point (north_star's number) and the same rank-1 on the evaluation set of the training
-    #    noise level; on the hard set (noise 3.0: descriptors of different identities overlap, a dozen queries decide the
-    #    number) the bar is the control's own movement + 2 points
-    assert abs(b16["evals"]["easy"][1] - ref["evals"]["easy"][1]) <= 1e-3
-    assert b16["evals"]["easy"][0] == ref["evals"]["easy"][0]
-    hard = lambda r: r["evals"]["hard"][1]
-    assert abs(hard(b16) - hard(ref)) <= abs(hard(ctl) - hard(ref)) + 0.02, (hard(b16), hard(ref), hard(ctl))
+    # 4. Engine.test() (48 queries x 64 gallery triples of the 8 training identities): mAP within 0.1 point (north_star's
+    #    number) and the same rank-1 on the evaluation set of the training noise level (0.5) and -- plus whatever the control
+    #    moves -- on the set with 12 x that noise (measured: fp32 1.0000, control 0.9986, bf16 0.9993).  At 16 x the noise
+    #    the ranking is decided by near-ties and the CONTROL moves mAP by 6 points (0.991 -> 0.927; bf16 0.934): there the bar
+    #    is the control's movement + 3 points.
+    mAP = lambda r, k: r["evals"][k][1]
+    assert abs(mAP(b16, "easy") - mAP(ref, "easy")) <= 1e-3 and b16["evals"]["easy"][0] == ref["evals"]["easy"][0]
+    assert abs(mAP(b16, "hard") - mAP(ref, "hard")) <= 1e-3 + abs(mAP(ctl, "hard") - mAP(ref, "hard")), (mAP(b16, "hard"), mAP(ref, "hard"))
+    assert abs(mAP(b16, "harder") - mAP(ref, "harder")) <= 0.03 + abs(mAP(ctl, "harder") - mAP(ref, "harder"))
 
 
 LEGS = {"interaction_off": dict(interaction=False), "attention_off": dict(attention=False), "rem_off": dict(using_REM=False)}
@@ -69,10 +71,12 @@ LEGS = {"interaction_off": dict(interaction=False), "attention_off": dict(attent
 
 def _tail_check(state, C, flags, B=32):
     """One bf16 engine step at (C, B) with the executor's gradient taps on; then the part of the step these flags switch --
-    everything behind the trunks: CIM (cim_tail / cim_bwd_* in the leg's mode), reduce layer, REM, the 18 heads, both losses
-    -- is differentiated by torch autograd in fp32 (oracle.model.tail on the native trunk maps, CIM conv weights rounded to
-    bf16 like the packed operands) and compared with what the native backward produced: the gradient handed to the trunk and
-    every parameter gradient of the tail."""
+    everything behind the CIM convolutions: the CIM tail (cim_tail / cim_bwd_* in the leg's mode), channel attention, reduce
+    layer, REM, the 18 heads, both losses -- is differentiated by torch autograd in fp32 (oracle.model.tail on the native
+    trunk maps and the native, bf16-rounded, convOne / convAvgRest outputs, so that both sides take their ReLU masks from the
+    same numbers) and compared with what the native backward produced: the gradient w.r.t. the two conv outputs (the taps
+    behind their BatchNorm backward), the gradient handed to the trunk by the pooling paths, and every parameter gradient of
+    the tail.  The conv units themselves are under tests/test_backward_units_gpu.py."""
     from ieee_amd.engine import Image3MEngine
     from ieee_amd.models import build_model
     from ieee_amd.optim import build_optimizer
@@ -88,33 +92,53 @@ def _tail_check(state, C, flags, B=32):
     xs, pids, cams = make_train_set(B // 4, 4, 21, 0.5)
     s = eng.forward_backward({"img": xs, "pid": pids, "camid": cams, "impath": "", "timeid": pids * 0})
     torch.cuda.synchronize()
+    inter = flags.get("interaction", True)
     sd = {k: v.detach().clone().cuda() for k, v in state.items()}
-    for k in sd:
-        if k.startswith(("convOne.", "convAvgRest.")) and k.endswith("layers.0.weight"):
-            sd[k] = sd[k].to(torch.bfloat16).float()
-    tail_names = [k for k, _ in m._param_items if not k.startswith("backbone.") and k not in m._no_grad_names()]
+    skip = ("backbone.", "convOne.0.layers.0", "convOne.1.layers.0", "convOne.2.layers.0", "convAvgRest.0.layers.0",
+            "convAvgRest.1.layers.0", "convAvgRest.2.layers.0")
+    tail_names = [k for k, _ in m._param_items if not k.startswith(skip) and k not in m._no_grad_names()]
     for k in tail_names:
         sd[k].requires_grad_(True)
-    f = [net.tensor("backbone.{m}.layer4.2.conv3.a").view(3, B, 16, 8, 2048)[mod].float().permute(0, 3, 1, 2).contiguous()
-         .requires_grad_(True) for mod in range(3)]
-    oflags = dict(interaction=flags.get("interaction", True), attention=flags.get("attention", True),
-                  using_rem=flags.get("using_REM", True))
-    out = om.tail(sd, f, True, "margin", **oflags)
+    nchw = lambda t: t.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    f = [nchw(net.tensor("backbone.{m}.layer4.2.conv3.a").view(3, B, 16, 8, 2048)[mod]) for mod in range(3)]
+    conv_out, leaves = None, list(f)
+    if inter:
+        conv_out = {"one": [nchw(net.tensor("convOne.{m}.layers.0.y").view(3, B, 16, 8, 2048)[mod]) for mod in range(3)],
+                    "rest": [nchw(net.tensor("convAvgRest.{m}.layers.0.y").view(3, B, 16, 8, 2048)[mod]) for mod in range(3)]}
+        leaves += conv_out["one"] + conv_out["rest"]
+    oflags = dict(interaction=inter, attention=flags.get("attention", True), using_rem=flags.get("using_REM", True))
+    out = om.tail(sd, f, True, "margin", conv_out=conv_out, **oflags)
     loss, summ = om.losses(out, pids.cuda(), C, margin=1.0)
-    grads = torch.autograd.grad(loss, f + [sd[k] for k in tail_names], allow_unused=True)
+    grads = torch.autograd.grad(loss, leaves + [sd[k] for k in tail_names], allow_unused=True)
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
     cos = lambda a, b: float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()).clamp_min(1e-300))
-    res = {"loss": (float(s["loss"]), float(loss))}
-    dF = net.tap("backbone.{m}.layer4.2.conv3.dout").view(3, B, 16, 8, 2048).float()
-    res["dF"] = [(rel(dF[mod], grads[mod].permute(0, 2, 3, 1)), cos(dF[mod], grads[mod].permute(0, 2, 3, 1))) for mod in range(3)]
-    res["params"] = {}
-    for k, g in zip(tail_names, grads[3:]):
+    res = {"loss": (float(s["loss"]), float(loss.detach())), "maps": {}, "params": {}}
+    nhwc = lambda g: g.permute(0, 2, 3, 1)
+    if inter:
+        # behind the CIM the trunk map only feeds the global pooling (reduce_layer on the pooled vector): dGp / (16 * 8) at
+        # every position -- what ieee_cim_bwd_combine adds to the two conv dgrads; the conv-output gradients are the taps
+        dGp = net.tensor("dGp").view(3, B, 2048).float()
+        for mod in range(3):
+            if grads[mod] is None:       # REM off: nothing reads the global vector, the native side hands the trunk zeros for it
+                assert float(dGp[mod].abs().max()) == 0.0
+            else:
+                res["maps"]["dGp[%d]" % mod] = (rel(dGp[mod] / 128.0, nhwc(grads[mod])[:, 0, 0, :]),
+                                                cos(dGp[mod], nhwc(grads[mod])[:, 0, 0, :]))
+            for j, unit in enumerate(("convOne.{m}.layers.0", "convAvgRest.{m}.layers.0")):
+                mine = net.tap(unit + ".dy").view(3, B, 16, 8, 2048)[mod].float()
+                want = nhwc(grads[3 + 3 * j + mod])
+                res["maps"]["%s[%d].dy" % (unit.split(".")[0], mod)] = (rel(mine, want), cos(mine, want))
+    else:
+        dF = net.tap("backbone.{m}.layer4.2.conv3.dout").view(3, B, 16, 8, 2048).float()
+        for mod in range(3):
+            res["maps"]["dF[%d]" % mod] = (rel(dF[mod], nhwc(grads[mod])), cos(dF[mod], nhwc(grads[mod])))
+    for k, g in zip(tail_names, grads[len(leaves):]):
         if g is None or ".conv_query." in k:
             continue
         off, n = m._offsets[k], sd[k].numel()
         mine = m._flat_grads[off:off + n].view(sd[k].shape)
-        if float(g.abs().max()) < 1e-12:      # e.g. a bias in front of a train-mode BatchNorm: zero on both sides
-            assert float(mine.abs().max()) < 1e-5, k
+        if float(g.abs().max()) < 1e-6:      # a bias in front of a train-mode BatchNorm: rounding noise on both sides
+            assert float(mine.abs().max()) < 1e-4, k
             continue
         res["params"][k] = (rel(mine, g), cos(mine, g))
     del net, eng, m
@@ -131,14 +155,13 @@ def test_bf16_ablation_leg_tail_gradients_and_short_trajectory(leg):
     st = tamed_state(C)
     res = _tail_check(st, C, flags)
     worst = sorted(res["params"].items(), key=lambda kv: -kv[1][0])[:4]
-    print("%s: native loss %.4f / torch tail on the native trunk maps %.4f; d(trunk output) rel / cos per modality %s; "
-          "%d tail parameter gradients, worst %s" % (leg, res["loss"][0], res["loss"][1], res["dF"], len(res["params"]), worst))
+    print("%s: native loss %.4f / torch tail on the native maps %.4f; map gradients (rel, cos) %s; %d tail parameter "
+          "gradients, worst %s" % (leg, res["loss"][0], res["loss"][1], res["maps"], len(res["params"]), worst))
     assert abs(res["loss"][0] - res["loss"][1]) < 2e-3 * abs(res["loss"][1])
-    for r, c in res["dF"]:
-        assert r < 3e-2 and c > 0.9995, res["dF"]
-    for k, (r, c) in res["params"].items():
-        assert r < 3e-2 and c > 0.9995, (k, r, c)
-    assert len(res["params"]) >= 100
+    # measured: 2.3e-3 on the maps (one bf16 rounding of the stored gradient), 3.3e-3 on the worst parameter gradient
+    for k, (r, c) in list(res["maps"].items()) + list(res["params"].items()):
+        assert r < 1e-2 and c > 0.9999, (k, r, c)
+    assert len(res["params"]) >= 100 and len(res["maps"]) >= 3
     kw = dict(C=C, flags=flags, n_ids=8, per_id=8, ids_per_batch=8, k=4, epochs=2, batches_per_epoch=10, milestones=(1,),
               eval_noise=0.5)
     ref = run_training(torch.float32, st, **kw)

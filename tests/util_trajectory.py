@@ -33,16 +33,18 @@ def epoch_batches(xs, pids, cams, n_ids, per_id, ids_per_batch, k, batches, rs):
     return out
 
 
-def eval_loaders(n_ids, seed, noise, bs=8):
-    """query: one triple per identity from camera 0; gallery: three per identity from cameras 1..3"""
+def eval_loaders(n_ids, seed, noise, bs=16, q_per_id=6, g_per_id=8):
+    """query: q_per_id triples per identity from camera 0; gallery: g_per_id per identity from cameras 1..4 (the evaluator
+    drops same-identity-same-camera pairs, so every query has g_per_id true matches)"""
     def loader(pids, cams, sd):
         xs = [torch.from_numpy(x) for x in detgen.generate_identity_images(pids, cams, sd, noise=noise)]
         return [{"img": [x[i:i + bs] for x in xs], "pid": torch.as_tensor(pids[i:i + bs]),
                  "camid": torch.as_tensor(cams[i:i + bs]), "impath": "", "timeid": torch.zeros(len(pids[i:i + bs]))}
                 for i in range(0, len(pids), bs)]
-    q_p, q_c = list(range(n_ids)), [0] * n_ids
-    g_p = [i for i in range(n_ids) for _ in range(3)]
-    g_c = [1 + j for _ in range(n_ids) for j in range(3)]
+    q_p = [i for i in range(n_ids) for _ in range(q_per_id)]
+    q_c = [0] * len(q_p)
+    g_p = [i for i in range(n_ids) for _ in range(g_per_id)]
+    g_c = [1 + j % 4 for _ in range(n_ids) for j in range(g_per_id)]
     return {"query": loader(q_p, q_c, seed + 1), "gallery": loader(g_p, g_c, seed + 2)}
 
 
