@@ -183,7 +183,11 @@ class DeviceLoader(object):
         cuda = torch.cuda.is_available()
         dev = torch.cuda.current_device() if cuda else None
         # high priority: the copy + transform of a batch is ~0.1 ms of GPU work that must not queue behind a 15 ms step
-        side = torch.cuda.Stream(device=dev, priority=-1) if cuda else None
+        # (one stream per loader, kept across epochs: stream churn in the middle of training re-shuffles the runtime's
+        # hardware-queue assignment, DESIGN.md round-4 log)
+        if cuda and getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=dev, priority=-1)
+        side = self._side_stream if cuda else None
         box = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
 
@@ -233,7 +237,7 @@ class DeviceLoader(object):
                 if ev is not None:
                     cur = torch.cuda.current_stream()
                     cur.wait_event(ev)                    # the consumer's stream, not the host, waits for the transform
-                    for t in batch['img']:
+                    for t in list(batch['img']) + [batch.get('pid_dev')]:
                         if torch.is_tensor(t) and t.is_cuda:
                             t.record_stream(cur)          # allocated on the side stream, used (and later freed) on this one
                 yield batch
@@ -249,8 +253,8 @@ class DeviceLoader(object):
         for k, batch in enumerate(self.loader):
             raw = batch['img']
             if raw is None:                                          # ring path: the images sit in the pinned ring slot
-                rows = int(batch.pop('rows'))
-                raw = [self.ring[int(batch.pop('slot')), m, :rows] for m in range(self.ring.shape[1])]
+                rows, slot = int(batch.pop('rows')), int(batch.pop('slot'))
+                raw = [self.ring[slot, m, :rows] for m in range(self.ring.shape[1])]
             elif 'slot' in batch:                                    # ring path, odd-sized batch: the list travelled
                 batch.pop('slot'), batch.pop('rows')
             stacked = bool(raw) and torch.is_tensor(raw[0])          # [modality] -> [B, H, W, 3] (see _collate)
@@ -266,6 +270,11 @@ class DeviceLoader(object):
                 flips = self.transform.draw_flips(n * mods).reshape(n, mods)
             batch['img'] = [self.transform(raw[m] if stacked else [raw[i][m] for i in range(n)], flips=flips[:, m])
                             for m in range(mods)]
+            if torch.cuda.is_available() and torch.is_tensor(batch['img'][0]) and batch['img'][0].is_cuda:
+                # the identity labels follow the images to the device on the same stream (pinned, asynchronous): the engine's
+                # own `pids.cuda()` is a blocking copy from pageable memory -- it drains the launch stream every step and the
+                # host can no longer enqueue step k + 1 while step k runs (4 ms per step at B = 64, scripts/loader_probe.py)
+                batch['pid_dev'] = batch['pid'].pin_memory().to(batch['img'][0].device, non_blocking=True)
             if self._owned is not None:
                 batch['batch_index'] = self._owned[k]
             if self.global_rows is not None:

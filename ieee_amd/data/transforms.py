@@ -93,9 +93,24 @@ class DeviceTransform(object):
             self._dev_tables[key] = (t, up(t["bounds_h"]), up(t["kk_h"]), up(t["bounds_v"]), up(t["kk_v"]))
         return self._dev_tables[key]
 
+    _vector_draw_ok = None     # does torch.rand(n) consume the generator like n x torch.rand(1) on this build?  (checked once)
+
     def draw_flips(self, n):
+        """one torch.rand(1) < 0.5 per image, in call order (torchvision's RandomHorizontalFlip inside the reference's per-image
+        Compose).  Drawn as ONE torch.rand(n) when this torch build produces the same numbers that way (checked once on a
+        saved generator state): 192 interpreter round trips per batch otherwise, under the lock the train step needs too."""
         if not self.flip:
             return np.zeros(n, dtype=np.uint8)
+        cls = DeviceTransform
+        if cls._vector_draw_ok is None:
+            state = torch.get_rng_state()
+            a = torch.rand(37)
+            torch.set_rng_state(state)
+            b = torch.cat([torch.rand(1) for _ in range(37)])
+            torch.set_rng_state(state)
+            cls._vector_draw_ok = bool(torch.equal(a, b))
+        if cls._vector_draw_ok and n > 0:
+            return (torch.rand(n) < 0.5).to(torch.uint8).numpy()
         return np.asarray([1 if float(torch.rand(1)) < 0.5 else 0 for _ in range(n)], dtype=np.uint8)
 
     def __call__(self, images, flips=None):

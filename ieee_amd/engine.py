@@ -515,10 +515,12 @@ class _FusedStepMixin(object):
             if p.grad is not None:
                 torch.distributed.all_reduce(p.grad, op=torch.distributed.ReduceOp.SUM)
 
-    def _to_device(self, imgs, pids):
+    def _to_device(self, imgs, pids, pids_dev=None):
+        """pids_dev: the labels already on the device (ieee_amd.data.DeviceLoader stamps `pid_dev` on its batches): a
+        `pids.cuda()` from pageable memory blocks the host until the launch stream has drained"""
         if self.use_gpu:
             imgs = [im.cuda(non_blocking=True) for im in imgs]
-            pids = pids.cuda()
+            pids = pids_dev if pids_dev is not None else pids.cuda()
         return imgs, pids
 
 
@@ -542,7 +544,7 @@ class Image3MEngine(_FusedStepMixin, Engine):
         data, total_rows = self._local_batch(data)
         imgs, pids, timeids = self.parse_data_for_train(data)
         self._guard_chunks(pids, self.weight_m)
-        imgs, pids = self._to_device(imgs, pids)
+        imgs, pids = self._to_device(imgs, pids, data.get('pid_dev') if isinstance(data, dict) else None)
         if self._fused_ok():
             small, out3 = self._fused_step(imgs, pids, self.weight_x, self.weight_m, self.margin, self.criterion_x.eps,
                                            total_rows)
@@ -589,7 +591,7 @@ class MultiModalImageSoftmaxEngine(_FusedStepMixin, Engine):
         self._sync_replicas_once()
         data, total_rows = self._local_batch(data)
         imgs, pids, timeids = self.parse_data_for_train(data)
-        imgs, pids = self._to_device(imgs, pids)
+        imgs, pids = self._to_device(imgs, pids, data.get('pid_dev') if isinstance(data, dict) else None)
         if self._fused_ok():
             small, _ = self._fused_step(imgs, pids, 1.0, 0.0, 0.0, self.criterion.eps, total_rows)
             return self._summary_from(small, lambda lR, lN, lT, aR, aN, aT, lm: (lR + lN + lT, lR, aR, lN, aN, lT, aT),

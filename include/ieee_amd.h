@@ -485,14 +485,17 @@ int ieee_net_set_frozen(void* handle, int mask);
  * running statistics may have changed outside ieee_net_forward(training = 1) (optimizer steps, state loading, ...). */
 int ieee_net_eval_cache(void* handle, int keep);
 /* measurement: enable=1 starts recording a HIP event pair around every conv launch of subsequent forward/backward
- * calls with ALL work on one ordered stream (the serialized pass: what each launch takes alone); enable=2 records the
- * same pairs with the executor's own streams left on -- forward / dgrad pairs on the launch stream, weight-gradient
- * pairs on the side stream they run on: what a launch takes INSIDE the two-stream step, beside the other stream's
- * kernels (every pair adds two barrier packets to its queue, so a step measured this way is a little slower than a
- * plain one); enable=0 stops, synchronises the device and returns
+ * calls with ALL work on one ordered stream (the serialized pass: what each launch takes alone); enable=2 times the
+ * launches with the executor's own streams left on -- every forward / dgrad launch carries its pair as its own start /
+ * stop signals (ieee_conv_profile_events: nothing added to the queue), weight-gradient calls get an event record on each
+ * side, on the side stream they run on: what a launch takes INSIDE the two-stream step; enable=0 stops, synchronises the device and returns
  * out6 = {ms, algorithmic FLOPs, launches} for [0] forward+dgrad (conv_gather / conv3x3_patch / stem_conv kernels) and
  * [1] wgrad (conv_wgrad / conv3x3_wgrad_patch / stem_wgrad kernels + their slab reductions) */
 int ieee_net_profile(void* handle, int enable, double* out6);
+/* measurement: the next conv forward / dgrad launch issued by the calling thread signals `start` when it begins and `stop`
+ * when it ends (hipEvent_t with timing enabled; NULL, NULL cancels): the kernel's own duration by the GPU's timestamps,
+ * without an event record in the queue.  ieee_net_profile(.., 2, ..) times the forward / dgrad family this way. */
+int ieee_conv_profile_events(void* start, void* stop);
 /* debugging / parity tests: location of a named intermediate inside the workspace */
 int ieee_net_tensor(void* handle, const char* name, int64_t* byte_offset, int64_t* numel, int* dtype);
 /* parity tests of the backward (what autograd keeps implicit in the reference, ieee3modalPart.py:439-523 under

@@ -8,7 +8,7 @@ find $O/trace -name "*_kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_
 find $O/trace -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $O/kernel_trace_in_situ.csv
 python - <<PY
 import json, subprocess
-line = json.loads(open("$O/trace.log").read().strip().splitlines()[-1])
+line = json.loads([l for l in open("$O/trace.log").read().splitlines() if l.startswith("{")][-1])
 B = 64
 meta = {"steps_in_trace": $STEPS + $WARM, "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps $STEPS --warmup $WARM --no-roofline-pass --no-cpu-baseline --no-distmat --no-fp32 --no-dp-path --no-loader",
         "build": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "worktree",
