@@ -2,7 +2,10 @@
 process with workers=0, configs/RGBNT_ieee_part_margin.yaml:13); the decoded bytes are resized / flipped / normalised on
 the GPU per batch.  Yields the reference's batch dict: {'img': [RGB, NI, TI] float tensors [B,3,H,W] (on the device),
 'pid', 'camid', 'impath', 'timeid'} (data/datasets/dataset.py:344-351)."""
+import multiprocessing
+import os
 import queue
+import sys
 import threading
 
 import numpy as np
@@ -12,6 +15,32 @@ from torch.utils.data import DataLoader
 from .datasets import MultiModalImageDataset
 from .sampler import build_train_sampler
 from .transforms import build_transforms
+
+
+def _worker_context(workers):
+    """How the decode workers are started.  NOT by fork() from the training process when it can be avoided: forking a process
+    that holds a live HIP context write-protects its page tables, the driver's MMU notifiers evict and re-validate the
+    process's GPU-visible host memory, and its queues stand still meanwhile -- measured on the MI355X box
+    (scripts/small_copy_probe.py): with a forked child alive the next 5 train steps take 364 ms each instead of 14.7, the
+    next twenty 1 KB host->device copies 78 ms each; a loader lifecycle that costs 0.3 s in a fresh process costs 10-15 s after
+    a train step has run in it.  A fork server (started through vfork + exec, preloaded with torch) hands out workers that
+    share nothing with the training process but the shared-memory ring.  It needs what every `spawn` start needs -- a
+    `__main__` that can be imported again without side effects (`if __name__ == "__main__":`, as scripts/mainMultiModal.py
+    has) -- so an interactive / stdin `__main__` falls back to fork.  IEEE_LOADER_START = fork | forkserver | spawn overrides."""
+    if workers <= 0:
+        return None
+    want = os.environ.get("IEEE_LOADER_START", "").lower()
+    if want not in ("fork", "forkserver", "spawn"):
+        main = sys.modules.get("__main__")
+        path = getattr(main, "__file__", None)
+        importable = getattr(main, "__spec__", None) is not None or (path is not None and os.path.isfile(path))
+        want = "forkserver" if importable else "fork"
+    if want == "forkserver":
+        try:
+            multiprocessing.set_forkserver_preload(["torch", "numpy", "PIL.Image", "ieee_amd.data.datasets"])
+        except Exception:
+            pass
+    return multiprocessing.get_context(want)
 
 
 def _collate(items):
@@ -40,13 +69,18 @@ class _SlotDataset(torch.utils.data.Dataset):
 
     def __init__(self, base, ring):
         self.base, self.ring = base, ring
-        self.view = ring.numpy()               # shares the mapping
+        self.view = None                       # numpy view of the shared mapping, made in the worker
+
+    def __getstate__(self):                    # (a numpy view would be pickled by value: the worker makes its own)
+        return {"base": self.base, "ring": self.ring, "view": None}
 
     def __len__(self):
         return len(self.base)
 
     def __getitem__(self, key):
         slot, indices = key
+        if self.view is None:
+            self.view = self.ring.numpy()
         items = [self.base[i] for i in indices]
         mods, (H, W) = self.view.shape[1], self.view.shape[3:5]
         fits = len(items) <= self.view.shape[2] and all(len(it['img']) == mods and all(im.shape == (H, W, 3) for im in it['img'])
@@ -110,12 +144,14 @@ class DeviceLoader(object):
                 self._all.pop()
             self._owned = list(range(self.rank, len(self._all), self.world))
             self.loader = DataLoader(self.dataset, batch_sampler=[self._all[b] for b in self._owned], num_workers=workers,
-                                     collate_fn=_collate, pin_memory=self._pin(), persistent_workers=workers > 0)
+                                     collate_fn=_collate, pin_memory=self._pin(), persistent_workers=workers > 0,
+                                     multiprocessing_context=_worker_context(workers))
         elif self.prefetch > 0 and workers > 0 and torch.cuda.is_available() and self._make_ring(sampler, shuffle, drop_last, workers):
             pass                                                         # self.loader / self.ring set by _make_ring
         else:
             self.loader = DataLoader(self.dataset, batch_size=batch_size, sampler=sampler, shuffle=shuffle and sampler is None,
                                      num_workers=workers, collate_fn=_collate, drop_last=drop_last, pin_memory=self._pin(),
+                                     multiprocessing_context=_worker_context(workers),
                                      persistent_workers=workers > 0)     # (an epoch of RGBNT201 is a few hundred batches:
                                      # respawning W processes that import torch at every epoch costs seconds)
 
@@ -144,7 +180,8 @@ class DeviceLoader(object):
         batches = torch.utils.data.BatchSampler(base, self.batch_size, drop_last)
         self._slot_sampler = _SlotSampler(batches, slots)
         self.loader = DataLoader(_SlotDataset(self.dataset, ring), batch_size=None, sampler=self._slot_sampler, num_workers=workers,
-                                 collate_fn=_identity, pin_memory=False, persistent_workers=True)
+                                 collate_fn=_identity, pin_memory=False, persistent_workers=True,
+                                 multiprocessing_context=_worker_context(workers))
         self.loader_base_sampler = base
         return True
 

@@ -21,7 +21,7 @@ import sys
 FAMILIES = (
     ("conv_patch", "conv3x3_patch_kernel"), ("conv_wgrad_patch", "conv3x3_wgrad_patch_kernel"), ("stem_fwd", "stem_conv_kernel"),
     ("stem_wgrad", "stem_wgrad_kernel"), ("conv_gather", "conv_gather_kernel"), ("conv_wgrad", "conv_wgrad_kernel"), ("wgrad_reduce", "wgrad_reduce_kernel"),
-    ("bn_apply", "bn_apply_kernel"), ("bn_bwd_apply", "bn_bwd_apply_kernel"), ("bn_bwd_reduce", "bn_bwd_reduce_kernel"),
+    ("bn_bwd_apply", "bn_bwd_apply"), ("bn_apply", "bn_apply"), ("bn_bwd_reduce", "bn_bwd_reduce_kernel"),
     ("bn_finalize", "bn_finalize_kernel"), ("bn_finalize", "bn_bwd_finalize_kernel"), ("distmat_f16split", "distmat_kernel<bool _Accum"),
     ("distmat_f16split", "distmat_kernelIDF16bLb1"), ("distmat_bf16", "distmat_kernelIDF16b"), ("distmat_fp32", "distmat_kernel<float"),
     ("distmat_fp32", "distmat_kernelIf"), ("distmat", "distmat_kernel"),

@@ -230,3 +230,38 @@ def test_eval_cache_follows_parameter_changes():
     with torch.no_grad():
         f5 = m(x).clone()
     assert not torch.equal(f5, f4) and torch.equal(f5, fresh_reference())
+
+
+def test_profile_passes_time_the_launches_without_changing_the_step():
+    """ieee_net_profile: mode 2 (every forward / dgrad launch carries an event pair as its own start / stop signals, the
+    executor's streams stay on) and mode 1 (event records around every launch on ONE ordered stream) both report the 109
+    forward + dgrad and the 55 weight-gradient launches of a step with positive durations and the algorithmic FLOPs of the
+    net, and a profiled step leaves bit-identical parameters (bench.py's roofline passes rest on both)"""
+    import ctypes
+    from ieee_amd import _lib
+    B = 8
+    data = batch(B, 5)
+    finals, reports = [], {}
+    for mode in (0, 2, 1):
+        eng, m, _ = make(5, dtype=torch.bfloat16)
+        eng.forward_backward(data)                      # (first step: stream / workspace set-up, self-check)
+        net = m.native_net(B, 256, 128)
+        lib = _lib.load()
+        if mode:
+            _lib.check(lib.ieee_net_profile(net.handle, mode, None))
+        s = eng.forward_backward(data)
+        if mode:
+            out = (ctypes.c_double * 6)()
+            _lib.check(lib.ieee_net_profile(net.handle, 0, out))
+            reports[mode] = list(out)
+        torch.cuda.synchronize()
+        finals.append((float(s["loss"]), m._flat_params.clone()))
+        del eng, m, net
+        torch.cuda.empty_cache()
+    for mode, (g_ms, g_fl, g_n, w_ms, w_fl, w_n) in reports.items():
+        assert (g_n, w_n) == (109, 55), (mode, g_n, w_n)
+        assert 0.01 < g_ms < 50 and 0.01 < w_ms < 50, (mode, g_ms, w_ms)
+        # 61.06 / 30.76 GFLOP per triple (forward + dgrad without the stems' dgrad; weight gradients)
+        assert abs(g_fl / B / 61.0617e9 - 1) < 1e-3 and abs(w_fl / B / 30.762e9 - 1) < 1e-3, (mode, g_fl, w_fl)
+    assert finals[0][0] == finals[1][0] == finals[2][0]
+    assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][1], finals[2][1])
