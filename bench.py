@@ -413,7 +413,8 @@ def main():
             traffic, traffic_src = committed_traffic("conv_gather")
     stats_line = committed_kernel_stats(TRAIN_GFLOP_PER_TRIPLE) if args.dtype == "bf16" and B == 64 else None
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "measured": "in situ: HIP event pairs around every launch of the family inside the two-stream step",
+                "measured": "in situ: every launch of the family carries a HIP event pair as its own start / stop signals "
+                            "(hipExtLaunchKernelGGL) inside the two-stream step; nothing is added to the queues",
                 "in_situ_frac": ach / peak, "serialized_achieved": ser, "serialized_frac": ser / peak,
                 "serialized_avg_launch_us": sg_ms * 1e3 / max(sg_n, 1),
                 "in_situ_from_committed_rocprof_stats": stats_line,
@@ -498,6 +499,16 @@ def main():
     if dp_path is not None:
         line["dp_path"] = dp_path
     if rank == 0:
+        if world == 1 and not args.no_loader and args.dtype == "bf16":
+            # input pipeline at step rate: JPEG tree -> worker decode -> device transform -> real steps,
+            # with THIS engine (the timed one), before the CPU-baseline leg fills the process with OpenMP threads
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import loader_probe
+                line["loader"] = loader_probe.measure(tuple(int(w) for w in args.loader_workers.split(",")), steps=30, B=B,
+                                                      device=device, engine=engine)
+            except Exception as e:      # informative leg: never costs the headline line
+                line["loader"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train()
         if world == 1 and (not args.no_distmat or not args.no_fp32):
@@ -524,16 +535,6 @@ def main():
                                         "whole_step_frac_of_fp32_mfma_peak": B / d32 * TRAIN_GFLOP_PER_TRIPLE * 1e9 /
                                         (PEAK_F32_TFLOPS * 1e12)}
             del e32, m32
-            torch.cuda.empty_cache()
-        if world == 1 and not args.no_loader and args.dtype == "bf16":
-            # input pipeline at step rate: JPEG tree -> worker decode -> device transform -> real steps
-            try:
-                sys.path.insert(0, os.path.join(ROOT, "scripts"))
-                import loader_probe
-                line["loader"] = loader_probe.measure(tuple(int(w) for w in args.loader_workers.split(",")), steps=30, B=B,
-                                                      device=device)
-            except Exception as e:      # informative leg: never costs the headline line
-                line["loader"] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
         if world == 1 and not args.no_distmat:
             line["distmat"] = bench_distmat(device)
