@@ -505,7 +505,7 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "scripts"))
                 import loader_probe
-                line["loader"] = loader_probe.measure(tuple(int(w) for w in args.loader_workers.split(",")), steps=30, B=B,
+                line["loader"] = loader_probe.measure(tuple(int(w) for w in args.loader_workers.split(",")), steps=40, B=B,
                                                       device=device, engine=engine)
             except Exception as e:      # informative leg: never costs the headline line
                 line["loader"] = {"error": "%s: %s" % (type(e).__name__, e)}

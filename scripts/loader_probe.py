@@ -84,6 +84,10 @@ def measure(workers=(4, 8, 16, 32), steps=40, warm=8, B=64, size=(256, 128), eng
                        "where": root.split("/")[1]}
         with contextlib.redirect_stdout(io.StringIO()):
             ds = RGBNT201(root=root)
+        # every file four times under four identity ranges: an epoch of 32 batches instead of 8 without a larger tree (RGBNT201's
+        # own epoch is ~60 batches of 64; at every epoch boundary the pipeline drains and refills)
+        n_ids = len({r[1] for r in ds.train})
+        ds.train = [(r[0], r[1] + n_ids * k, r[2], r[3]) for k in range(4) for r in ds.train]
         eng = engine or build_engine(B, device)
         # the train step alone on a resident batch of the same shape: what the loader has to keep up with
         g = torch.Generator().manual_seed(0)
