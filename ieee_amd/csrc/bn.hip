@@ -475,6 +475,163 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fixed_kernel(const T* __rest
   }
 }
 
+// ---- BatchNorm passes that take their statistics from fixed-point TOTALS (conv.hip: tl_totals) and derive the per-channel
+// coefficients in their own prologue: no finalize launch.  Every workgroup runs the prologue -- the same arithmetic on the
+// same integers, so the same bits -- and workgroup 0 publishes what later kernels read (stats, running statistics,
+// d(gamma), d(beta)).  What the prologue may cost decides whether the path pays (B = 64 step, layer3 + layer4 on it):
+//   every thread converts its own 8 channels, 1.0 / sqrt and / M in double, stores inside the channel loop   19.8 ms
+//   no double division / square root (E[y^2] - mean^2 stays in double, the reciprocal square root is float)  19.8 ms
+//   all loads issued before the first store of the publishing threads (the compiler kept eight load -> wait
+//   -> store rounds in order; a 20 us pass took 140 us)                                                       15.4 ms
+//   one channel per thread through LDS (an eighth of the int64 -> double conversions), at most 1 024
+//   workgroups per modality so that a thread walks >= 4 chunks behind one prologue                            14.69 ms
+// against 14.83 ms with the finalize launches.
+template <int VEC> __device__ __forceinline__ void load_totals(const long long* __restrict__ p, long long* dst) {
+#pragma unroll
+  for (int e = 0; e < VEC; e += 2) {
+    const int4 v = *(const int4*)(p + e);
+    dst[e] = (long long)(((unsigned long long)(unsigned)v.y << 32) | (unsigned)v.x);
+    dst[e + 1] = (long long)(((unsigned long long)(unsigned)v.w << 32) | (unsigned)v.z);
+  }
+}
+constexpr double TOT_INV_FWD = 1.0 / 16777216.0;          // 2^-24
+constexpr double TOT_INV_BWD = 1.0 / 1099511627776.0;     // 2^-40
+
+template <typename T, bool RES, bool BITS>
+__global__ __launch_bounds__(256) void bn_apply_totals_kernel(const T* __restrict__ y, const T* __restrict__ residual,
+                                                              T* __restrict__ out, const long long* __restrict__ totals,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int64_t param_gs, float* running_mean, float* running_var,
+                                                              int64_t buf_gs, float* __restrict__ stats, int M, float momentum,
+                                                              float eps, int64_t total_chunks, int cprw, int C, int64_t gs,
+                                                              int relu, uint8_t* __restrict__ relu_bits, double inv_m,
+                                                              float unbias) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  uint8_t* bb = BITS ? relu_bits + z * (gs / 8) : nullptr;
+  const int c0 = (threadIdx.x & (cprw - 1)) * VEC;
+  const long long* tt = totals + (int64_t)z * 2 * C + c0;
+  const bool publish = blockIdx.x == 0 && threadIdx.x < cprw;
+  // one channel per thread (C / 256 rounds), through LDS: an eighth of the conversions of "every thread its 8 channels"
+  extern __shared__ float tot_lds[];
+  float* s_sc = tot_lds;
+  float* s_sh = tot_lds + C;
+  (void)tt; (void)publish;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const long long t1 = totals[(int64_t)z * 2 * C + c], t2 = totals[(int64_t)z * 2 * C + C + c];
+    const float ga = gamma[z * param_gs + c], be = beta[z * param_gs + c];
+    const double mu = (double)t1 * inv_m;                    // inv_m = 2^-24 / M
+    double var = (double)t2 * inv_m - mu * mu;
+    if (var < 0) var = 0;
+    const float mean = (float)mu, varf = (float)var, invstd = rsqrtf(varf + eps);
+    const float scv = ga * invstd, shv = be - mean * scv;
+    s_sc[c] = scv; s_sh[c] = shv;
+    if (blockIdx.x == 0) {
+      float* st = stats + (int64_t)z * 4 * C;
+      st[c] = mean; st[C + c] = invstd; st[2 * C + c] = scv; st[3 * C + c] = shv;
+      if (running_mean != nullptr) {
+        float* rm = running_mean + z * buf_gs + c;
+        float* rv = running_var + z * buf_gs + c;
+        *rm = (1.f - momentum) * *rm + momentum * mean;
+        *rv = (1.f - momentum) * *rv + momentum * (varf * unbias);             // unbias = M / (M - 1)
+      }
+    }
+  }
+  __syncthreads();
+  float sc[VEC], sh[VEC];
+  load_floats<VEC>(s_sc + c0, sc);
+  load_floats<VEC>(s_sh + c0, sh);
+  if (out == nullptr) return;
+  const T* yy = y + z * gs;
+  const T* rr = RES ? residual + z * gs : nullptr;
+  T* oo = out + z * gs;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += stride) {
+    float v[VEC], r[VEC];
+    Vec16<T>::unpack(*(const uint4*)(yy + i * VEC), v);
+    if (RES) Vec16<T>::unpack(*(const uint4*)(rr + i * VEC), r);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float x = v[e] * sc[e] + sh[e];
+      if (RES) x += r[e];
+      if (relu) x = fmaxf(x, 0.f);
+      v[e] = x;
+    }
+    const uint4 pv = Vec16<T>::pack(v);
+    *(uint4*)(oo + i * VEC) = pv;
+    if constexpr (BITS && VEC == 8) {
+      Vec16<T>::unpack(pv, v);
+      unsigned b = 0;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
+      bb[i] = (uint8_t)b;
+    }
+  }
+}
+
+// backward: totals = sum g, sum g*y (2^40 fixed point); MASK as in bn_bwd_apply_fixed_kernel
+template <typename T, int MASK, bool GOUT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_totals_kernel(const T* __restrict__ da, const T* __restrict__ a,
+                                                                  const T* __restrict__ y, T* __restrict__ dy,
+                                                                  T* __restrict__ gout, const long long* __restrict__ totals,
+                                                                  const float* __restrict__ gamma, int64_t param_gs,
+                                                                  const float* __restrict__ stats, float* dgamma,
+                                                                  float* dbeta, int64_t grad_gs, int M, int64_t total_chunks,
+                                                                  int cprw, int C, int64_t gs, double inv_m) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  const int c0 = (threadIdx.x & (cprw - 1)) * VEC;
+  const long long* tt = totals + (int64_t)z * 2 * C + c0;
+  const float* st = stats + (int64_t)z * 4 * C;
+  const bool publish = blockIdx.x == 0 && threadIdx.x < cprw;
+  extern __shared__ float tot_lds[];
+  float* s_k = tot_lds;                                      // [3][C]
+  (void)tt; (void)publish;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double s1 = (double)totals[(int64_t)z * 2 * C + c] * TOT_INV_BWD, s2 = (double)totals[(int64_t)z * 2 * C + C + c] * TOT_INV_BWD;
+    const double mean = st[c], invstd = st[C + c];
+    const double sgx = invstd * (s2 - mean * s1);            // sum g * xhat
+    const double A = (double)gamma[z * param_gs + c] * invstd;
+    const double c1 = s1 * inv_m, c2 = sgx * inv_m;          // inv_m = 1 / M
+    s_k[c] = (float)A;
+    s_k[C + c] = (float)(-A * invstd * c2);
+    s_k[2 * C + c] = (float)(-A * c1 + A * invstd * c2 * mean);
+    if (blockIdx.x == 0 && dgamma != nullptr) {
+      dgamma[z * grad_gs + c] = (float)sgx;
+      dbeta[z * grad_gs + c] = (float)s1;
+    }
+  }
+  __syncthreads();
+  float k1[VEC], k2[VEC], k3[VEC], sc[VEC], sh[VEC];
+  load_floats<VEC>(s_k + c0, k1);
+  load_floats<VEC>(s_k + C + c0, k2);
+  load_floats<VEC>(s_k + 2 * C + c0, k3);
+  if (MASK == 2) { load_floats<VEC>(st + 2 * C + c0, sc); load_floats<VEC>(st + 3 * C + c0, sh); }
+  const T* dd = da + z * gs;
+  const T* aa = MASK == 1 ? a + z * gs : nullptr;
+  const T* yy = y + z * gs;
+  T* oo = dy + z * gs;
+  T* go = GOUT ? gout + z * gs : nullptr;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += stride) {
+    float d[VEC], v[VEC], m[VEC];
+    Vec16<T>::unpack(*(const uint4*)(dd + i * VEC), d);
+    Vec16<T>::unpack(*(const uint4*)(yy + i * VEC), v);
+    if (MASK == 1) {
+      Vec16<T>::unpack(*(const uint4*)(aa + i * VEC), m);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d[e] = m[e] > 0.f ? d[e] : 0.f;
+    } else if (MASK == 2) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d[e] = (v[e] * sc[e] + sh[e]) > 0.f ? d[e] : 0.f;
+    }
+    if (GOUT) *(uint4*)(go + i * VEC) = Vec16<T>::pack(d);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = k1[e] * d[e] + k2[e] * v[e] + k3[e];
+    *(uint4*)(oo + i * VEC) = Vec16<T>::pack(v);
+  }
+}
+
 struct PoolShifts { int pow2, lw, lh, lc, lq; };   // log2 of Wi, Hi, C, chunks per row when all are powers of two
 
 // ---- the stem's backward in two passes: d(out) of its ReLU(BatchNorm(y)) is the backward of MaxPool2d(3,2,1) applied
@@ -674,6 +831,15 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_tiled_kernel(const T* __res
       }
     }
   }
+}
+
+// the totals kernels pay a prologue per workgroup: fewer, longer-lived workgroups than the plain passes
+static int tot_blocks(int64_t chunks) {
+  static const int64_t cap = getenv("IEEE_BN_TOTALS_BLOCKS") ? atoll(getenv("IEEE_BN_TOTALS_BLOCKS")) : 1024;
+  int64_t b = (chunks + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
 }
 
 static int ew_blocks(int64_t chunks) {
@@ -941,6 +1107,69 @@ extern "C" int ieee_bn2d_bwd_frozen(const void* dout, const void* out_mask, cons
   bn_frozen_coef_kernel<<<dim3(cdiv(C, 256), (unsigned)groups), 256, 0, st>>>(stats, 4 * C, coef, 3 * C, (int)C);
   IEEE_TRY(launch_status("bn_frozen_coef_kernel"));
   return launch_bwd_apply(dout, out_mask, y, dy, g_out, dtype, groups, M, C, act_gs, stats, coef, mask_from_y, done_event, st);
+}
+
+/* train-mode BatchNorm2d forward whose statistics arrive as fixed-point totals (ieee_conv_next_bn_totals): finalize + apply
+ * in ONE launch.  out NULL: statistics only (stats / running statistics are still published). */
+extern "C" int ieee_bn2d_fwd_totals(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
+                                    int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
+                                    float* running_mean, float* running_var, int64_t buf_gs, float* stats, const void* totals,
+                                    float momentum, float eps, int relu, void* relu_bits, void* stream) {
+  IEEE_REQUIRE(y && gamma && beta && stats && totals, "bn2d_fwd_totals: null pointer");
+  IEEE_REQUIRE(dtype == IEEE_BF16, "bn2d_fwd_totals: bf16 only (the fused statistics exist on the bf16 path)");
+  const int cprw = (int)(C / 8);
+  IEEE_REQUIRE(C % 8 == 0 && cprw >= 1 && cprw <= 256 && 256 % cprw == 0, "bn2d_fwd_totals: C / 8 must divide 256");
+  IEEE_REQUIRE(!relu_bits || (out && act_gs % 8 == 0), "bn2d_fwd_totals: relu_bits needs an output");
+  IEEE_REQUIRE((((uintptr_t)totals | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && param_gs % 4 == 0,
+               "bn2d_fwd_totals: totals / gamma / beta must be 16-byte aligned (group stride a multiple of 4 floats)");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t chunks = M * C / 8;
+  dim3 grid(out ? tot_blocks(chunks) : 1, (unsigned)groups);
+  const bf16 *yb = (const bf16*)y, *rb = (const bf16*)residual;
+  bf16* ob = (bf16*)out;
+  uint8_t* bits = (uint8_t*)relu_bits;
+#define IEEE_BN_TOT(RES, BITS)                                                                                              \
+  bn_apply_totals_kernel<bf16, RES, BITS><<<grid, 256, 2 * C * sizeof(float), st>>>(yb, rb, ob, (const long long*)totals, gamma, beta, param_gs, \
+      running_mean, running_var, buf_gs, stats, (int)M, momentum, eps, chunks, cprw, (int)C, act_gs, relu, bits,       \
+      TOT_INV_FWD / (double)M, M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f)
+  if (residual && bits) IEEE_BN_TOT(true, true);
+  else if (residual) IEEE_BN_TOT(true, false);
+  else if (bits) IEEE_BN_TOT(false, true);
+  else IEEE_BN_TOT(false, false);
+#undef IEEE_BN_TOT
+  return launch_status("bn_apply_totals_kernel");
+}
+
+/* ... and its backward: totals = sum g, sum g*y from the dgrad epilogue; finalize + apply in ONE launch */
+extern "C" int ieee_bn2d_bwd_totals(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                                    int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma,
+                                    int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
+                                    const void* totals, int mask_from_y, void* done_event, void* stream) {
+  IEEE_REQUIRE(dout && y && dy && gamma && stats && totals, "bn2d_bwd_totals: null pointer");
+  IEEE_REQUIRE(dtype == IEEE_BF16, "bn2d_bwd_totals: bf16 only");
+  const int cprw = (int)(C / 8);
+  IEEE_REQUIRE(C % 8 == 0 && cprw >= 1 && cprw <= 256 && 256 % cprw == 0, "bn2d_bwd_totals: C / 8 must divide 256");
+  IEEE_REQUIRE((((uintptr_t)totals | (uintptr_t)gamma | (uintptr_t)stats) & 15) == 0 && param_gs % 4 == 0,
+               "bn2d_bwd_totals: totals / gamma / stats must be 16-byte aligned (group stride a multiple of 4 floats)");
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t ev = (hipEvent_t)done_event;
+  const int64_t chunks = M * C / 8;
+  dim3 grid(tot_blocks(chunks), (unsigned)groups);
+  const int variant = (out_mask ? 1 : (mask_from_y ? 2 : 0)) * 2 + (g_out ? 1 : 0);
+#define IEEE_BN_BWD_TOT(MASK, GOUT)                                                                                          \
+  case MASK * 2 + (GOUT ? 1 : 0):                                                                                            \
+    hipExtLaunchKernelGGL((bn_bwd_apply_totals_kernel<bf16, MASK, GOUT>), grid, dim3(256), 3 * C * sizeof(float), st,        \
+                          nullptr, ev, 0,                                                                                    \
+                          (const bf16*)dout, (const bf16*)out_mask, (const bf16*)y, (bf16*)dy, (bf16*)g_out,                 \
+                          (const long long*)totals, gamma, param_gs, stats, dgamma, dbeta, grad_gs, (int)M, chunks, cprw,    \
+                          (int)C, act_gs, 1.0 / (double)M);                                                                  \
+    break;
+  switch (variant) {
+    IEEE_BN_BWD_TOT(0, false) IEEE_BN_BWD_TOT(0, true) IEEE_BN_BWD_TOT(1, false) IEEE_BN_BWD_TOT(1, true)
+    IEEE_BN_BWD_TOT(2, false) IEEE_BN_BWD_TOT(2, true)
+  }
+#undef IEEE_BN_BWD_TOT
+  return launch_status("bn_bwd_apply_totals_kernel");
 }
 
 extern "C" int ieee_bn2d_bwd_pooled(const void* dpool, const uint8_t* argmax, const void* y, void* dy, int dtype,

@@ -31,6 +31,7 @@ struct ConvUnit {
   int Ci_src = 0, S_src = 0, R_src = 0;   // dims of the reference parameter when the unit runs zero-padded
   int s_w, s_g, s_b, s_rm, s_rv;   // slot ids of modality 0 (modality m = id + m)
   Tensor y, a, stats, wf, wd, dwpad, slab;
+  Tensor tot_f, tot_b;             // fixed-point totals of the fused BatchNorm sums (forward / backward), [3][2][Co] int64
   Tensor abits;                    // bf16 block outputs: the ReLU mask of `a` as packed bits (bn_apply writes it, the next block's conv1 dgrad reads it)
   bool want_bits = false;
   bool need_dgrad = true;
@@ -98,6 +99,7 @@ struct Net {
   std::vector<ieee_wgrad_reduce_desc> rtab_host[RT_SLOTS];
   const void* rtab_ws[RT_SLOTS] = {};
   ConvUnit reduce_unit;   // profiling label of the batched reductions
+  size_t tot_begin = 0, tot_end = 0;   // the units' totals are one contiguous region: ONE memset per training forward
   Tensor tickets;   // 2 x 256 int32: arrival tickets of the convs that finalize their BatchNorm themselves (launch / branch stream)
   std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
   int pack_blocks_train = 0, pack_blocks_eval = 0;
@@ -108,6 +110,7 @@ struct Net {
   hipEvent_t pack_ev[2] = {nullptr, nullptr};
   const void* pack_uploaded_ws = nullptr;
   bool fused_bwd_state = false;   // survives between the staged ieee_net_backward_part calls
+  bool bwd_totals_state = false;  // ... and: those sums went into the unit's fixed-point totals (tot_b), not into bn_partial
   bool stem_a_valid = false;      // "<stem>.a" holds the activation of the LAST forward (a training forward does not write it)
   // inference: the packed weights and every BatchNorm's scale / shift only depend on the parameters and running
   // statistics; while the caller vouches that those have not changed (ieee_net_eval_cache) consecutive eval forwards
@@ -316,6 +319,13 @@ void Net::plan() {
     max_part = std::max(max_part, 3 * ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) * 2 * u.Co);
     max_c = std::max(max_c, (int64_t)u.Co);
   }
+  tot_begin = ws_bytes;
+  for (size_t i = 0; i < units.size(); ++i) {
+    ConvUnit& u = units[i];
+    u.tot_f = alloc("", (int64_t)3 * 2 * u.Co * 2, IEEE_F32);   // int64 = 2 floats' worth
+    u.tot_b = alloc("", (int64_t)3 * 2 * u.Co * 2, IEEE_F32);
+  }
+  tot_end = ws_bytes;
   const ConvUnit& st = units[u_stem];
   const int ph = (st.Ho + 2 - 3) / 2 + 1, pw = (st.Wo + 2 - 3) / 2 + 1;
   pool = alloc("pool", (int64_t)3 * B * ph * pw * 64, dt);
@@ -458,13 +468,30 @@ struct Run {
   bool fused_stats = false;
   bool fused_fin = false;    // ... and finalized them too (ieee_conv2d_fwd_bn_train): bn() only applies
   bool frz(const ConvUnit& u) const { return (n.frozen & u.child) != 0; }
+  // BatchNorm sums as fixed-point totals (conv.hip: tl_totals) for the units of at most IEEE_BN_TOTALS_TILES row tiles per
+  // modality (default 256: layer2, layer3, layer4; 0 switches the path off): the conv epilogue adds, the BatchNorm apply /
+  // backward-apply launch finalizes in its prologue, the finalize launch is gone.  Same-address atomics retire at ~23 ns
+  // each, so a 1 024-tile layer1 conv would pay +24 us for its sums (256 tiles: +4.5, 64: +1): layer1 keeps the partials.
+  // Step 14.83 -> 14.69 ms at 64, 14.60 at 256 (four interleaved runs each, +-0.01; DESIGN.md, "Round 4")
+  static int totals_tiles() {
+    static const int t = getenv("IEEE_BN_TOTALS_TILES") ? atoi(getenv("IEEE_BN_TOTALS_TILES")) : 256;
+    return t;
+  }
+  bool use_totals(const ConvUnit& u) const {
+    // (the kernels fetch gamma / beta / stats as 16-byte loads: slot offsets and modality strides multiples of 4 floats)
+    return n.dtype == IEEE_BF16 && (u.M(B) + 127) / 128 <= totals_tiles() && u.Co % 8 == 0 && 256 % (u.Co / 8) == 0 && u.Co / 8 <= 256 &&
+           &u != &n.units[n.u_stem] && ((n.slot_off[u.s_g] | n.slot_off[u.s_b] | gs(u.s_g)) & 3) == 0;
+  }
+  bool fwd_totals = false;   // the last conv() put its statistics into u.tot_f
   int conv(const ConvUnit& u, const void* in, bool want_stats = false) {
     const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
     fused_stats = want_stats && n.dtype == IEEE_BF16 && !frz(u);
+    fwd_totals = fused_stats && use_totals(u);
+    if (fwd_totals) IEEE_TRY(ieee_conv_next_bn_totals(P(u.tot_f), (int64_t)2 * u.Co));
     // (off by default: correct and bit-reproducible, but measured SLOWER -- 15.40 -> 15.91 ms per step: every workgroup of the
     // conv has to drain its output stores before it may take its ticket, which costs the conv more than the launch saves)
     static const bool f_fin = getenv("IEEE_BN_FIN_FUSE") && atoi(getenv("IEEE_BN_FIN_FUSE")) != 0;
-    fused_fin = f_fin && fused_stats && u.M(B) <= ieee_conv2d_fwd_bn_train_max_rows() && u.Ci % 64 == 0 && u.Co % 8 == 0;
+    fused_fin = f_fin && fused_stats && !fwd_totals && u.M(B) <= ieee_conv2d_fwd_bn_train_max_rows() && u.Ci % 64 == 0 && u.Co % 8 == 0;
     prof_begin(0, u);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     if (fused_fin)
@@ -476,6 +503,12 @@ struct Run {
   }
   int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training, void* relu_bits = nullptr) {
     if (frz(u)) training = 0;      // frozen child: running statistics, no update (module.eval() in the reference)
+    if (training && fwd_totals) {  // statistics in u.tot_f: finalize + apply in one launch
+      fwd_totals = fused_stats = fused_fin = false;
+      return ieee_bn2d_fwd_totals(P(u.y), residual, out, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b), gs(u.s_g),
+                                  buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), P(u.tot_f), n.bn_mom, n.bn_eps, relu, relu_bits, st);
+    }
+    fwd_totals = false;
     const int64_t rb = (training && fused_fin) ? -1 : ((training && fused_stats) ? ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) : 0);
     fused_stats = false;
     fused_fin = false;
@@ -515,8 +548,10 @@ struct Run {
   int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0,
              float* partial = nullptr, int64_t partial_rb = 0) {
     const int64_t rb = partial ? partial_rb : (fused_bwd ? (u.M(B) + 127) / 128 : 0);
+    const bool from_totals = !partial && fused_bwd && n.bwd_totals_state;
     if (!partial) partial = bnpart_cur;
     fused_bwd = false;
+    n.bwd_totals_state = false;
     will_write(dy);
     if (gout) will_write(gout);
     // (the first use checks once per process that a never-recorded stop event does order another stream on this runtime --
@@ -527,6 +562,9 @@ struct Run {
     if (frz(u))
       return ieee_bn2d_bwd_frozen(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, F(u.stats), bncoef_cur,
                                   mask_from_y, (void*)bn_done, st);
+    if (from_totals)   // the dgrad that produced `dout` added sum g, sum g*y to u.tot_b: finalize + apply in one launch
+      return ieee_bn2d_bwd_totals(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
+                                  F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), P(u.tot_b), mask_from_y, (void*)bn_done, st);
     return ieee_bn2d_bwd_ev(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
                             F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, bncoef_cur, 0, mask_from_y, rb,
                             (void*)bn_done, st);
@@ -595,10 +633,11 @@ struct Run {
     Run& r;
     void* main_st;
     float *part0, *coef0;
-    bool fs, fb;
+    bool fs, fb, ft, bt;
     hipEvent_t done;
     BranchScope(Run& run, int slot) : r(run), main_st(run.st), part0(run.bnpart_cur), coef0(run.bncoef_cur),
-                                      fs(run.fused_stats), fb(run.fused_bwd), done(run.n.branch_ev[2 * slot + 1]) {
+                                      fs(run.fused_stats), fb(run.fused_bwd), ft(run.fwd_totals), bt(run.n.bwd_totals_state),
+                                      done(run.n.branch_ev[2 * slot + 1]) {
       (void)hipEventRecord(r.n.branch_ev[2 * slot], (hipStream_t)main_st);
       (void)hipStreamWaitEvent(r.n.side2, r.n.branch_ev[2 * slot], 0);
       r.st = (void*)r.n.side2;
@@ -607,6 +646,8 @@ struct Run {
       r.tickets_cur = (int32_t*)(r.ws + r.n.tickets.off) + 256;
       r.fused_stats = false;
       r.fused_bwd = false;
+      r.fwd_totals = false;
+      r.n.bwd_totals_state = false;
     }
     ~BranchScope() {
       (void)hipEventRecord(done, r.n.side2);
@@ -616,6 +657,8 @@ struct Run {
       r.tickets_cur = (int32_t*)(r.ws + r.n.tickets.off);
       r.fused_stats = fs;
       r.fused_bwd = fb;
+      r.fwd_totals = ft;
+      r.n.bwd_totals_state = bt;
     }
   };
   void branch_join(int slot) { (void)hipStreamWaitEvent((hipStream_t)st, n.branch_ev[2 * slot + 1], 0); }
@@ -708,6 +751,8 @@ struct Run {
     static const bool ds_sums = getenv("IEEE_DS_SUMS") && atoi(getenv("IEEE_DS_SUMS")) != 0;   // measured: no gain
     const bool fuse2 = fuse && prev_ds != nullptr && ds_sums && !branch_enabled(2);
     fused_bwd = fuse;
+    n.bwd_totals_state = fuse && !fuse2 && use_totals(*prev) && !frz(*prev);
+    if (n.bwd_totals_state) IEEE_TRY(ieee_conv_next_bn_totals(P(prev->tot_b), (int64_t)2 * prev->Co));
     if (fuse2) ds_sums_of = prev_ds;     // (consumed, and cleared, by that unit's bn_bwd in the next block)
     will_write(dx);
     prof_begin(0, u, "dgrad");
@@ -732,6 +777,7 @@ struct Run {
   int dgrad_compact(const ConvUnit& d, const void* dy, void* dx) {
     const int64_t ldd = ieee_conv_packed_ld(n.dtype, d.Co, 1, 1);
     fused_bwd = false;
+    n.bwd_totals_state = false;
     will_write(dx);
     prof_begin(0, d, "dgrad");
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
@@ -805,6 +851,8 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
     if (training) N.eval_cache_valid = false;     // the step that follows changes parameters and running statistics
   }
   if (training) IEEE_HIP(hipMemsetAsync(P(N.tickets), 0, 512 * 4, (hipStream_t)st));   // arrival tickets of the fused finalizes
+  if (training && dt == IEEE_BF16 && totals_tiles() > 0)   // the units' fixed-point BatchNorm totals (forward AND backward) start at zero
+    IEEE_HIP(hipMemsetAsync(ws + N.tot_begin, 0, N.tot_end - N.tot_begin, (hipStream_t)st));
   IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, 4, 3, st));
   // stem: conv7x7/2 -> BN -> ReLU -> maxpool3x3/2   (resnet.py:622-626)
   const ConvUnit& s = N.units[N.u_stem];

@@ -246,6 +246,25 @@ int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void
                   int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
                   const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, float* partial,
                   float* coef, int accumulate, int mask_from_y, int64_t stats_rblocks, void* done_event, void* stream);
+/* BatchNorm statistics as order-independent TOTALS (round 4; no reference counterpart: autograd's batch_norm computes its
+ * statistics in one kernel, torchreid/models/resnet.py:164-184 only calls it).  ieee_conv_next_bn_totals arms the NEXT
+ * ieee_conv2d_fwd (with fused statistics) or ieee_conv2d_dgrad / _dgrad2 (with fused backward sums) issued by the calling
+ * thread: instead of one float per (channel, 128-row tile) in bn_partial, every tile ADDS its per-channel sums, as 64-bit
+ * fixed point (2^24 forward: sum y, sum y^2; 2^40 backward: sum g, sum g*y), to totals[group][2][C] with no-return global
+ * atomics.  Integer adds commute: the totals are bit-reproducible whatever the arrival order; nothing inside the conv waits.
+ * The caller zeroes the totals beforehand.  ieee_bn2d_fwd_totals / ieee_bn2d_bwd_totals then finalize AND apply in one
+ * launch (every workgroup derives its channels' coefficients from the 2 x C integers in its prologue; workgroup 0 publishes
+ * stats / running statistics / d(gamma), d(beta)), i.e. the separate finalize launch of ieee_bn2d_fwd / ieee_bn2d_bwd
+ * disappears.  bf16 only, C / 8 must divide 256.  Same results as the partial-sum path up to the last bit of a float sum. */
+int ieee_conv_next_bn_totals(void* totals, int64_t group_stride);
+int ieee_bn2d_fwd_totals(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
+                         int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
+                         float* running_mean, float* running_var, int64_t buf_gs, float* stats, const void* totals,
+                         float momentum, float eps, int relu, void* relu_bits, void* stream);
+int ieee_bn2d_bwd_totals(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
+                         int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
+                         const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, const void* totals,
+                         int mask_from_y, void* done_event, void* stream);
 /* backward through a FROZEN BatchNorm2d (module.eval() while the rest trains: open_specified_layers, utils/torchtools.py:
  * 183-221): `stats` holds the running-statistics scale / shift of the forward (ieee_bn2d_fwd with training = 0), the map
  * is a fixed affine one and dy = scale * g, g = dout * mask as in ieee_bn2d_bwd; no parameter gradient is produced. */
