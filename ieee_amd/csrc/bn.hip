@@ -486,14 +486,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fixed_kernel(const T* __rest
 //   one channel per thread through LDS (an eighth of the int64 -> double conversions), at most 1 024
 //   workgroups per modality so that a thread walks >= 4 chunks behind one prologue                            14.69 ms
 // against 14.83 ms with the finalize launches.
-template <int VEC> __device__ __forceinline__ void load_totals(const long long* __restrict__ p, long long* dst) {
-#pragma unroll
-  for (int e = 0; e < VEC; e += 2) {
-    const int4 v = *(const int4*)(p + e);
-    dst[e] = (long long)(((unsigned long long)(unsigned)v.y << 32) | (unsigned)v.x);
-    dst[e + 1] = (long long)(((unsigned long long)(unsigned)v.w << 32) | (unsigned)v.z);
-  }
-}
 constexpr double TOT_INV_FWD = 1.0 / 16777216.0;          // 2^-24
 constexpr double TOT_INV_BWD = 1.0 / 1099511627776.0;     // 2^-40
 
@@ -510,13 +502,10 @@ __global__ __launch_bounds__(256) void bn_apply_totals_kernel(const T* __restric
   const int z = blockIdx.y;
   uint8_t* bb = BITS ? relu_bits + z * (gs / 8) : nullptr;
   const int c0 = (threadIdx.x & (cprw - 1)) * VEC;
-  const long long* tt = totals + (int64_t)z * 2 * C + c0;
-  const bool publish = blockIdx.x == 0 && threadIdx.x < cprw;
   // one channel per thread (C / 256 rounds), through LDS: an eighth of the conversions of "every thread its 8 channels"
   extern __shared__ float tot_lds[];
   float* s_sc = tot_lds;
   float* s_sh = tot_lds + C;
-  (void)tt; (void)publish;
   for (int c = threadIdx.x; c < C; c += 256) {
     const long long t1 = totals[(int64_t)z * 2 * C + c], t2 = totals[(int64_t)z * 2 * C + C + c];
     const float ga = gamma[z * param_gs + c], be = beta[z * param_gs + c];
@@ -581,12 +570,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_totals_kernel(const T* __res
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
   const int c0 = (threadIdx.x & (cprw - 1)) * VEC;
-  const long long* tt = totals + (int64_t)z * 2 * C + c0;
   const float* st = stats + (int64_t)z * 4 * C;
-  const bool publish = blockIdx.x == 0 && threadIdx.x < cprw;
   extern __shared__ float tot_lds[];
   float* s_k = tot_lds;                                      // [3][C]
-  (void)tt; (void)publish;
   for (int c = threadIdx.x; c < C; c += 256) {
     const double s1 = (double)totals[(int64_t)z * 2 * C + c] * TOT_INV_BWD, s2 = (double)totals[(int64_t)z * 2 * C + C + c] * TOT_INV_BWD;
     const double mean = st[c], invstd = st[C + c];
