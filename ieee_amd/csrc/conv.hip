@@ -30,6 +30,7 @@ thread_local hipEvent_t tl_time_start = nullptr, tl_time_stop = nullptr;
 // a tile's float sum carries 24 bits itself.  ieee_conv_next_bn_totals() arms the NEXT forward / dgrad launch of the thread.
 thread_local long long* tl_totals = nullptr;
 thread_local int64_t tl_totals_gs = 0;
+thread_local int tl_totals_rep = 1;   // replicas of the totals (a power of two): tile t adds to replica t % rep -- fewer adders per address
 constexpr float TOT_SCALE_FWD = 16777216.0f;          // 2^24
 constexpr float TOT_SCALE_BWD = 1099511627776.0f;     // 2^40
 __device__ __forceinline__ long long to_fixed(float v, float scale) {
@@ -512,6 +513,8 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
   float* partial2 = nullptr;
   long long* tot = nullptr;     // MODE 1 / 2: add the tile's sums to these [groups][2][N] fixed-point totals instead of writing
   int64_t tot_gs = 0;           //             bn_partial (see tl_totals)
+  int tot_rep = 1;              //             replicas [tot_rep][groups][2][N]: row tile tm adds to replica tm % tot_rep
+  int64_t tot_rs = 0;           //             elements between replicas
 };
 
 // MODE 1: hand the epilogue its group's finalize operands
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
                               ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
   if constexpr (MODE == 3) epi.relu = bs.relu;
   if constexpr (MODE == 1) set_fin(epi, bs, z, tn, a.tiles_n, a.N);
-  if constexpr (MODE == 1 || MODE == 2) { if (bs.tot != nullptr) epi.tot = bs.tot + z * bs.tot_gs; }
+  if constexpr (MODE == 1 || MODE == 2) { if (bs.tot != nullptr) epi.tot = bs.tot + z * bs.tot_gs + (tm & (bs.tot_rep - 1)) * bs.tot_rs; }
   if constexpr (VAR == 2) { epi.as_wl = __ffs(a.g.Wo) - 1; epi.as_hl = __ffs(a.g.Ho) - 1; }
   if constexpr (MODE == 2) {
     if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const bf16* __res
                                     ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
   if constexpr (MODE == 3) epi.relu = bs.relu;
   if constexpr (MODE == 1) set_fin(epi, bs, z, tn, a.tiles_n, a.N);
-  if constexpr (MODE == 1 || MODE == 2) { if (bs.tot != nullptr) epi.tot = bs.tot + z * bs.tot_gs; }
+  if constexpr (MODE == 1 || MODE == 2) { if (bs.tot != nullptr) epi.tot = bs.tot + z * bs.tot_gs + (tm & (bs.tot_rep - 1)) * bs.tot_rs; }
   if constexpr (MODE == 2) {
     if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
     if (bs.y2) { epi.by2 = (decltype(epi.by2))bs.y2 + z * bs.act_gs; epi.bn_partial2 = bs.partial2 + (int64_t)z * a.tiles_m * 2 * a.N; }
@@ -1722,7 +1725,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   BwdStats bs{nullptr, nullptr, nullptr, 0, 0, 0};
   if (bwd) bs = *bwd;
   if (tl_totals != nullptr) {      // armed by ieee_conv_next_bn_totals for this launch
-    if (stats && bs.y2 == nullptr && !(fin != nullptr && fin->on)) { bs.tot = tl_totals; bs.tot_gs = tl_totals_gs; }
+    if (stats && bs.y2 == nullptr && !(fin != nullptr && fin->on)) { bs.tot = tl_totals; bs.tot_gs = tl_totals_gs; bs.tot_rep = tl_totals_rep; bs.tot_rs = tl_totals_gs * groups; }
     tl_totals = nullptr;
   }
   if (fin != nullptr && fin->on) {
@@ -2277,11 +2280,14 @@ extern "C" int ieee_conv_profile_events(void* start, void* stop) {
 }
 
 /* BatchNorm sums as order-independent totals: the next conv forward (fused statistics) / dgrad (fused backward sums) launch
- * of this thread adds its per-channel sums to totals[group][2][C] (int64 fixed point: 2^24 forward, 2^40 backward; the
- * caller zeroes them) with no-return atomics instead of writing per-tile partials; ieee_bn2d_fwd_totals /
- * ieee_bn2d_bwd_totals read them.  NULL cancels.  The stem (4 096 row tiles per modality) ignores it. */
-extern "C" int ieee_conv_next_bn_totals(void* totals, int64_t group_stride) {
+ * of this thread adds its per-channel sums to totals[replica][group][2][C] (int64 fixed point: 2^24 forward, 2^40 backward;
+ * the caller zeroes them; row tile t adds to replica t % replicas, a power of two <= 64) with no-return atomics instead of
+ * writing per-tile partials; ieee_bn2d_fwd_totals / ieee_bn2d_bwd_totals add the replicas up.  NULL cancels.  The stem
+ * (4 096 row tiles per modality) ignores it. */
+extern "C" int ieee_conv_next_bn_totals(void* totals, int64_t group_stride, int replicas) {
+  IEEE_REQUIRE(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0, "conv_next_bn_totals: replicas must be a power of two <= 64");
   ieee::tl_totals = (long long*)totals;
   ieee::tl_totals_gs = group_stride;
+  ieee::tl_totals_rep = replicas;
   return IEEE_OK;
 }

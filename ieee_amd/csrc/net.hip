@@ -24,6 +24,27 @@ struct Tensor {
   int dtype = IEEE_F32;
 };
 
+// BatchNorm sums as fixed-point totals (conv.hip: tl_totals) for the units of at most IEEE_BN_TOTALS_TILES row tiles per
+// modality (default 1024: layer1-4; 0 switches the path off; the stem's 4 096 tiles always write partial sums): the conv
+// epilogue adds, the BatchNorm apply / backward-apply launch finalizes in its prologue, the finalize launch is gone.
+// Same-address atomics retire at ~23 ns each -- a conv of 64 / 256 / 1 024 row tiles pays +1 / +4.5 / +24 us for its sums
+// with one copy of the totals -- so units of more than 64 tiles spread their adders over IEEE_BN_TOTALS_REP copies
+// (default 4; the prologue that adds the copies up costs +1.3 us at 4, +3.6 at 8: scripts/bn_totals_probe.py).
+// Returns the copies to use, 0 = not on this path.  Measurements: DESIGN.md, "Round 4".
+static constexpr int TOT_REP_MAX = 8;
+static int totals_tiles() {
+  static const int t = getenv("IEEE_BN_TOTALS_TILES") ? atoi(getenv("IEEE_BN_TOTALS_TILES")) : 1024;
+  return t;
+}
+static int totals_rep_for(int64_t tiles) {
+  static const int rep = [] {
+    int r = getenv("IEEE_BN_TOTALS_REP") ? atoi(getenv("IEEE_BN_TOTALS_REP")) : 4;
+    return (r == 1 || r == 2 || r == 4 || r == 8) ? r : 4;
+  }();
+  if (tiles > totals_tiles()) return 0;
+  return tiles <= 64 ? 1 : rep;
+}
+
 struct ConvUnit {
   std::string name;
   int Ci, Co, R, stride, pad, Hi, Wi, Ho, Wo;
@@ -322,8 +343,10 @@ void Net::plan() {
   tot_begin = ws_bytes;
   for (size_t i = 0; i < units.size(); ++i) {
     ConvUnit& u = units[i];
-    u.tot_f = alloc("", (int64_t)3 * 2 * u.Co * 2, IEEE_F32);   // int64 = 2 floats' worth
-    u.tot_b = alloc("", (int64_t)3 * 2 * u.Co * 2, IEEE_F32);
+    // (a run at a smaller batch than the planned one has fewer tiles: it asks for the same number of copies or for one)
+    const int rep = (u.M(B) + 127) / 128 <= 64 ? 1 : TOT_REP_MAX;
+    u.tot_f = alloc("", (int64_t)rep * 3 * 2 * u.Co * 2, IEEE_F32);   // [replicas][3][2][Co] int64 = 2 floats' worth each
+    u.tot_b = alloc("", (int64_t)rep * 3 * 2 * u.Co * 2, IEEE_F32);
   }
   tot_end = ws_bytes;
   const ConvUnit& st = units[u_stem];
@@ -468,18 +491,10 @@ struct Run {
   bool fused_stats = false;
   bool fused_fin = false;    // ... and finalized them too (ieee_conv2d_fwd_bn_train): bn() only applies
   bool frz(const ConvUnit& u) const { return (n.frozen & u.child) != 0; }
-  // BatchNorm sums as fixed-point totals (conv.hip: tl_totals) for the units of at most IEEE_BN_TOTALS_TILES row tiles per
-  // modality (default 256: layer2, layer3, layer4; 0 switches the path off): the conv epilogue adds, the BatchNorm apply /
-  // backward-apply launch finalizes in its prologue, the finalize launch is gone.  Same-address atomics retire at ~23 ns
-  // each, so a 1 024-tile layer1 conv would pay +24 us for its sums (256 tiles: +4.5, 64: +1): layer1 keeps the partials.
-  // Step 14.83 -> 14.69 ms at 64, 14.60 at 256 (four interleaved runs each, +-0.01; DESIGN.md, "Round 4")
-  static int totals_tiles() {
-    static const int t = getenv("IEEE_BN_TOTALS_TILES") ? atoi(getenv("IEEE_BN_TOTALS_TILES")) : 256;
-    return t;
-  }
+  int totals_rep(const ConvUnit& u) const { return totals_rep_for((u.M(B) + 127) / 128); }
   bool use_totals(const ConvUnit& u) const {
     // (the kernels fetch gamma / beta / stats as 16-byte loads: slot offsets and modality strides multiples of 4 floats)
-    return n.dtype == IEEE_BF16 && (u.M(B) + 127) / 128 <= totals_tiles() && u.Co % 8 == 0 && 256 % (u.Co / 8) == 0 && u.Co / 8 <= 256 &&
+    return n.dtype == IEEE_BF16 && totals_rep(u) > 0 && u.Co % 8 == 0 && 256 % (u.Co / 8) == 0 && u.Co / 8 <= 256 &&
            &u != &n.units[n.u_stem] && ((n.slot_off[u.s_g] | n.slot_off[u.s_b] | gs(u.s_g)) & 3) == 0;
   }
   bool fwd_totals = false;   // the last conv() put its statistics into u.tot_f
@@ -487,7 +502,7 @@ struct Run {
     const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
     fused_stats = want_stats && n.dtype == IEEE_BF16 && !frz(u);
     fwd_totals = fused_stats && use_totals(u);
-    if (fwd_totals) IEEE_TRY(ieee_conv_next_bn_totals(P(u.tot_f), (int64_t)2 * u.Co));
+    if (fwd_totals) IEEE_TRY(ieee_conv_next_bn_totals(P(u.tot_f), (int64_t)2 * u.Co, totals_rep(u)));
     // (off by default: correct and bit-reproducible, but measured SLOWER -- 15.40 -> 15.91 ms per step: every workgroup of the
     // conv has to drain its output stores before it may take its ticket, which costs the conv more than the launch saves)
     static const bool f_fin = getenv("IEEE_BN_FIN_FUSE") && atoi(getenv("IEEE_BN_FIN_FUSE")) != 0;
@@ -506,7 +521,7 @@ struct Run {
     if (training && fwd_totals) {  // statistics in u.tot_f: finalize + apply in one launch
       fwd_totals = fused_stats = fused_fin = false;
       return ieee_bn2d_fwd_totals(P(u.y), residual, out, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b), gs(u.s_g),
-                                  buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), P(u.tot_f), n.bn_mom, n.bn_eps, relu, relu_bits, st);
+                                  buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), P(u.tot_f), totals_rep(u), n.bn_mom, n.bn_eps, relu, relu_bits, st);
     }
     fwd_totals = false;
     const int64_t rb = (training && fused_fin) ? -1 : ((training && fused_stats) ? ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) : 0);
@@ -564,7 +579,7 @@ struct Run {
                                   mask_from_y, (void*)bn_done, st);
     if (from_totals)   // the dgrad that produced `dout` added sum g, sum g*y to u.tot_b: finalize + apply in one launch
       return ieee_bn2d_bwd_totals(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
-                                  F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), P(u.tot_b), mask_from_y, (void*)bn_done, st);
+                                  F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), P(u.tot_b), totals_rep(u), mask_from_y, (void*)bn_done, st);
     return ieee_bn2d_bwd_ev(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
                             F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, bncoef_cur, 0, mask_from_y, rb,
                             (void*)bn_done, st);
@@ -752,7 +767,7 @@ struct Run {
     const bool fuse2 = fuse && prev_ds != nullptr && ds_sums && !branch_enabled(2);
     fused_bwd = fuse;
     n.bwd_totals_state = fuse && !fuse2 && use_totals(*prev) && !frz(*prev);
-    if (n.bwd_totals_state) IEEE_TRY(ieee_conv_next_bn_totals(P(prev->tot_b), (int64_t)2 * prev->Co));
+    if (n.bwd_totals_state) IEEE_TRY(ieee_conv_next_bn_totals(P(prev->tot_b), (int64_t)2 * prev->Co, totals_rep(*prev)));
     if (fuse2) ds_sums_of = prev_ds;     // (consumed, and cleared, by that unit's bn_bwd in the next block)
     will_write(dx);
     prof_begin(0, u, "dgrad");

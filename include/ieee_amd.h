@@ -255,16 +255,19 @@ int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void
  * The caller zeroes the totals beforehand.  ieee_bn2d_fwd_totals / ieee_bn2d_bwd_totals then finalize AND apply in one
  * launch (every workgroup derives its channels' coefficients from the 2 x C integers in its prologue; workgroup 0 publishes
  * stats / running statistics / d(gamma), d(beta)), i.e. the separate finalize launch of ieee_bn2d_fwd / ieee_bn2d_bwd
- * disappears.  bf16 only, C / 8 must divide 256.  Same results as the partial-sum path up to the last bit of a float sum. */
-int ieee_conv_next_bn_totals(void* totals, int64_t group_stride);
+ * disappears.  bf16 only, C / 8 must divide 256.  Same results as the partial-sum path up to the last bit of a float sum.
+ * `replicas` (a power of two <= 64; 1 = plain) spreads the adders: totals[replica][group][2][C] (group_stride = 2 * C), row
+ * tile t adds to replica t % replicas, and the BatchNorm passes add the replicas up in their prologue -- same-address atomics
+ * retire at ~23 ns each, so a launch of 1 024 row tiles pays +24 us with one copy and +3 us with eight. */
+int ieee_conv_next_bn_totals(void* totals, int64_t group_stride, int replicas);
 int ieee_bn2d_fwd_totals(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
                          int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
                          float* running_mean, float* running_var, int64_t buf_gs, float* stats, const void* totals,
-                         float momentum, float eps, int relu, void* relu_bits, void* stream);
+                         int replicas, float momentum, float eps, int relu, void* relu_bits, void* stream);
 int ieee_bn2d_bwd_totals(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
                          int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
                          const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, const void* totals,
-                         int mask_from_y, void* done_event, void* stream);
+                         int replicas, int mask_from_y, void* done_event, void* stream);
 /* backward through a FROZEN BatchNorm2d (module.eval() while the rest trains: open_specified_layers, utils/torchtools.py:
  * 183-221): `stats` holds the running-statistics scale / shift of the forward (ieee_bn2d_fwd with training = 0), the map
  * is a fixed affine one and dy = scale * g, g = dout * mask as in ieee_bn2d_bwd; no parameter gradient is produced. */

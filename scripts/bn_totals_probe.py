@@ -1,6 +1,7 @@
 """BatchNorm from fixed-point totals against the partial-sum path, launch by launch (GPU box):
   python scripts/bn_totals_probe.py
-Per shape: the conv with per-tile partials / with atomics into the totals, and the BatchNorm forward that follows each."""
+Per shape: the conv with per-tile partials / with atomics into the totals, and the BatchNorm forward that follows each.
+PROBE_REPLICAS=R: the totals in R copies (row tile t adds to copy t % R)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,7 +33,8 @@ for (N, H, W, Ci, Co, R) in ((64, 8, 4, 2048, 512, 1), (64, 16, 8, 1024, 256, 1)
     rb = lib.ieee_conv2d_fwd_stats_rblocks(N, H, W)
     gam, bet = torch.ones(G, Co).cuda(), torch.zeros(G, Co).cuda()
     part = torch.zeros(G, 2, Co, rb, device="cuda")
-    tot = torch.zeros(G, 2, Co, dtype=torch.int64, device="cuda")
+    REP = int(os.environ.get("PROBE_REPLICAS", "1"))
+    tot = torch.zeros(REP, G, 2, Co, dtype=torch.int64, device="cuda")
     y = torch.empty(G, N, H, W, Co, device="cuda", dtype=dt)
     a = torch.empty_like(y)
     stats = torch.zeros(G, 4, Co, device="cuda")
@@ -40,14 +42,14 @@ for (N, H, W, Ci, Co, R) in ((64, 8, 4, 2048, 512, 1), (64, 16, 8, 1024, 256, 1)
 
     def conv(use_totals):
         if use_totals:
-            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Co))
+            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Co, REP))
         L.check(lib.ieee_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(y), L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad, x[0].numel(),
                                     wp.stride(0), y[0].numel(), L.ptr(part), L.stream()))
 
     def bn(use_totals):
         if use_totals:
             L.check(lib.ieee_bn2d_fwd_totals(L.ptr(y), None, L.ptr(a), L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co,
-                                             L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(tot), 0.1, 1e-5, 1, None, L.stream()))
+                                             L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(tot), REP, 0.1, 1e-5, 1, None, L.stream()))
         else:
             L.check(lib.ieee_bn2d_fwd(L.ptr(y), None, L.ptr(a), L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co,
                                       L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, 1, rb, None, L.stream()))

@@ -418,13 +418,15 @@ def test_deferred_wgrad_with_one_batched_reduction_is_bit_identical(dtype):
         assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("Ci,Co,R,H,W", [(64, 256, 1, 16, 8), (128, 128, 3, 16, 8), (256, 64, 1, 12, 10)])
-def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co, R, H, W):
+@pytest.mark.parametrize("Ci,Co,R,H,W,REP", [(64, 256, 1, 16, 8, 1), (128, 128, 3, 16, 8, 1), (256, 64, 1, 12, 10, 1), (64, 256, 1, 16, 8, 8),
+                                             (128, 128, 3, 16, 8, 4)])
+def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co, R, H, W, REP):
     """ieee_conv_next_bn_totals: the conv / dgrad epilogue adds its per-channel sums to int64 fixed-point totals (no-return
     atomics) instead of writing per-tile partials, and ieee_bn2d_fwd_totals / ieee_bn2d_bwd_totals finalize + apply in one
     launch.  Against the partial-sum path (conv -> ieee_bn2d_fwd / dgrad -> ieee_bn2d_bwd) on the same operands: the totals
     are the integer image of the partial sums (2^24 / 2^40), every output of the BatchNorm passes agrees to a float rounding,
-    and the totals are bit-identical over repeated launches (integer adds commute)."""
+    and the totals are bit-identical over repeated launches (integer adds commute).  REP > 1: row tile t adds to replica
+    t % REP of the totals and the BatchNorm passes add the replicas up."""
     from ieee_amd import _lib as L, _ops
     lib = L.require_gpu()
     g = torch.Generator().manual_seed(33)
@@ -441,19 +443,19 @@ def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co,
 
     def forward(use_totals):
         part = torch.zeros(G, 2, Co, rb, device="cuda")
-        tot = torch.zeros(G, 2, Co, dtype=torch.int64, device="cuda")
+        tot = torch.zeros(REP, G, 2, Co, dtype=torch.int64, device="cuda")
         y = torch.empty(G, N, H, W, Co, device="cuda", dtype=dt)
         a = torch.empty_like(y)
         bits = torch.zeros(y.numel() // 8, dtype=torch.uint8, device="cuda")
         stats = torch.zeros(G, 4, Co, device="cuda")
         rm, rv = torch.zeros(G, Co, device="cuda"), torch.ones(G, Co, device="cuda")
         if use_totals:
-            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Co))
+            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Co, REP))
         L.check(lib.ieee_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(y), L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad, x[0].numel(),
                                     wp.stride(0), y[0].numel(), L.ptr(part), L.stream()))
         if use_totals:
             L.check(lib.ieee_bn2d_fwd_totals(L.ptr(y), L.ptr(res), L.ptr(a), L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co,
-                                             L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(tot), 0.1, 1e-5, 1, L.ptr(bits), L.stream()))
+                                             L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(tot), REP, 0.1, 1e-5, 1, L.ptr(bits), L.stream()))
         else:
             L.check(lib.ieee_bn2d_fwd(L.ptr(y), L.ptr(res), L.ptr(a), L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co,
                                       L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, 1, rb, L.ptr(bits), L.stream()))
@@ -463,7 +465,11 @@ def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co,
     assert torch.equal(t["tot"], t2["tot"]) and torch.equal(t["a"], t2["a"])             # order-independent: the same bits every time
     assert torch.equal(p["y"], t["y"]) and float(t["part"].abs().max()) == 0.0           # same conv stores; no partials written
     want = torch.round(p["part"].double() * 2.0 ** 24).sum(-1)                           # each tile's float sum, converted, added
-    assert torch.equal(t["tot"], want.to(torch.int64))
+    assert torch.equal(t["tot"].sum(0), want.to(torch.int64))
+    if REP > 1:   # tile t went to replica t % REP
+        per = torch.round(p["part"].double() * 2.0 ** 24)
+        for r in range(REP):
+            assert torch.equal(t["tot"][r], per[..., r::REP].sum(-1).to(torch.int64))
     torch.testing.assert_close(t["stats"], p["stats"], rtol=2e-6, atol=2e-6)
     torch.testing.assert_close(t["rm"], p["rm"], rtol=2e-6, atol=1e-7)
     torch.testing.assert_close(t["rv"], p["rv"], rtol=2e-6, atol=1e-7)
@@ -479,19 +485,19 @@ def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co,
 
     def backward(use_totals):
         part = torch.zeros(G, 2, Ci, rb, device="cuda")
-        tot = torch.zeros(G, 2, Ci, dtype=torch.int64, device="cuda")
+        tot = torch.zeros(REP, G, 2, Ci, dtype=torch.int64, device="cuda")
         dx = torch.empty(G, N, H, W, Ci, device="cuda", dtype=dt)
         dyp = torch.empty_like(dx)
         dgam, dbet = torch.zeros(G, Ci, device="cuda"), torch.zeros(G, Ci, device="cuda")
         coef = torch.zeros(G, 3, Ci, device="cuda")
         if use_totals:
-            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Ci))
+            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Ci, REP))
         L.check(lib.ieee_conv2d_dgrad(L.ptr(dyo), L.ptr(wpd), L.ptr(dx), None, L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad,
                                       dyo[0].numel(), wpd.stride(0), dx[0].numel(), L.ptr(part), L.ptr(ypre), None, L.ptr(pst), 0, 1,
                                       L.stream()))
         if use_totals:
             L.check(lib.ieee_bn2d_bwd_totals(L.ptr(dx), None, L.ptr(ypre), L.ptr(dyp), None, L.IEEE_BF16, G, M, Ci, M * Ci, L.ptr(pgam), Ci,
-                                             L.ptr(pst), L.ptr(dgam), L.ptr(dbet), Ci, L.ptr(tot), 1, None, L.stream()))
+                                             L.ptr(pst), L.ptr(dgam), L.ptr(dbet), Ci, L.ptr(tot), REP, 1, None, L.stream()))
         else:
             L.check(lib.ieee_bn2d_bwd(L.ptr(dx), None, L.ptr(ypre), L.ptr(dyp), None, L.IEEE_BF16, G, M, Ci, M * Ci, L.ptr(pgam), Ci,
                                       L.ptr(pst), L.ptr(dgam), L.ptr(dbet), Ci, L.ptr(part), L.ptr(coef), 0, 1, rb, L.stream()))
@@ -500,7 +506,7 @@ def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co,
     p, t, t2 = backward(False), backward(True), backward(True)
     assert torch.equal(t["tot"], t2["tot"]) and torch.equal(t["dy"], t2["dy"]) and torch.equal(p["dx"], t["dx"])
     want = torch.round(p["part"].double() * 2.0 ** 40).sum(-1)
-    assert torch.equal(t["tot"], want.to(torch.int64))
+    assert torch.equal(t["tot"].sum(0), want.to(torch.int64))
     torch.testing.assert_close(t["dgam"], p["dgam"], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(t["dbet"], p["dbet"], rtol=1e-5, atol=1e-5)
     assert float((t["dy"].float() - p["dy"].float()).abs().max()) <= 2.0 ** -6 * float(p["dy"].float().abs().max())
