@@ -31,6 +31,11 @@ thread_local hipEvent_t tl_time_start = nullptr, tl_time_stop = nullptr;
 thread_local long long* tl_totals = nullptr;
 thread_local int64_t tl_totals_gs = 0;
 thread_local int tl_totals_rep = 1;   // replicas of the totals (a power of two): tile t adds to replica t % rep -- fewer adders per address
+// whatever a conv entry point returns, nothing stays armed for a later launch of the thread (a call that fails its argument
+// checks must not leave its totals / timing events to the next one)
+struct OneShotArms {
+  ~OneShotArms() { tl_totals = nullptr; tl_totals_rep = 1; tl_time_start = tl_time_stop = nullptr; }
+};
 constexpr float TOT_SCALE_FWD = 16777216.0f;          // 2^24
 constexpr float TOT_SCALE_BWD = 1099511627776.0f;     // 2^40
 __device__ __forceinline__ long long to_fixed(float v, float scale) {
@@ -1917,6 +1922,7 @@ extern "C" int ieee_pack_conv_weight(const float* w_oihw, void* dst, int dtype, 
 extern "C" int ieee_conv2d_fwd(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N,
                                int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride,
                                int64_t pad, int64_t x_gs, int64_t w_gs, int64_t y_gs, float* bn_partial, void* stream) {
+  ieee::OneShotArms disarm;
   IEEE_REQUIRE(x && w_packed && y, "conv2d_fwd: null pointer");
   Dims d;
   IEEE_TRY(check_dims("conv2d_fwd", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
@@ -1950,6 +1956,7 @@ extern "C" int ieee_conv2d_fwd_bn_train(const void* x, const void* w_packed, voi
                                         const float* gamma, const float* beta, int64_t param_gs, float* running_mean,
                                         float* running_var, int64_t buf_gs, float* stats, float momentum, float eps,
                                         int32_t* tickets, void* stream) {
+  ieee::OneShotArms disarm;
   IEEE_REQUIRE(x && w_packed && y && bn_partial && gamma && beta && stats && tickets, "conv2d_fwd_bn_train: null pointer");
   IEEE_REQUIRE(dtype == IEEE_BF16, "conv2d_fwd_bn_train: bf16 only");
   Dims d;
@@ -1970,6 +1977,7 @@ extern "C" int ieee_conv2d_fwd_bn_eval(const void* x, const void* w_packed, void
                                        const float* bn_stats, int relu, int dtype, int64_t groups, int64_t N, int64_t Hi,
                                        int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride,
                                        int64_t pad, int64_t x_gs, int64_t w_gs, int64_t out_gs, void* stream) {
+  ieee::OneShotArms disarm;
   IEEE_REQUIRE(x && w_packed && out && bn_stats, "conv2d_fwd_bn_eval: null pointer");
   Dims d;
   IEEE_TRY(check_dims("conv2d_fwd_bn_eval", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
@@ -2011,6 +2019,7 @@ extern "C" int ieee_conv2d_dgrad2(const void* dy, const void* w_packed_d, void* 
                                   int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
                                   float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
                                   int bn_mask_bits, int addend_stride, const void* bn_y2, float* bn_partial2, void* stream) {
+  ieee::OneShotArms disarm;
   IEEE_REQUIRE(dy && w_packed_d && dx, "conv2d_dgrad: null pointer");
   IEEE_REQUIRE((bn_y2 == nullptr) == (bn_partial2 == nullptr) && (!bn_y2 || (bn_partial && dtype == IEEE_BF16)),
                "conv2d_dgrad: the second BatchNorm's sums need its input AND its partial block, in the bf16 fused form");

@@ -475,6 +475,13 @@ def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co,
     torch.testing.assert_close(t["rv"], p["rv"], rtol=2e-6, atol=1e-7)
     assert float((t["a"].float() - p["a"].float()).abs().max()) <= 2.0 ** -6 * float(p["a"].float().abs().max())   # <= one bf16 ulp where sc / sh moved a bit
     assert float((t["a"] != p["a"]).float().mean()) < 2e-3 and float((t["bits"] != p["bits"]).float().mean()) < 2e-3
+    # a call that fails its argument checks leaves nothing armed for the next launch of the thread
+    stale = torch.zeros(REP, G, 2, Co, dtype=torch.int64, device="cuda")
+    L.check(lib.ieee_conv_next_bn_totals(L.ptr(stale), 2 * Co, REP))
+    assert lib.ieee_conv2d_fwd(None, L.ptr(wp), L.ptr(p["y"]), L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad, x[0].numel(), wp.stride(0),
+                               p["y"][0].numel(), L.ptr(p["part"]), L.stream()) != 0
+    again = forward(False)
+    assert torch.equal(again["part"], p["part"]) and int(stale.abs().max()) == 0
     # ---- backward: dgrad with the fused sums of the unit in front (mask recomputed from its y and statistics), then its
     # BatchNorm backward
     dyo = torch.randn(G, N, H, W, Co, generator=g).cuda().to(dt)
