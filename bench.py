@@ -164,8 +164,9 @@ def dp_path_leg(engine, batch, model, rounds=3, steps=12):
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
             made = True
 
-        def run(forced, n):
+        def run(forced, n, overlap=True):
             os.environ["IEEE_FORCE_DP_PATH"] = "1" if forced else "0"
+            engine.dp_overlap = overlap
             torch.cuda.synchronize()
             t0 = time.time()
             for _ in range(n):
@@ -178,20 +179,25 @@ def dp_path_leg(engine, batch, model, rounds=3, steps=12):
             for a, b in ranges:
                 dist.all_reduce(model._flat_grads[a:b], op=dist.ReduceOp.SUM)
         run(True, 25)
-        plain, staged = [], []
+        run(True, 6, overlap=False)
+        plain, staged, simple = [], [], []
         for _ in range(rounds):
             plain.append(run(False, steps))
             staged.append(run(True, steps))
-        p, st = sorted(plain)[len(plain) // 2], sorted(staged)[len(staged) // 2]
-        return {"plain_ms_per_step": p, "staged_ms_per_step": st, "dp_path_overhead_ms": st - p, "backend": dist.get_backend(),
+            simple.append(run(True, steps, overlap=False))
+        p, st, sm = (sorted(v)[len(v) // 2] for v in (plain, staged, simple))
+        return {"plain_ms_per_step": p, "staged_ms_per_step": st, "dp_path_overhead_ms": st - p,
+                "unoverlapped_dp_ms_per_step": sm, "backend": dist.get_backend(),
                 "ranks": dist.get_world_size(), "rounds": rounds, "steps_per_round": steps,
                 "what": "the N > 1 step (5 backward parts, 13 gradient slices all-reduced from a communication stream, optimizer "
                         "slices behind them) run over a 1-rank RCCL group on this GPU, interleaved with the plain step: the fixed "
-                        "per-rank cost of the data-parallel code path without any wire time"}
+                        "per-rank cost of the data-parallel code path without any wire time; unoverlapped = the fallback form "
+                        "(whole backward, one all-reduce pass on the compute stream, one optimizer step; IEEE_DP_OVERLAP=0)"}
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
     finally:
         os.environ["IEEE_FORCE_DP_PATH"] = "0"
+        engine.dp_overlap = None
         if made:
             try:
                 dist.destroy_process_group()
@@ -357,6 +363,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    dp_calibration = None
     if world > 1:
         # communicator set-up is not a training step: RCCL builds its channels and registers the gradient buffer at the
         # first collectives over it (measured with a 1-rank group: the first ~20 staged steps run 1.3-1.6x slower), so
@@ -366,6 +373,29 @@ def main():
                 torch.distributed.all_reduce(model._flat_grads[a:b], op=torch.distributed.ReduceOp.SUM)
         model._flat_grads.zero_()
         barrier()
+        if os.environ.get("IEEE_DP_OVERLAP") is None:
+            # which form of the data-parallel step runs: the overlapped one (5 backward parts, gradient slices all-reduced
+            # from a communication stream while the next part computes, optimizer slices behind them) unless the plain one
+            # (whole backward, one all-reduce pass, one update) is clearly faster HERE -- how the runtime maps the step's
+            # streams and RCCL's onto hardware queues decides whether the overlap materialises ("Round 4"), and a
+            # single-GPU box cannot tell.  Timed on every rank, decided on the slowest rank's figures.
+            def cal_steps(n):
+                barrier()
+                t0 = time.time()
+                for _ in range(n):
+                    engine.forward_backward(batch)
+                barrier()
+                return (time.time() - t0) / n * 1e3
+            cal = []
+            for ov in (True, False):
+                engine.dp_overlap = ov
+                cal_steps(6)
+                cal.append(cal_steps(8))
+            t = torch.tensor(cal, dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            engine.dp_overlap = bool(float(t[0]) <= 1.02 * float(t[1]))
+            dp_calibration = {"overlapped_ms_per_step": float(t[0]), "unoverlapped_ms_per_step": float(t[1]),
+                              "used": "overlapped" if engine.dp_overlap else "unoverlapped", "steps_each": 8}
     if os.environ.get("IEEE_BENCH_HIPRIO") == "1":       # experiment: the step's launch stream as a high-priority stream
         torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=-1))
     for _ in range(args.warmup):
@@ -458,10 +488,13 @@ def main():
     # with event pairs on the communication stream; not part of the timed region)
     rccl = None
     if world > 1:
+        used_overlap = engine.dp_overlap
+        engine.dp_overlap = True             # the per-part event pairs exist in the overlapped form
         engine.time_collectives = []
         for _ in range(min(args.steps, 10)):
             engine.forward_backward(batch)
         torch.cuda.synchronize()
+        engine.dp_overlap = used_overlap
         parts = {}
         for part, e0, e1, nbytes in engine.time_collectives:
             parts.setdefault(part, []).append((e0.elapsed_time(e1), nbytes))
@@ -498,6 +531,12 @@ def main():
         line["rccl"] = rccl
     if dp_path is not None:
         line["dp_path"] = dp_path
+    if world > 1:
+        line["config"]["dp_step"] = ("overlapped: 5 backward parts, 13 gradient slices all-reduced over RCCL from a communication stream, "
+                                     "optimizer slices behind them") if getattr(engine, "dp_overlap", None) is not False and os.environ.get("IEEE_DP_OVERLAP", "1") != "0" \
+            else "unoverlapped: whole backward, one all-reduce pass over RCCL, one optimizer step"
+        if dp_calibration is not None:
+            line["dp_calibration"] = dp_calibration
     if rank == 0:
         if world == 1 and not args.no_loader and args.dtype == "bf16":
             # input pipeline at step rate: JPEG tree -> worker decode -> device transform -> real steps,

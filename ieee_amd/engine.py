@@ -427,7 +427,20 @@ class _FusedStepMixin(object):
             self.optimizer.step_part(4)
             main.wait_stream(helper)
             return small, out3
-        if not staged:
+        # IEEE_DP_OVERLAP=0 / engine.dp_overlap = False: the plain data-parallel step of the reference's DataParallel run
+        # (scripts/mainMultiModal.py:219-220) -- whole backward, ONE all-reduce pass over the flat gradient on the compute
+        # stream, one optimizer step.  No helper stream, nothing overlapped: the fallback when the overlapped form below
+        # meets a stream -> hardware-queue assignment it does not like (bench.py times both at N > 1 and says which it used).
+        overlap = getattr(self, "dp_overlap", None)
+        if overlap is None:
+            overlap = os.environ.get("IEEE_DP_OVERLAP", "1") != "0"
+        if staged and not overlap:
+            net.backward(dl, df)
+            handles = [torch.distributed.all_reduce(m._flat_grads[a:b], op=torch.distributed.ReduceOp.SUM, async_op=True)
+                       for ranges in m.grad_part_ranges() for a, b in ranges]
+            for h in handles:
+                h.wait()                         # orders the compute stream (not the host) after the collectives
+        elif not staged:
             net.backward(dl, df)
         else:
             # data parallel: the backward runs in 5 parts; as soon as a part is done its (final) slice of the flat

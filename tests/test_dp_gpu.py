@@ -91,7 +91,8 @@ def test_two_rank_step_equals_serial_sum(tmp_path):
 
 def _worker_update(rank, world, port, out_path, overlap):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
-                      LOCAL_RANK=str(rank), IEEE_DIST_BACKEND="gloo", IEEE_FORCE_DEVICE="0", IEEE_OPT_OVERLAP=overlap)
+                      LOCAL_RANK=str(rank), IEEE_DIST_BACKEND="gloo", IEEE_FORCE_DEVICE="0",
+                      IEEE_OPT_OVERLAP="1" if overlap == "plain" else overlap, IEEE_DP_OVERLAP="0" if overlap == "plain" else "1")
     from ieee_amd import dist as ddp
     from ieee_amd.optim import build_optimizer
     ddp.init_from_env()
@@ -106,15 +107,17 @@ def _worker_update(rank, world, port, out_path, overlap):
 
 def test_two_rank_update_by_part_equals_one_update_and_keeps_replicas_equal(tmp_path):
     """staged data-parallel step: the optimizer update applied part by part behind each part's all-reduce (the default)
-    leaves bit for bit the parameters and momentum of one optimizer.step() after the last all-reduce, on both ranks"""
+    leaves bit for bit the parameters and momentum of one optimizer.step() after the last all-reduce, on both ranks -- and of
+    the plain data-parallel step (IEEE_DP_OVERLAP=0: whole backward, one all-reduce pass on the compute stream, one update)"""
     got = {}
-    for overlap in ("1", "0"):
+    for overlap in ("1", "0", "plain"):
         out = str(tmp_path / ("upd%s_" % overlap))
         mp.spawn(_worker_update, args=(2, _free_port(), out, overlap), nprocs=2, join=True)
         got[overlap] = [torch.load(out + str(r)) for r in range(2)]
     for key in ("params", "momentum"):
         assert torch.equal(got["1"][0][key], got["1"][1][key])          # replicas stay identical
         assert torch.equal(got["1"][0][key], got["0"][0][key])          # by part == all at once
+        assert torch.equal(got["1"][0][key], got["plain"][0][key]) and torch.equal(got["plain"][0][key], got["plain"][1][key])
     assert not torch.equal(got["1"][0]["momentum"], torch.zeros_like(got["1"][0]["momentum"]))
 
 
