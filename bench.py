@@ -122,6 +122,33 @@ def committed_kernel_stats(train_gflop_per_triple):
     return None
 
 
+def committed_layer_ceiling(batch):
+    """What the forward + dgrad launches of THIS layer mix could reach if every launch sat on its own roof: per row of the
+    newest committed per-layer table (profiles/rNN_layers.csv: FLOPs and algorithmic bytes per launch, B = 64) the time
+    max(FLOPs / MFMA peak, algorithmic bytes / HBM peak), summed.  layer1 / layer2 are HBM-bound at 50-100 FLOP per byte, so
+    the family's ceiling is well below the MFMA peak that `frac` is quoted against; a second figure uses what the guide's
+    best kernels reach (1.27 PFLOP/s for a GEMM, 5.5 TB/s for a stream) instead of the nominal peaks."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_layers.csv")), reverse=True):
+        try:
+            rows = [r for r in csv.DictReader(open(path)) if r["kind"] in ("fwd", "dgrad")]
+            fl = sum(int(r["launches_per_step"]) * float(r["gflop"]) * 1e9 for r in rows)
+            def at(pf, bw):
+                return sum(int(r["launches_per_step"]) * max(float(r["gflop"]) * 1e9 / pf, float(r["algorithmic_bytes"]) / bw) for r in rows)
+            t_nom, t_prac = at(PEAK_BF16_TFLOPS * 1e12, PEAK_HBM_GBS * 1e9), at(1.27e15, 5.5e12)
+            if batch != 64 or fl <= 0:
+                return None
+            return {"source": os.path.relpath(path, ROOT), "nominal": {"ms_per_step": t_nom * 1e3, "TFLOPs": fl / t_nom / 1e12,
+                                                                        "frac_of_mfma_peak": fl / t_nom / 1e12 / PEAK_BF16_TFLOPS},
+                    "practical": {"ms_per_step": t_prac * 1e3, "TFLOPs": fl / t_prac / 1e12, "gemm_TFLOPs": 1270.0, "stream_GBps": 5500.0},
+                    "what": "sum over the 109 forward + dgrad launches of max(FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s); practical: "
+                            "against 1.27 PFLOP/s and 5.5 TB/s, what the guide's best GEMM and streaming kernels reach"}
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline_train(seconds_budget=25.0):
     """oracle (stock torch CPU ops arranged like the reference) on a bounded sample: B=8 steps"""
     from ieee_amd import detgen
@@ -442,12 +469,17 @@ def main():
         if traffic is None:
             traffic, traffic_src = committed_traffic("conv_gather")
     stats_line = committed_kernel_stats(TRAIN_GFLOP_PER_TRIPLE) if args.dtype == "bf16" and B == 64 else None
+    ceiling = committed_layer_ceiling(B) if args.dtype == "bf16" else None
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "measured": "in situ: every launch of the family carries a HIP event pair as its own start / stop signals "
                             "(hipExtLaunchKernelGGL) inside the two-stream step; nothing is added to the queues",
                 "in_situ_frac": ach / peak, "serialized_achieved": ser, "serialized_frac": ser / peak,
                 "serialized_avg_launch_us": sg_ms * 1e3 / max(sg_n, 1),
                 "in_situ_from_committed_rocprof_stats": stats_line,
+                "layer_mix_ceiling": ceiling,
+                "frac_of_layer_mix_ceiling": ({"in_situ": ach / ceiling["nominal"]["TFLOPs"], "serialized": ser / ceiling["nominal"]["TFLOPs"],
+                                               "in_situ_vs_practical": ach / ceiling["practical"]["TFLOPs"],
+                                               "serialized_vs_practical": ser / ceiling["practical"]["TFLOPs"]} if ceiling else None),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "conv forward + dgrad launches: conv_gather_kernel (implicit GEMM), conv3x3_patch_kernel (3x3 from an "
                           "LDS-resident patch), stem_conv_kernel",
