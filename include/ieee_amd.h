@@ -256,6 +256,10 @@ int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void
  * launch (every workgroup derives its channels' coefficients from the 2 x C integers in its prologue; workgroup 0 publishes
  * stats / running statistics / d(gamma), d(beta)), i.e. the separate finalize launch of ieee_bn2d_fwd / ieee_bn2d_bwd
  * disappears.  bf16 only, C / 8 must divide 256.  Same results as the partial-sum path up to the last bit of a float sum.
+ * Range and resolution of the fixed point: forward sums up to 5.4e11 with 6e-8 absolute resolution (a 131 072-row map
+ * overflows at an rms of 2 000 per channel), backward sums up to 8.3e6 with 9e-13 (finer than the float tile sum itself above
+ * 1.5e-5); a tile's contribution saturates at +-9e18 units instead of wrapping, a NaN tile sum saturates too -- the NaN
+ * itself still reaches the output through y.
  * `replicas` (a power of two <= 64; 1 = plain) spreads the adders: totals[replica][group][2][C] (group_stride = 2 * C), row
  * tile t adds to replica t % replicas, and the BatchNorm passes add the replicas up in their prologue -- same-address atomics
  * retire at ~23 ns each, so a launch of 1 024 row tiles pays +24 us with one copy and +3 us with eight. */
