@@ -564,9 +564,10 @@ def main():
     if dp_path is not None:
         line["dp_path"] = dp_path
     if world > 1:
-        line["config"]["dp_step"] = ("overlapped: 5 backward parts, 13 gradient slices all-reduced over RCCL from a communication stream, "
-                                     "optimizer slices behind them") if getattr(engine, "dp_overlap", None) is not False and os.environ.get("IEEE_DP_OVERLAP", "1") != "0" \
-            else "unoverlapped: whole backward, one all-reduce pass over RCCL, one optimizer step"
+        be = torch.distributed.get_backend()
+        line["config"]["dp_step"] = ("overlapped: 5 backward parts, 13 gradient slices all-reduced (%s) from a communication stream, "
+                                     "optimizer slices behind them" % be) if getattr(engine, "dp_overlap", None) is not False and os.environ.get("IEEE_DP_OVERLAP", "1") != "0" \
+            else "unoverlapped: whole backward, one all-reduce pass (%s), one optimizer step" % be
         if dp_calibration is not None:
             line["dp_calibration"] = dp_calibration
     if rank == 0:
