@@ -502,6 +502,16 @@ __global__ __launch_bounds__(256) void bn_apply_totals_kernel(const T* __restric
   const int z = blockIdx.y;
   uint8_t* bb = BITS ? relu_bits + z * (gs / 8) : nullptr;
   const int c0 = (threadIdx.x & (cprw - 1)) * VEC;
+  // the first chunk's operands are requested BEFORE the prologue: their HBM latency runs beside the totals' round trip
+  const T* yy = y + z * gs;
+  const T* rr = RES ? residual + z * gs : nullptr;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint4 ynext = make_uint4(0, 0, 0, 0), rnext = make_uint4(0, 0, 0, 0);
+  if (out != nullptr && i < total_chunks) {
+    ynext = *(const uint4*)(yy + i * VEC);
+    if (RES) rnext = *(const uint4*)(rr + i * VEC);
+  }
   // one channel per thread (C / 256 rounds), through LDS: an eighth of the conversions of "every thread its 8 channels"
   extern __shared__ float tot_lds[];
   float* s_sc = tot_lds;
@@ -535,14 +545,15 @@ __global__ __launch_bounds__(256) void bn_apply_totals_kernel(const T* __restric
   load_floats<VEC>(s_sc + c0, sc);
   load_floats<VEC>(s_sh + c0, sh);
   if (out == nullptr) return;
-  const T* yy = y + z * gs;
-  const T* rr = RES ? residual + z * gs : nullptr;
   T* oo = out + z * gs;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += stride) {
+  for (; i < total_chunks; i += stride) {
     float v[VEC], r[VEC];
-    Vec16<T>::unpack(*(const uint4*)(yy + i * VEC), v);
-    if (RES) Vec16<T>::unpack(*(const uint4*)(rr + i * VEC), r);
+    Vec16<T>::unpack(ynext, v);
+    if (RES) Vec16<T>::unpack(rnext, r);
+    if (i + stride < total_chunks) {                          // the next chunk is in flight while this one is finished
+      ynext = *(const uint4*)(yy + (i + stride) * VEC);
+      if (RES) rnext = *(const uint4*)(rr + (i + stride) * VEC);
+    }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       float x = v[e] * sc[e] + sh[e];
@@ -576,6 +587,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_totals_kernel(const T* __res
   const int z = blockIdx.y;
   const int c0 = (threadIdx.x & (cprw - 1)) * VEC;
   const float* st = stats + (int64_t)z * 4 * C;
+  // the first chunk's operands are requested BEFORE the prologue (see bn_apply_totals_kernel)
+  const T* dd = da + z * gs;
+  const T* aa = MASK == 1 ? a + z * gs : nullptr;
+  const T* yy = y + z * gs;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint4 dnext = make_uint4(0, 0, 0, 0), ynext = dnext, anext = dnext;
+  if (i < total_chunks) {
+    dnext = *(const uint4*)(dd + i * VEC);
+    ynext = *(const uint4*)(yy + i * VEC);
+    if (MASK == 1) anext = *(const uint4*)(aa + i * VEC);
+  }
   extern __shared__ float tot_lds[];
   float* s_k = tot_lds;                                      // [3][C]
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -603,18 +626,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_totals_kernel(const T* __res
   load_floats<VEC>(s_k + C + c0, k2);
   load_floats<VEC>(s_k + 2 * C + c0, k3);
   if (MASK == 2) { load_floats<VEC>(st + 2 * C + c0, sc); load_floats<VEC>(st + 3 * C + c0, sh); }
-  const T* dd = da + z * gs;
-  const T* aa = MASK == 1 ? a + z * gs : nullptr;
-  const T* yy = y + z * gs;
   T* oo = dy + z * gs;
   T* go = GOUT ? gout + z * gs : nullptr;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += stride) {
+  for (; i < total_chunks; i += stride) {
     float d[VEC], v[VEC], m[VEC];
-    Vec16<T>::unpack(*(const uint4*)(dd + i * VEC), d);
-    Vec16<T>::unpack(*(const uint4*)(yy + i * VEC), v);
+    Vec16<T>::unpack(dnext, d);
+    Vec16<T>::unpack(ynext, v);
+    if (MASK == 1) Vec16<T>::unpack(anext, m);
+    if (i + stride < total_chunks) {                          // the next chunk is in flight while this one is finished
+      dnext = *(const uint4*)(dd + (i + stride) * VEC);
+      ynext = *(const uint4*)(yy + (i + stride) * VEC);
+      if (MASK == 1) anext = *(const uint4*)(aa + (i + stride) * VEC);
+    }
     if (MASK == 1) {
-      Vec16<T>::unpack(*(const uint4*)(aa + i * VEC), m);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) d[e] = m[e] > 0.f ? d[e] : 0.f;
     } else if (MASK == 2) {
