@@ -853,9 +853,12 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_tiled_kernel(const T* __res
   }
 }
 
-// the totals kernels pay a prologue per workgroup: fewer, longer-lived workgroups than the plain passes
-static int tot_blocks(int64_t chunks) {
-  static const int64_t cap = getenv("IEEE_BN_TOTALS_BLOCKS") ? atoll(getenv("IEEE_BN_TOTALS_BLOCKS")) : 1024;
+// the totals kernels pay a prologue per workgroup: fewer, longer-lived workgroups than the plain passes -- ONE resident wave of
+// them (256 CUs x 8 workgroups of 256 threads, over the modalities of the launch).  B = 64 step, three interleaved rounds:
+// 256 per modality 14.60 ms, 384 14.50, 512 14.45, 682 14.43, 1024 14.46, 2048 14.80, 4096 15.05 (scripts/r4_ab.sh)
+static int tot_blocks(int64_t chunks, int64_t groups) {
+  static const int64_t fixed = getenv("IEEE_BN_TOTALS_BLOCKS") ? atoll(getenv("IEEE_BN_TOTALS_BLOCKS")) : 0;
+  const int64_t cap = fixed > 0 ? fixed : std::max<int64_t>(256, 2048 / std::max<int64_t>(groups, 1));
   int64_t b = (chunks + 255) / 256;
   if (b > cap) b = cap;
   if (b < 1) b = 1;
@@ -1145,7 +1148,7 @@ extern "C" int ieee_bn2d_fwd_totals(const void* y, const void* residual, void* o
                "bn2d_fwd_totals: totals / gamma / beta must be 16-byte aligned (group stride a multiple of 4 floats)");
   hipStream_t st = (hipStream_t)stream;
   const int64_t chunks = M * C / 8;
-  dim3 grid(out ? tot_blocks(chunks) : 1, (unsigned)groups);
+  dim3 grid(out ? tot_blocks(chunks, groups) : 1, (unsigned)groups);
   const bf16 *yb = (const bf16*)y, *rb = (const bf16*)residual;
   bf16* ob = (bf16*)out;
   uint8_t* bits = (uint8_t*)relu_bits;
@@ -1176,7 +1179,7 @@ extern "C" int ieee_bn2d_bwd_totals(const void* dout, const void* out_mask, cons
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t ev = (hipEvent_t)done_event;
   const int64_t chunks = M * C / 8;
-  dim3 grid(tot_blocks(chunks), (unsigned)groups);
+  dim3 grid(tot_blocks(chunks, groups), (unsigned)groups);
   const int variant = (out_mask ? 1 : (mask_from_y ? 2 : 0)) * 2 + (g_out ? 1 : 0);
 #define IEEE_BN_BWD_TOT(MASK, GOUT)                                                                                          \
   case MASK * 2 + (GOUT ? 1 : 0):                                                                                            \
