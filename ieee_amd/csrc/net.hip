@@ -131,6 +131,7 @@ struct Net {
   hipEvent_t pack_ev[2] = {nullptr, nullptr};
   const void* pack_uploaded_ws = nullptr;
   bool fused_bwd_state = false;   // survives between the staged ieee_net_backward_part calls
+  bool bwd_totals_fresh = false;  // the backward totals are zero (set by the training forward, cleared by the backward that uses them)
   bool bwd_totals_state = false;  // ... and: those sums went into the unit's fixed-point totals (tot_b), not into bn_partial
   bool stem_a_valid = false;      // "<stem>.a" holds the activation of the LAST forward (a training forward does not write it)
   // inference: the packed weights and every BatchNorm's scale / shift only depend on the parameters and running
@@ -866,8 +867,10 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
     if (training) N.eval_cache_valid = false;     // the step that follows changes parameters and running statistics
   }
   if (training) IEEE_HIP(hipMemsetAsync(P(N.tickets), 0, 512 * 4, (hipStream_t)st));   // arrival tickets of the fused finalizes
-  if (training && dt == IEEE_BF16 && totals_tiles() > 0)   // the units' fixed-point BatchNorm totals (forward AND backward) start at zero
+  if (training && dt == IEEE_BF16 && totals_tiles() > 0) {   // the units' fixed-point BatchNorm totals (forward AND backward) start at zero
     IEEE_HIP(hipMemsetAsync(ws + N.tot_begin, 0, N.tot_end - N.tot_begin, (hipStream_t)st));
+    N.bwd_totals_fresh = true;
+  }
   IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, 4, 3, st));
   // stem: conv7x7/2 -> BN -> ReLU -> maxpool3x3/2   (resnet.py:622-626)
   const ConvUnit& s = N.units[N.u_stem];
@@ -1057,7 +1060,15 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     IEEE_REQUIRE(false, "net_backward: the previous backward ended with unflushed weight-gradient reductions (a failed call?); "
                         "its gradients are incomplete -- run the step again");
   }
-  if (part <= 0) IEEE_TRY(backward_head(dlogits, dfeats));
+  if (part <= 0) {
+    // a SECOND backward over the same forward (e.g. two loss terms differentiated one after the other) must not add to
+    // the first one's totals: zero them again (the forward's totals were consumed by its BatchNorm passes)
+    if (dt == IEEE_BF16 && totals_tiles() > 0) {
+      if (!N.bwd_totals_fresh) IEEE_HIP(hipMemsetAsync(ws + N.tot_begin, 0, N.tot_end - N.tot_begin, (hipStream_t)st));
+      N.bwd_totals_fresh = false;
+    }
+    IEEE_TRY(backward_head(dlogits, dfeats));
+  }
   if (part == 0) return IEEE_OK;
   static const int first_block[5] = {0, 3, 7, 13, 16};   // layer1..4 start indices ([3,4,6,3] blocks)
   int hi = (int)N.blocks.size() - 1, lo = 0;

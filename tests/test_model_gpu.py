@@ -229,6 +229,28 @@ def test_batched_weight_gradient_reductions_leave_the_same_bits():
         assert digests[name] == digests["default"], name
 
 
+def test_a_second_backward_over_the_same_forward_leaves_the_same_gradients():
+    """the backward's BatchNorm sums are ADDED to fixed-point totals that the training forward zeroes: a second backward over
+    the same forward (a caller differentiating two terms one after the other) zeroes them again instead of adding to the first
+    one's sums"""
+    B = 8
+    m = make_model(5, dtype=torch.bfloat16).train()
+    xs = [x.cuda() for x in images(B, 5)]
+    net = m.native_net(B, 256, 128)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dl = torch.randn(18, B, C, generator=g, device="cuda") * 1e-2
+    df = torch.randn(3, B, 768, generator=g, device="cuda") * 1e-2
+    m._bump_counters()
+    net.forward(xs, training=True)
+    got = []
+    for _ in range(2):
+        m._flat_grads.zero_()
+        net.backward(dl, df)
+        torch.cuda.synchronize()
+        got.append(m._flat_grads.clone())
+    assert torch.equal(got[0], got[1]) and float(got[0].abs().max()) > 0
+
+
 _GRAD_DUMP = r"""
 import hashlib, sys, numpy as np, torch
 sys.path.insert(0, %r)
