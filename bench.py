@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")    # before the HIP runtime starts: see ieee_amd/__init__.py
+
 import numpy as np
 import torch
 

@@ -5,4 +5,15 @@ the reference's Python surface (build_model / Image3MEngine /
 compute_distance_matrix / evaluate_rank).  There is no CPU fallback: every
 compute entry point raises if the HIP library or a gfx950 GPU is missing."""
 
+import os as _os
+
+# Hardware queues per stream priority (ROCclr's GPU_MAX_HW_QUEUES, default 4; read when the HIP runtime initialises, i.e. at
+# the first HIP call of the process -- import ieee_amd before touching torch.cuda).  The train step runs on 4-6 streams
+# (compute, weight gradients at low priority, branch, optimizer / communication, torch's high-priority collective stream);
+# with 4 or more queues per priority, and the collective stream created BEFORE the executor's streams -- the order of a
+# torchrun job -- the two main streams of the step stop overlapping on this runtime: 22.9 ms per step instead of 14.7
+# (8 and 16: 20.5-21 ms in either order; 1, 2 and 3: 14.5-15.1 in every order tried; scripts/dp_order_probe.py, DESIGN.md
+# section 6).  An explicit setting of the caller wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 __version__ = "0.1.0"

@@ -1,0 +1,76 @@
+"""The N > 1 run's ORDER of stream creation on one GPU: a 1-rank nccl (= RCCL) group is initialised and every gradient slice
+is all-reduced once BEFORE the first training step -- as bench.py does at N > 1 -- so torch's collective stream exists before
+the executor creates its weight-gradient / branch streams (in bench.py's N = 1 `dp_path` leg it is the other way round).
+Then, in ONE process, never having run the single-GPU step: overlapped and unoverlapped data-parallel steps, interleaved.
+  python scripts/dp_order_probe.py            (GPU box; PROBE_PRECREATE=1: two single-GPU steps before the group exists)
+Measured (ms per step, overlapped / unoverlapped form):   GPU_MAX_HW_QUEUES   collective stream first   executor first
+                                                                  1                 15.05 / 14.95          15.11 / 14.91
+                                                                  2                 14.73 / 14.62          14.67 / 14.78
+                                                                  3                 14.97 / 14.73          14.52 / 14.69
+                                                                  4 (runtime default) 22.94 / 24.19        14.93 / 15.06
+                                                                  8                 20.89 / 21.07          21.35 / 22.22
+                                                                 16                 20.48 / 21.77                      """
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ieee_amd  # noqa: E402,F401   (sets GPU_MAX_HW_QUEUES=2 unless the caller set it: pass GPU_MAX_HW_QUEUES=4 for the runtime's default)
+print("GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES"), flush=True)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29519")
+os.environ["IEEE_FORCE_DP_PATH"] = "1"
+torch.cuda.set_device(0)
+PRE = os.environ.get("PROBE_PRECREATE", "0")
+if PRE == "0":
+    dist.init_process_group("nccl", rank=0, world_size=1)
+from bench import _FakeDM, make_batch  # noqa: E402
+from ieee_amd.engine import Image3MEngine  # noqa: E402
+from ieee_amd.models import build_model  # noqa: E402
+from ieee_amd.optim import build_optimizer  # noqa: E402
+
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+model = build_model("ieee3modalPart", num_classes=171, loss="margin", pretrained=False, use_gpu=True, compute_dtype=torch.bfloat16, device=dev)
+opt = build_optimizer(model, optim="sgd", lr=1e-3, weight_decay=5e-4, momentum=0.9)
+eng = Image3MEngine(_FakeDM(171), model, opt, margin=1, weight_m=1, weight_x=1, use_gpu=True, label_smooth=True)
+eng.dp_presharded, eng.dp_total_rows, eng.resident_batch, eng.defer_summary = True, 64, True, True
+model.train()
+batch = make_batch(64, seed=0, device=dev)
+if PRE != "0":
+    # the executor's streams first: PRE=1 two single-GPU training steps, PRE=2 only ieee_amd.warm_streams()
+    if PRE == "1":
+        os.environ["IEEE_FORCE_DP_PATH"] = "0"
+        for _ in range(2):
+            eng.forward_backward(batch)
+        torch.cuda.synchronize()
+        os.environ["IEEE_FORCE_DP_PATH"] = "1"
+    else:
+        import ieee_amd
+        ieee_amd.warm_streams(model, 64)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+for ranges in model.grad_part_ranges():
+    for a, b in ranges:
+        dist.all_reduce(model._flat_grads[a:b], op=dist.ReduceOp.SUM)
+model._flat_grads.zero_()
+torch.cuda.synchronize()
+
+
+def run(overlap, n):
+    eng.dp_overlap = overlap
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(n):
+        eng.forward_backward(batch)
+    torch.cuda.synchronize()
+    return (time.time() - t0) / n * 1e3
+
+
+run(True, 25)
+run(False, 6)
+for r in range(3):
+    print("round %d: overlapped %.3f ms/step, unoverlapped %.3f ms/step" % (r, run(True, 15), run(False, 15)), flush=True)
+dist.destroy_process_group()
