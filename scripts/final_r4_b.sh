@@ -1,5 +1,5 @@
 # round-4 evidence, part B: per-launch table, PMC passes of the train step, per-layer table
-cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+cd "$(dirname "$0")/.." && export TMPDIR=/tmp && export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-2}
 O=gpurun_out/final_r4; mkdir -p $O
 IEEE_PROFILE_DUMP=$O/launches.csv python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-distmat --no-fp32 --no-loader --no-dp-path > $O/launch_bench.json 2> $O/launch_bench.err
 bash scripts/pmc_passes.sh $O/pmc --steps 3 --warmup 1 --no-roofline-pass --no-cpu-baseline --no-distmat --no-fp32 --no-loader --no-dp-path > $O/pmc.log 2>&1

@@ -1,5 +1,5 @@
 # round-4 evidence, part C: kernel stats of plain two-stream steps, stream phase table, evaluator counters, host enqueue time
-cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+cd "$(dirname "$0")/.." && export TMPDIR=/tmp && export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-2}
 O=gpurun_out/final_r4; mkdir -p $O
 bash scripts/in_situ_stats.sh $O/in_situ r04 > $O/in_situ.log 2>&1; tail -n 2 $O/in_situ.log
 python scripts/phase_table.py $O/in_situ/trace 8 > $O/phase.txt 2>&1; head -n 12 $O/phase.txt

@@ -1,6 +1,6 @@
 # kernel stats of PLAIN two-stream steps (no event passes in the trace): profiles/rNN_kernel_stats_in_situ.{csv,json}
 # usage: bash scripts/in_situ_stats.sh OUTDIR TAG   (GPU box)
-cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+cd "$(dirname "$0")/.." && export TMPDIR=/tmp && export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-2}
 O=${1:-gpurun_out/in_situ}; TAG=${2:-r04}; mkdir -p $O
 STEPS=20; WARM=5
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps $STEPS --warmup $WARM --no-roofline-pass --no-cpu-baseline --no-distmat --no-fp32 --no-dp-path --no-loader > $O/trace.log 2>&1

@@ -1,6 +1,6 @@
 # rocprofv3 counter passes of the training step (GPU box).  One counter group per pass, no trace domains beside --pmc.
 # usage: bash scripts/pmc_passes.sh OUTDIR [bench args]
-cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+cd "$(dirname "$0")/.." && export TMPDIR=/tmp && export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-2}
 OUT=${1:-gpurun_out/pmc_r2}; shift
 ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline --no-distmat --no-fp32 --no-loader --no-dp-path}
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 # rocprofv3 counter passes of the config-4 evaluator (GPU box); one counter group per pass
-cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+cd "$(dirname "$0")/.." && export TMPDIR=/tmp && export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-2}
 OUT=${1:-gpurun_out/pmc_eval}
 mkdir -p $OUT
 pass() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 scripts/evaluator_probe.py > $OUT/$name.log 2>&1; tail -1 $OUT/$name.log; }
