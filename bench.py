@@ -18,7 +18,8 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")    # before the HIP runtime starts: see ieee_amd/__init__.py
+# before the HIP runtime starts: see ieee_amd/__init__.py (2 hardware queues per stream priority on one GPU, 1 under torchrun)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "1" if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 else "2")
 
 import numpy as np
 import torch

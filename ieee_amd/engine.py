@@ -455,7 +455,12 @@ class _FusedStepMixin(object):
             # all parameters on the compute stream after the last collective).
             main = torch.cuda.current_stream()
             if not hasattr(self, "_comm_stream"):
-                self._comm_stream = torch.cuda.Stream()
+                # high priority in a real data-parallel job (with ONE hardware queue per priority, ieee_amd/__init__.py, it
+                # then shares torch's collective stream's queue and never the compute stream's: DESIGN.md section 6); normal
+                # priority in the single-GPU 1-rank leg of bench.py, where two queues per priority are on
+                prio = os.environ.get("IEEE_COMM_PRIO")
+                prio = int(prio) if prio is not None else (-1 if ddp.world_size() > 1 else 0)
+                self._comm_stream = torch.cuda.Stream(priority=prio)
             comm = self._comm_stream
             by_part = isinstance(self.optimizer, FusedSGD) and os.environ.get("IEEE_OPT_OVERLAP", "1") != "0"
             for part, ranges in enumerate(m.grad_part_ranges()):

@@ -59,6 +59,44 @@ model._flat_grads.zero_()
 torch.cuda.synchronize()
 
 
+FAKE_US = float(os.environ.get("PROBE_FAKE_COMM_US", "0"))
+if FAKE_US > 0:
+    # a collective that TAKES TIME, as on a real node: every all_reduce becomes a spin of PROBE_FAKE_COMM_US microseconds on a
+    # high-priority stream (torch's collective streams are), ordered behind the calling stream, whose handle's wait() orders
+    # the calling stream behind it -- ProcessGroupNCCL's semantics.  If the compute stream shares a hardware queue with the
+    # communication stream, its kernels queue up behind those waits and the step grows by the spins' total.
+    fake_stream = torch.cuda.Stream(priority=-1)
+    cycles_per_us = 100.0      # s_sleep-based: calibrated below
+
+    class _Handle:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def fake_all_reduce(t, op=None, async_op=False, group=None):
+        cur = torch.cuda.current_stream()
+        fake_stream.wait_stream(cur)
+        with torch.cuda.stream(fake_stream):
+            torch.cuda._sleep(int(FAKE_US * cycles_per_us))
+            ev = torch.cuda.Event()
+            ev.record(fake_stream)
+        h = _Handle(ev)
+        if not async_op:
+            h.wait()
+        return h
+
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1000)      # (first call: module load)
+    torch.cuda.synchronize(); a.record(); torch.cuda._sleep(1000000); b.record(); torch.cuda.synchronize()
+    cycles_per_us = 1000000 / (a.elapsed_time(b) * 1e3)
+    dist.all_reduce = fake_all_reduce
+    torch.distributed.all_reduce = fake_all_reduce
+    n_coll = sum(len(r) for r in model.grad_part_ranges())
+    print("fake collectives: %d per step x %.0f us = %.2f ms per step if nothing overlaps (%.0f spin cycles per us)" % (n_coll, FAKE_US, n_coll * FAKE_US / 1e3, cycles_per_us), flush=True)
+
+
 def run(overlap, n):
     eng.dp_overlap = overlap
     torch.cuda.synchronize()
