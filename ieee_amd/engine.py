@@ -459,7 +459,9 @@ class _FusedStepMixin(object):
                 # then shares torch's collective stream's queue and never the compute stream's: DESIGN.md section 6); normal
                 # priority in the single-GPU 1-rank leg of bench.py, where two queues per priority are on
                 prio = os.environ.get("IEEE_COMM_PRIO")
-                prio = int(prio) if prio is not None else (-1 if ddp.world_size() > 1 else 0)
+                # (with two or more queues per priority a busy high-priority communication stream beside torch's busy
+                # collective stream is the one combination that fell apart in the probe: high priority only with ONE queue)
+                prio = int(prio) if prio is not None else (-1 if ddp.world_size() > 1 and os.environ.get("GPU_MAX_HW_QUEUES") == "1" else 0)
                 self._comm_stream = torch.cuda.Stream(priority=prio)
             comm = self._comm_stream
             by_part = isinstance(self.optimizer, FusedSGD) and os.environ.get("IEEE_OPT_OVERLAP", "1") != "0"
