@@ -5,7 +5,8 @@ batches, config "Single-GPU MI355X: RGBNT201 256x128 batch=64, full CIM+REM+3M, 
 (weak scaling: 64 triples per rank), plus the evaluator's query x gallery distmat GFLOP/s.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
+  (N>1: that plain command starts its own N ranks, one process per GPU (ieee_amd.dist.launch); equally
+   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
 One "step" = one Image3MEngine.forward_backward over one resident batch (inputs already in HBM).
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (conv_gather_kernel: implicit
@@ -18,14 +19,17 @@ import os
 import sys
 import time
 
-# before the HIP runtime starts: see ieee_amd/__init__.py (2 hardware queues per stream priority on one GPU, 1 under torchrun)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "1" if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 else "2")
-
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# before the HIP runtime starts: ieee_amd/__init__.py picks the hardware queues per stream priority (2 on one GPU, 1 in a
+# multi-process job) unless the caller exported a value; the ranks this file starts itself (--gpus N from a plain `python`)
+# get the caller's value or 1
+_USER_QUEUES = os.environ.get("GPU_MAX_HW_QUEUES")
+import ieee_amd  # noqa: E402,F401
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
@@ -355,6 +359,13 @@ def main():
     ap.add_argument("--loader-workers", default="8,16,32", help="worker counts of the input-pipeline leg")
     args = ap.parse_args()
 
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1") or 1) == 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher -- N child interpreters, one rank per GPU, with
+        # the environment torchrun would give them (ieee_amd.dist.launch).  It never touches the GPU and nothing is exec'd;
+        # rank 0 inherits stdout (the JSON line), the other ranks' stdout goes to stderr; exit code = the first failure.
+        from ieee_amd import dist as ddp
+        sys.exit(ddp.launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, queues=_USER_QUEUES))
+
     # Only the JSON line may reach the caller's stdout: RCCL prints a version banner (through C stdio, flushed at exit) when
     # a communicator is created, and other libraries chat too.  From here on file descriptor 1 IS stderr; the line is written
     # to the saved descriptor at the very end.
@@ -363,7 +374,7 @@ def main():
     os.dup2(2, 1)
     from ieee_amd import _lib, dist as ddp
     world, rank, local = ddp.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torchrun for --gpus > 1"
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` or under torchrun with N ranks" % (args.gpus, world)
     _lib.require_gpu()
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
@@ -560,6 +571,9 @@ def main():
                    "summary_readback": "on first look (engine.defer_summary)" if engine.defer_summary else "inside every step"},
         "roofline": roofline,
     }
+    line["launch"] = {"how": "self-spawned" if os.environ.get("IEEE_LAUNCHED_BY") == "ieee_amd.dist.launch" else
+                      ("torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else ("single process" if world == 1 else "external")),
+                      "hw_queues": ieee_amd.HW_QUEUES, "grad_dtype": engine._grad_dtype() if world > 1 else None}
     if step_hbm is not None:
         line["step_hbm"] = step_hbm
     if rccl is not None:

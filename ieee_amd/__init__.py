@@ -17,14 +17,37 @@ import os as _os
 # with the communication stream (which runs at high priority there, beside torch's collective stream), so the gradient
 # all-reduces overlap the backward whatever order the streams were created in -- with 2 queues they overlap only when the
 # executor's streams exist before the process group's.  An explicit setting of the caller wins.
-if "GPU_MAX_HW_QUEUES" not in _os.environ:
+def _world_size():
+    try:
+        return int(_os.environ.get("WORLD_SIZE", "1") or 1)
+    except ValueError:
+        return 1
+
+
+def _decide_hw_queues():
+    """-> the queue count the HIP runtime of this process runs (or will start) with.  The variable is written only when the
+    runtime has not started yet: a value exported after that would describe a configuration the process is not in (the engine
+    picks the communication stream's priority from HW_QUEUES, not from the environment)."""
+    explicit = _os.environ.get("GPU_MAX_HW_QUEUES")
+    if explicit is not None:
+        try:
+            return int(explicit)
+        except ValueError:
+            return 4
     import sys as _sys
     _torch = _sys.modules.get("torch")
     if _torch is not None and getattr(_torch, "cuda", None) is not None and _torch.cuda.is_initialized():
         import warnings as _warnings
         _warnings.warn("ieee_amd: the HIP runtime of this process started before `import ieee_amd` could set GPU_MAX_HW_QUEUES; with the "
                        "runtime's default of 4 hardware queues per stream priority the train step's streams may not overlap (22.9 instead "
-                       "of 14.7 ms per step in a data-parallel job). Export GPU_MAX_HW_QUEUES=2 (1 under torchrun) or import ieee_amd first.")
-    _os.environ["GPU_MAX_HW_QUEUES"] = "1" if int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1 else "2"
+                       "of 14.7 ms per step in a data-parallel job). Export GPU_MAX_HW_QUEUES=2 (1 in a multi-process job) or import "
+                       "ieee_amd first.")
+        return 4
+    n = 1 if _world_size() > 1 else 2
+    _os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+    return n
+
+
+HW_QUEUES = _decide_hw_queues()
 
 __version__ = "0.1.0"

@@ -96,6 +96,14 @@ class NativeNet:
         """children whose BatchNorms run on their running statistics in a training forward (ieee_net_set_frozen)"""
         _lib.check(self.lib.ieee_net_set_frozen(self.handle, int(mask)))
 
+    def bn_overflow(self):
+        """(fwd tile clamped, bwd tile clamped, fwd total beyond half the range, bwd total beyond half the range) reported by
+        the range guard of the fixed-point BatchNorm totals since the last call (ieee_net_bn_overflow: read and clear; the
+        caller has synchronised with the steps it asks about)"""
+        out = (ctypes.c_int * 4)()
+        _lib.check(self.lib.ieee_net_bn_overflow(self.handle, out))
+        return tuple(out)
+
     def debug_taps(self, nbytes):
         """parity tests: allocate a tap buffer of nbytes and make the backward copy its gradient tensors into it
         (include/ieee_amd.h: ieee_net_debug_taps); nbytes = 0 switches the taps off"""

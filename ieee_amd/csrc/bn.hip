@@ -488,6 +488,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fixed_kernel(const T* __rest
 // against 14.83 ms with the finalize launches.
 constexpr double TOT_INV_FWD = 1.0 / 16777216.0;          // 2^-24
 constexpr double TOT_INV_BWD = 1.0 / 1099511627776.0;     // 2^-40
+// a total beyond HALF the range the conv kernels guarantee (+-2^62) is reported in overflow[2] (forward) / [3] (backward):
+// the next doubling of the activations would saturate tiles
+constexpr long long TOT_HALF_RANGE = 1ll << 61;
+__device__ __forceinline__ long long tot_abs(long long v) { return v < 0 ? -v : v; }
 
 template <typename T, bool RES, bool BITS>
 __global__ __launch_bounds__(256) void bn_apply_totals_kernel(const T* __restrict__ y, const T* __restrict__ residual,
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256) void bn_apply_totals_kernel(const T* __restric
                                                               int64_t buf_gs, float* __restrict__ stats, int M, float momentum,
                                                               float eps, int64_t total_chunks, int cprw, int C, int64_t gs,
                                                               int relu, uint8_t* __restrict__ relu_bits, double inv_m,
-                                                              float unbias, int rep, int64_t rep_stride) {
+                                                              float unbias, int rep, int64_t rep_stride, int* overflow) {
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
   uint8_t* bb = BITS ? relu_bits + z * (gs / 8) : nullptr;
@@ -522,6 +526,8 @@ __global__ __launch_bounds__(256) void bn_apply_totals_kernel(const T* __restric
       t1 += totals[r * rep_stride + (int64_t)z * 2 * C + c];
       t2 += totals[r * rep_stride + (int64_t)z * 2 * C + C + c];
     }
+    // (the conv clamps every tile to its share of +-2^62, so these sums cannot have wrapped: conv.hip, tl_totals_flag)
+    if (blockIdx.x == 0 && overflow != nullptr && (tot_abs(t1) > TOT_HALF_RANGE || tot_abs(t2) > TOT_HALF_RANGE)) *(volatile int*)(overflow + 2) = 1;
     const float ga = gamma[z * param_gs + c], be = beta[z * param_gs + c];
     const double mu = (double)t1 * inv_m;                    // inv_m = 2^-24 / M
     double var = (double)t2 * inv_m - mu * mu;
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_totals_kernel(const T* __res
                                                                   const float* __restrict__ stats, float* dgamma,
                                                                   float* dbeta, int64_t grad_gs, int M, int64_t total_chunks,
                                                                   int cprw, int C, int64_t gs, double inv_m, int rep,
-                                                                  int64_t rep_stride) {
+                                                                  int64_t rep_stride, int* overflow) {
   constexpr int VEC = 16 / sizeof(T);
   const int z = blockIdx.y;
   const int c0 = (threadIdx.x & (cprw - 1)) * VEC;
@@ -607,6 +613,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_totals_kernel(const T* __res
       t1 += totals[r * rep_stride + (int64_t)z * 2 * C + c];
       t2 += totals[r * rep_stride + (int64_t)z * 2 * C + C + c];
     }
+    if (blockIdx.x == 0 && overflow != nullptr && (tot_abs(t1) > TOT_HALF_RANGE || tot_abs(t2) > TOT_HALF_RANGE)) *(volatile int*)(overflow + 3) = 1;
     const double s1 = (double)t1 * TOT_INV_BWD, s2 = (double)t2 * TOT_INV_BWD;
     const double mean = st[c], invstd = st[C + c];
     const double sgx = invstd * (s2 - mean * s1);            // sum g * xhat
@@ -1137,7 +1144,8 @@ extern "C" int ieee_bn2d_bwd_frozen(const void* dout, const void* out_mask, cons
 extern "C" int ieee_bn2d_fwd_totals(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
                                     int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
                                     float* running_mean, float* running_var, int64_t buf_gs, float* stats, const void* totals,
-                                    int replicas, float momentum, float eps, int relu, void* relu_bits, void* stream) {
+                                    int replicas, float momentum, float eps, int relu, void* relu_bits, int* overflow,
+                                    void* stream) {
   IEEE_REQUIRE(replicas >= 1 && replicas <= 64, "bn2d_fwd_totals: 1..64 replicas");
   IEEE_REQUIRE(y && gamma && beta && stats && totals, "bn2d_fwd_totals: null pointer");
   IEEE_REQUIRE(dtype == IEEE_BF16, "bn2d_fwd_totals: bf16 only (the fused statistics exist on the bf16 path)");
@@ -1155,7 +1163,7 @@ extern "C" int ieee_bn2d_fwd_totals(const void* y, const void* residual, void* o
 #define IEEE_BN_TOT(RES, BITS)                                                                                              \
   bn_apply_totals_kernel<bf16, RES, BITS><<<grid, 256, 2 * C * sizeof(float), st>>>(yb, rb, ob, (const long long*)totals, gamma, beta, param_gs, \
       running_mean, running_var, buf_gs, stats, (int)M, momentum, eps, chunks, cprw, (int)C, act_gs, relu, bits,       \
-      TOT_INV_FWD / (double)M, M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f, replicas, groups * 2 * C)
+      TOT_INV_FWD / (double)M, M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f, replicas, groups * 2 * C, overflow)
   if (residual && bits) IEEE_BN_TOT(true, true);
   else if (residual) IEEE_BN_TOT(true, false);
   else if (bits) IEEE_BN_TOT(false, true);
@@ -1168,7 +1176,8 @@ extern "C" int ieee_bn2d_fwd_totals(const void* y, const void* residual, void* o
 extern "C" int ieee_bn2d_bwd_totals(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
                                     int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma,
                                     int64_t param_gs, const float* stats, float* dgamma, float* dbeta, int64_t grad_gs,
-                                    const void* totals, int replicas, int mask_from_y, void* done_event, void* stream) {
+                                    const void* totals, int replicas, int mask_from_y, int* overflow, void* done_event,
+                                    void* stream) {
   IEEE_REQUIRE(replicas >= 1 && replicas <= 64, "bn2d_bwd_totals: 1..64 replicas");
   IEEE_REQUIRE(dout && y && dy && gamma && stats && totals, "bn2d_bwd_totals: null pointer");
   IEEE_REQUIRE(dtype == IEEE_BF16, "bn2d_bwd_totals: bf16 only");
@@ -1187,7 +1196,7 @@ extern "C" int ieee_bn2d_bwd_totals(const void* dout, const void* out_mask, cons
                           nullptr, ev, 0,                                                                                    \
                           (const bf16*)dout, (const bf16*)out_mask, (const bf16*)y, (bf16*)dy, (bf16*)g_out,                 \
                           (const long long*)totals, gamma, param_gs, stats, dgamma, dbeta, grad_gs, (int)M, chunks, cprw,    \
-                          (int)C, act_gs, 1.0 / (double)M, replicas, groups * 2 * C);                                        \
+                          (int)C, act_gs, 1.0 / (double)M, replicas, groups * 2 * C, overflow);                              \
     break;
   switch (variant) {
     IEEE_BN_BWD_TOT(0, false) IEEE_BN_BWD_TOT(0, true) IEEE_BN_BWD_TOT(1, false) IEEE_BN_BWD_TOT(1, true)

@@ -6,6 +6,7 @@
 // launch: blockIdx.y = modality, pointers advance by per-modality strides.
 // Replaces torch's conv2d / conv2d backward as dispatched from the reference's
 // torchreid/models/resnet.py:164-184,622-631 and ieee3modalPart.py:427-435.
+#include <math.h>
 #include <stdlib.h>
 
 #include <hip/hip_ext.h>
@@ -31,15 +32,27 @@ thread_local hipEvent_t tl_time_start = nullptr, tl_time_stop = nullptr;
 thread_local long long* tl_totals = nullptr;
 thread_local int64_t tl_totals_gs = 0;
 thread_local int tl_totals_rep = 1;   // replicas of the totals (a power of two): tile t adds to replica t % rep -- fewer adders per address
+// Range guard (round 5).  An int64 total wraps silently; the reference's fp32 batch_norm (torchreid/models/resnet.py:164-184)
+// would return finite numbers or inf there.  So: a tile may contribute at most 2^62 / (row tiles of the launch) units -- the sum
+// of ALL tiles, replicas included, then cannot leave +-2^62 and never wraps -- and a tile sum beyond that share (or NaN) is
+// clamped AND reported: overflow[0] (forward sums) / overflow[1] (backward sums) = 1, plain stores to a word the caller owns
+// (the executor: host-visible memory it looks at when it reads the step's summary).  The BatchNorm passes report a total
+// beyond half the range (2^61) in overflow[2] / overflow[3] (bn.hip).  Nothing is paid unless the compare fails.
+thread_local int* tl_totals_flag = nullptr;
+constexpr float TOT_RANGE = 4611686018427387904.0f;   // 2^62
 // whatever a conv entry point returns, nothing stays armed for a later launch of the thread (a call that fails its argument
 // checks must not leave its totals / timing events to the next one)
 struct OneShotArms {
-  ~OneShotArms() { tl_totals = nullptr; tl_totals_rep = 1; tl_time_start = tl_time_stop = nullptr; }
+  ~OneShotArms() { tl_totals = nullptr; tl_totals_flag = nullptr; tl_totals_rep = 1; tl_time_start = tl_time_stop = nullptr; }
 };
 constexpr float TOT_SCALE_FWD = 16777216.0f;          // 2^24
 constexpr float TOT_SCALE_BWD = 1099511627776.0f;     // 2^40
-__device__ __forceinline__ long long to_fixed(float v, float scale) {
-  const float x = fminf(fmaxf(v * scale, -9.0e18f), 9.0e18f);
+__device__ __forceinline__ long long to_fixed(float v, float scale, float lim, int* flag) {
+  float x = v * scale;
+  if (!(fabsf(x) <= lim)) {                      // beyond this tile's share of the range, or NaN
+    if (flag != nullptr) *(volatile int*)flag = 1;
+    x = fminf(fmaxf(x, -lim), lim);              // (NaN -> -lim; the NaN itself reaches the output through y)
+  }
   return __float2ll_rn(x);
 }
 
@@ -158,6 +171,8 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
   const T* by2 = nullptr;     // MODE 2: second BatchNorm input fed by the same g (BwdStats::y2) ...
   float* bn_partial2 = nullptr;   // ... and this group's [2][N][tiles_m] block for it (sum g, sum g*y2)
   long long* tot = nullptr;   // this group's [2][N] fixed-point totals (BwdStats::tot); non-null: atomics instead of bn_partial
+  int* tot_flag = nullptr;    // the word a tile sum beyond tot_lim units is reported in (see tl_totals_flag)
+  float tot_lim = TOT_RANGE;
   __device__ __forceinline__ int tile_pixel0(int m0) const {   // pixel of the tile's first row (class offsets included)
     const int per_img = phc * pwc, per_cls = pnimg * per_img;
     const int cls = m0 / per_cls, rc = m0 - cls * per_cls, n = rc / per_img, i0 = (rc - n * per_img) >> pwl;
@@ -355,7 +370,8 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
         for (int y = 0; y < RPP; ++y) s += col[y * CPRW];
         if (n0 + c < N && tile_m < tiles_m) {
           if (tot != nullptr) {   // order-independent total (see tl_totals): no-return atomic, nothing to wait for
-            (void)__hip_atomic_fetch_add(tot + (int64_t)q * N + n0 + c, to_fixed(s, MODE == 1 ? TOT_SCALE_FWD : TOT_SCALE_BWD),
+            (void)__hip_atomic_fetch_add(tot + (int64_t)q * N + n0 + c,
+                                         to_fixed(s, MODE == 1 ? TOT_SCALE_FWD : TOT_SCALE_BWD, tot_lim, tot_flag),
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
           }
@@ -520,6 +536,8 @@ struct BwdStats {            // MODE 2 operands (per-group strides in elements /
   int64_t tot_gs = 0;           //             bn_partial (see tl_totals)
   int tot_rep = 1;              //             replicas [tot_rep][groups][2][N]: row tile tm adds to replica tm % tot_rep
   int64_t tot_rs = 0;           //             elements between replicas
+  int* tot_flag = nullptr;      //             overflow report word of this direction (tl_totals_flag + 0 / + 1), may be null
+  float tot_lim = TOT_RANGE;    //             a tile's share of the range: 2^62 / row tiles of the launch
 };
 
 // MODE 1: hand the epilogue its group's finalize operands
@@ -558,7 +576,9 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
                               ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
   if constexpr (MODE == 3) epi.relu = bs.relu;
   if constexpr (MODE == 1) set_fin(epi, bs, z, tn, a.tiles_n, a.N);
-  if constexpr (MODE == 1 || MODE == 2) { if (bs.tot != nullptr) epi.tot = bs.tot + z * bs.tot_gs + (tm & (bs.tot_rep - 1)) * bs.tot_rs; }
+  if constexpr (MODE == 1 || MODE == 2) {
+    if (bs.tot != nullptr) { epi.tot = bs.tot + z * bs.tot_gs + (tm & (bs.tot_rep - 1)) * bs.tot_rs; epi.tot_flag = bs.tot_flag; epi.tot_lim = bs.tot_lim; }
+  }
   if constexpr (VAR == 2) { epi.as_wl = __ffs(a.g.Wo) - 1; epi.as_hl = __ffs(a.g.Ho) - 1; }
   if constexpr (MODE == 2) {
     if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
@@ -653,7 +673,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const bf16* __res
                                     ((MODE == 2 || MODE == 3) && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
   if constexpr (MODE == 3) epi.relu = bs.relu;
   if constexpr (MODE == 1) set_fin(epi, bs, z, tn, a.tiles_n, a.N);
-  if constexpr (MODE == 1 || MODE == 2) { if (bs.tot != nullptr) epi.tot = bs.tot + z * bs.tot_gs + (tm & (bs.tot_rep - 1)) * bs.tot_rs; }
+  if constexpr (MODE == 1 || MODE == 2) {
+    if (bs.tot != nullptr) { epi.tot = bs.tot + z * bs.tot_gs + (tm & (bs.tot_rep - 1)) * bs.tot_rs; epi.tot_flag = bs.tot_flag; epi.tot_lim = bs.tot_lim; }
+  }
   if constexpr (MODE == 2) {
     if (bs.mask && bs.mask_bits) epi.bbits = (const uint8_t*)bs.mask + z * (bs.act_gs >> 3);
     if (bs.y2) { epi.by2 = (decltype(epi.by2))bs.y2 + z * bs.act_gs; epi.bn_partial2 = bs.partial2 + (int64_t)z * a.tiles_m * 2 * a.N; }
@@ -1730,8 +1752,13 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   BwdStats bs{nullptr, nullptr, nullptr, 0, 0, 0};
   if (bwd) bs = *bwd;
   if (tl_totals != nullptr) {      // armed by ieee_conv_next_bn_totals for this launch
-    if (stats && bs.y2 == nullptr && !(fin != nullptr && fin->on)) { bs.tot = tl_totals; bs.tot_gs = tl_totals_gs; bs.tot_rep = tl_totals_rep; bs.tot_rs = tl_totals_gs * groups; }
+    if (stats && bs.y2 == nullptr && !(fin != nullptr && fin->on)) {
+      bs.tot = tl_totals; bs.tot_gs = tl_totals_gs; bs.tot_rep = tl_totals_rep; bs.tot_rs = tl_totals_gs * groups;
+      bs.tot_flag = tl_totals_flag != nullptr ? tl_totals_flag + (bwd ? 1 : 0) : nullptr;
+      bs.tot_lim = nextafterf(TOT_RANGE / (float)cdiv(M, 128), 0.f);   // (rounded DOWN: tiles * lim <= 2^62 exactly)
+    }
     tl_totals = nullptr;
+    tl_totals_flag = nullptr;
   }
   if (fin != nullptr && fin->on) {
     if (!(sizeof(T) == 2 && !slow && stats && !bwd && !affine && cdiv(M, 128) <= FIN_MAX_TILES && a.g.Cs != 4)) {
@@ -2293,9 +2320,10 @@ extern "C" int ieee_conv_profile_events(void* start, void* stop) {
  * the caller zeroes them; row tile t adds to replica t % replicas, a power of two <= 64) with no-return atomics instead of
  * writing per-tile partials; ieee_bn2d_fwd_totals / ieee_bn2d_bwd_totals add the replicas up.  NULL cancels.  The stem
  * (4 096 row tiles per modality) ignores it. */
-extern "C" int ieee_conv_next_bn_totals(void* totals, int64_t group_stride, int replicas) {
+extern "C" int ieee_conv_next_bn_totals(void* totals, int64_t group_stride, int replicas, int* overflow) {
   IEEE_REQUIRE(replicas >= 1 && replicas <= 64 && (replicas & (replicas - 1)) == 0, "conv_next_bn_totals: replicas must be a power of two <= 64");
   ieee::tl_totals = (long long*)totals;
+  ieee::tl_totals_flag = totals != nullptr ? overflow : nullptr;
   ieee::tl_totals_gs = group_stride;
   ieee::tl_totals_rep = replicas;
   return IEEE_OK;

@@ -131,6 +131,10 @@ struct Net {
   hipEvent_t pack_ev[2] = {nullptr, nullptr};
   const void* pack_uploaded_ws = nullptr;
   bool fused_bwd_state = false;   // survives between the staged ieee_net_backward_part calls
+  // range guard of the fixed-point totals (conv.hip: tl_totals_flag): 4 ints in HOST memory the device can write (plain stores
+  // on the overflow path only).  The kernels of a step set them, ieee_net_bn_overflow reads and clears them on the host after
+  // the caller has synchronised with the step -- no launch, no copy, nothing on the queues.
+  int* bn_overflow = nullptr;
   bool bwd_totals_fresh = false;  // the backward totals are zero (set by the training forward, cleared by the backward that uses them)
   bool bwd_totals_state = false;  // ... and: those sums went into the unit's fixed-point totals (tot_b), not into bn_partial
   bool stem_a_valid = false;      // "<stem>.a" holds the activation of the LAST forward (a training forward does not write it)
@@ -167,6 +171,7 @@ struct Net {
     if (side) (void)hipStreamDestroy(side);
     for (hipEvent_t e : branch_ev) if (e) (void)hipEventDestroy(e);
     if (side2) (void)hipStreamDestroy(side2);
+    if (bn_overflow) (void)hipHostFree(bn_overflow);
   }
   Tensor Gp, avgmax, amax, Hh, Hs, att, Pp, Zg, Zp, glob, part, sv_g, sv_p, rr, part2, fcraw, sv_fc, featcat, fcall,
       logits, featn, norms;
@@ -503,7 +508,7 @@ struct Run {
     const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
     fused_stats = want_stats && n.dtype == IEEE_BF16 && !frz(u);
     fwd_totals = fused_stats && use_totals(u);
-    if (fwd_totals) IEEE_TRY(ieee_conv_next_bn_totals(P(u.tot_f), (int64_t)2 * u.Co, totals_rep(u)));
+    if (fwd_totals) IEEE_TRY(ieee_conv_next_bn_totals(P(u.tot_f), (int64_t)2 * u.Co, totals_rep(u), n.bn_overflow));
     // (off by default: correct and bit-reproducible, but measured SLOWER -- 15.40 -> 15.91 ms per step: every workgroup of the
     // conv has to drain its output stores before it may take its ticket, which costs the conv more than the launch saves)
     static const bool f_fin = getenv("IEEE_BN_FIN_FUSE") && atoi(getenv("IEEE_BN_FIN_FUSE")) != 0;
@@ -522,7 +527,8 @@ struct Run {
     if (training && fwd_totals) {  // statistics in u.tot_f: finalize + apply in one launch
       fwd_totals = fused_stats = fused_fin = false;
       return ieee_bn2d_fwd_totals(P(u.y), residual, out, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b), gs(u.s_g),
-                                  buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), P(u.tot_f), totals_rep(u), n.bn_mom, n.bn_eps, relu, relu_bits, st);
+                                  buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), P(u.tot_f), totals_rep(u), n.bn_mom, n.bn_eps, relu, relu_bits,
+                                  n.bn_overflow, st);
     }
     fwd_totals = false;
     const int64_t rb = (training && fused_fin) ? -1 : ((training && fused_stats) ? ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) : 0);
@@ -580,7 +586,8 @@ struct Run {
                                   mask_from_y, (void*)bn_done, st);
     if (from_totals)   // the dgrad that produced `dout` added sum g, sum g*y to u.tot_b: finalize + apply in one launch
       return ieee_bn2d_bwd_totals(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
-                                  F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), P(u.tot_b), totals_rep(u), mask_from_y, (void*)bn_done, st);
+                                  F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), P(u.tot_b), totals_rep(u), mask_from_y, n.bn_overflow,
+                                  (void*)bn_done, st);
     return ieee_bn2d_bwd_ev(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
                             F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, bncoef_cur, 0, mask_from_y, rb,
                             (void*)bn_done, st);
@@ -768,7 +775,7 @@ struct Run {
     const bool fuse2 = fuse && prev_ds != nullptr && ds_sums && !branch_enabled(2);
     fused_bwd = fuse;
     n.bwd_totals_state = fuse && !fuse2 && use_totals(*prev) && !frz(*prev);
-    if (n.bwd_totals_state) IEEE_TRY(ieee_conv_next_bn_totals(P(prev->tot_b), (int64_t)2 * prev->Co, totals_rep(*prev)));
+    if (n.bwd_totals_state) IEEE_TRY(ieee_conv_next_bn_totals(P(prev->tot_b), (int64_t)2 * prev->Co, totals_rep(*prev), n.bn_overflow));
     if (fuse2) ds_sums_of = prev_ds;     // (consumed, and cleared, by that unit's bn_bwd in the next block)
     will_write(dx);
     prof_begin(0, u, "dgrad");
@@ -868,6 +875,10 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
   }
   if (training) IEEE_HIP(hipMemsetAsync(P(N.tickets), 0, 512 * 4, (hipStream_t)st));   // arrival tickets of the fused finalizes
   if (training && dt == IEEE_BF16 && totals_tiles() > 0) {   // the units' fixed-point BatchNorm totals (forward AND backward) start at zero
+    if (N.bn_overflow == nullptr) {
+      IEEE_HIP(hipHostMalloc((void**)&N.bn_overflow, 4 * sizeof(int), hipHostMallocMapped));
+      for (int i = 0; i < 4; ++i) N.bn_overflow[i] = 0;
+    }
     IEEE_HIP(hipMemsetAsync(ws + N.tot_begin, 0, N.tot_end - N.tot_begin, (hipStream_t)st));
     N.bwd_totals_fresh = true;
   }
@@ -1518,6 +1529,16 @@ extern "C" int ieee_net_set_frozen(void* handle, int mask) {
   Net* n = as_net(handle);
   IEEE_REQUIRE(n && mask >= 0 && mask < 128, "net_set_frozen: bad arguments");
   n->frozen = mask;
+  return IEEE_OK;
+}
+
+extern "C" int ieee_net_bn_overflow(void* handle, int* out4) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && out4, "net_bn_overflow: null pointer");
+  for (int i = 0; i < 4; ++i) {
+    out4[i] = n->bn_overflow != nullptr ? ((volatile int*)n->bn_overflow)[i] : 0;
+    if (n->bn_overflow != nullptr) ((volatile int*)n->bn_overflow)[i] = 0;
+  }
   return IEEE_OK;
 }
 

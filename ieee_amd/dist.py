@@ -265,3 +265,104 @@ def sharded_evaluate_rank(qf, gf, q_pids, g_pids, q_camids, g_camids, max_rank=2
         vec = vec.cpu()
     v = vec.numpy()
     return rank_mod.finish_counts(np.rint(v[:max_rank]).astype(np.int64), float(v[max_rank]), float(v[max_rank + 1]))
+
+
+# ---- launching: one process per GPU from a plain `python script.py` ------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_env(rank_, world, port, base=None, queues=None):
+    """environment of rank `rank_` of a `world`-process job on THIS node: what torchrun would export, plus ONE hardware
+    queue per stream priority (ieee_amd/__init__.py) unless the caller exported a value of their own (`queues`)"""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank_), LOCAL_RANK=str(rank_), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env["GPU_MAX_HW_QUEUES"] = str(queues) if queues else "1"
+    env["IEEE_LAUNCHED_BY"] = "ieee_amd.dist.launch"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs between processes on this driver
+    return env
+
+
+def _reap(procs, alive, poll, grace, timeout, kill):
+    """wait for the children; when one fails the others (stuck in a collective with a dead peer) get `grace` seconds and are
+    then ended through their own handles.  Returns 0 when every rank succeeded, else the exit code of the rank that failed
+    FIRST (128 + signal number when a signal ended it), 124 when `timeout` seconds ran out."""
+    import time
+    t0, first_bad, deadline, timed_out = time.time(), None, None, False
+    while True:
+        running = [p for p in procs if alive(p)]
+        if first_bad is None:
+            bad = [poll(p) for p in procs if not alive(p) and poll(p) not in (0, None)]
+            if bad:
+                first_bad, deadline = bad[0], time.time() + grace
+        if not running:
+            break
+        now = time.time()
+        if timeout and deadline is None and now - t0 > timeout:
+            timed_out, deadline = True, now
+        if deadline is not None and now >= deadline:
+            for p in running:
+                kill(p)
+            deadline = float("inf")                      # ended once: now only wait for them to go
+        time.sleep(0.05)
+    if timed_out:
+        return 124
+    if first_bad is None:
+        return 0
+    return 128 - first_bad if first_bad < 0 else first_bad
+
+
+def launch(target, nprocs, args=(), port=None, queues=None, timeout=None, grace=15.0):
+    """Start `nprocs` ranks on this node, one process per GPU, and wait for them: the replacement for the reference's
+    single-process `nn.DataParallel(model).cuda()` (scripts/mainMultiModal.py:219-220) that needs no launcher.
+
+      launch([sys.executable, "train.py", ...], 8)     an argv: every rank runs it with RANK / LOCAL_RANK / WORLD_SIZE /
+                                                       MASTER_ADDR / MASTER_PORT / GPU_MAX_HW_QUEUES=1 in its environment;
+                                                       rank 0 keeps this process's stdout, the others write theirs to stderr
+      launch(fn, 8, args=(cfg,))                       a picklable callable: fn(rank, world, *args) in freshly SPAWNED
+                                                       interpreters (never fork: a forked child of a process with a live HIP
+                                                       context costs 364 ms per step while it lives)
+
+    The calling process must not have touched the GPU and is not replaced (nothing is exec'd): it only waits, and returns
+    the worst exit code (0 = every rank succeeded).  When a rank dies the others are given `grace` seconds, then ended."""
+    import subprocess
+    import sys
+    nprocs = int(nprocs)
+    if nprocs < 1:
+        raise ValueError("launch: nprocs must be >= 1")
+    if "torch" in sys.modules and torch.cuda.is_initialized():
+        raise RuntimeError("ieee_amd.dist.launch: this process already holds a HIP context; start the ranks before touching "
+                           "the GPU (the parent only waits for them)")
+    port = port or _free_port()
+    if callable(target):
+        import multiprocessing
+        ctx = multiprocessing.get_context("spawn")
+        procs = []
+        saved = dict(os.environ)
+        try:
+            for r in range(nprocs):
+                os.environ.clear()                   # spawn copies the parent's environment at start()
+                os.environ.update(rank_env(r, nprocs, port, base=saved, queues=queues))
+                p = ctx.Process(target=_call_rank, args=(target, r, nprocs, tuple(args)), daemon=False)
+                p.start()
+                procs.append(p)
+        finally:
+            os.environ.clear()
+            os.environ.update(saved)
+        return _reap(procs, lambda p: p.is_alive(), lambda p: p.exitcode, grace, timeout, lambda p: p.kill())
+    argv = list(target) + list(args)
+    procs = []
+    for r in range(nprocs):
+        out = None if r == 0 else sys.stderr         # one JSON line / one report on stdout, not one per rank
+        procs.append(subprocess.Popen(argv, env=rank_env(r, nprocs, port, queues=queues), stdout=out))
+    return _reap(procs, lambda p: p.poll() is None, lambda p: p.poll(), grace, timeout, lambda p: p.kill())
+
+
+def _call_rank(fn, rank_, world, args):
+    fn(rank_, world, *args)

@@ -383,7 +383,7 @@ class _FusedStepMixin(object):
         m = self.model
         B, _, H, W = imgs[0].shape
         dev = m._flat_params.device
-        net = m.native_net(B, H, W)
+        net = self._step_net = m.native_net(B, H, W)
         pids = pids.to(device=dev, dtype=torch.int64).contiguous()
         m._bump_counters()
         logits, feats = net.forward(imgs, training=True)
@@ -436,10 +436,7 @@ class _FusedStepMixin(object):
             overlap = os.environ.get("IEEE_DP_OVERLAP", "1") != "0"
         if staged and not overlap:
             net.backward(dl, df)
-            handles = [torch.distributed.all_reduce(m._flat_grads[a:b], op=torch.distributed.ReduceOp.SUM, async_op=True)
-                       for ranges in m.grad_part_ranges() for a, b in ranges]
-            for h in handles:
-                h.wait()                         # orders the compute stream (not the host) after the collectives
+            self._allreduce_ranges(m, [r for ranges in m.grad_part_ranges() for r in ranges])
         elif not staged:
             net.backward(dl, df)
         else:
@@ -461,7 +458,8 @@ class _FusedStepMixin(object):
                 prio = os.environ.get("IEEE_COMM_PRIO")
                 # (with two or more queues per priority a busy high-priority communication stream beside torch's busy
                 # collective stream is the one combination that fell apart in the probe: high priority only with ONE queue)
-                prio = int(prio) if prio is not None else (-1 if ddp.world_size() > 1 and os.environ.get("GPU_MAX_HW_QUEUES") == "1" else 0)
+                from . import HW_QUEUES         # what the runtime really runs with (not what the environment says now)
+                prio = int(prio) if prio is not None else (-1 if ddp.world_size() > 1 and HW_QUEUES == 1 else 0)
                 self._comm_stream = torch.cuda.Stream(priority=prio)
             comm = self._comm_stream
             by_part = isinstance(self.optimizer, FusedSGD) and os.environ.get("IEEE_OPT_OVERLAP", "1") != "0"
@@ -474,13 +472,10 @@ class _FusedStepMixin(object):
                     if timing is not None:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record(comm)
-                    handles = [torch.distributed.all_reduce(m._flat_grads[a:b], op=torch.distributed.ReduceOp.SUM, async_op=True)
-                               for a, b in ranges]
-                    for h in handles:
-                        h.wait()                 # orders the comm stream (not the host) after the collective
+                    self._allreduce_ranges(m, ranges)
                     if timing is not None:
                         e1.record(comm)
-                        timing.append((part, e0, e1, 4 * sum(b - a for a, b in ranges)))
+                        timing.append((part, e0, e1, (4 if self._grad_dtype() == 'fp32' else 2) * sum(b - a for a, b in ranges)))
                     if by_part:
                         self.optimizer.step_part(part)
             net.side_wait()                      # final join of the weight-gradient stream into the compute stream
@@ -489,6 +484,37 @@ class _FusedStepMixin(object):
                 return small, out3
         self.optimizer.step()
         return small, out3
+
+    def _grad_dtype(self):
+        """'fp32' (default: what the reference's DataParallel reduces) or 'bf16' (`engine.dp_grad_dtype` /
+        IEEE_DP_GRAD_DTYPE=bf16: half the bytes on the wire; every rank's slice is rounded to bf16 before the sum and the sum
+        itself is a bf16 sum -- relative error of a reduced element <= ~2^-8 * (1 + log2 world), tests/test_dist_cpu.py)"""
+        v = getattr(self, "dp_grad_dtype", None) or os.environ.get("IEEE_DP_GRAD_DTYPE", "fp32")
+        v = {"float32": "fp32", "bfloat16": "bf16"}.get(v, v)
+        if v not in ("fp32", "bf16"):
+            raise ValueError("IEEE_DP_GRAD_DTYPE / dp_grad_dtype must be fp32 or bf16, not %r" % (v,))
+        return v
+
+    def _allreduce_ranges(self, m, ranges):
+        """all-reduce (sum) of these [a, b) slices of the flat gradient, enqueued on the CURRENT stream; on return that
+        stream (not the host) is ordered after the collectives"""
+        ar = torch.distributed.all_reduce
+        if self._grad_dtype() == "fp32":
+            handles = [ar(m._flat_grads[a:b], op=torch.distributed.ReduceOp.SUM, async_op=True) for a, b in ranges]
+            for h in handles:
+                h.wait()
+            return
+        lib = _lib.load()
+        stage = getattr(m, "_flat_grads_bf16", None)
+        if stage is None or stage.numel() != m._flat_grads.numel() or stage.device != m._flat_grads.device:
+            stage = m._flat_grads_bf16 = torch.empty(m._flat_grads.numel(), dtype=torch.bfloat16, device=m._flat_grads.device)
+        for a, b in ranges:
+            _lib.check(lib.ieee_grad_pack_bf16(_lib.ptr(m._flat_grads[a:b]), _lib.ptr(stage[a:b]), b - a, _lib.stream()))
+        handles = [ar(stage[a:b], op=torch.distributed.ReduceOp.SUM, async_op=True) for a, b in ranges]
+        for h in handles:
+            h.wait()
+        for a, b in ranges:
+            _lib.check(lib.ieee_grad_unpack_bf16(_lib.ptr(stage[a:b]), _lib.ptr(m._flat_grads[a:b]), b - a, _lib.stream()))
 
     _RING = 4                            # pinned read-back buffers: the host runs at most _RING - 1 steps ahead
 
@@ -512,9 +538,12 @@ class _FusedStepMixin(object):
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(small.device))
 
+        net = getattr(self, "_step_net", None)
+
         def read():
             done.synchronize()
             slot[1] = None
+            self._check_bn_range(net)
             v = host.numpy().copy()
             hl, ha = v[:18], v[18:36]
             lR, lN, lT = float(hl[0:6].sum()), float(hl[6:12].sum()), float(hl[12:18].sum())
@@ -525,6 +554,33 @@ class _FusedStepMixin(object):
             return read()
         slot[1] = DeferredSummary(keys, read)
         return slot[1]
+
+    def _check_bn_range(self, net):
+        """The bf16 train step keeps its BatchNorm sums as int64 fixed-point totals (include/ieee_amd.h,
+        ieee_conv_next_bn_totals): bit-reproducible, but with a RANGE (forward sum y^2 up to 2.7e11 per channel, backward sums up
+        to 4.2e6) that torch's fp32 batch_norm (reference: torchreid/models/resnet.py:164-184) does not have.  The kernels
+        clamp and report instead of wrapping; this is where the report reaches the caller -- at the step's (possibly deferred)
+        summary read, on the host, without a launch or a copy.  A clamped tile means the statistics of that step were wrong:
+        raise.  A total beyond half the range is still exact: warn once."""
+        if net is None:
+            return
+        f_clamp, b_clamp, f_half, b_half = net.bn_overflow()
+        if f_clamp or b_clamp:
+            which = " and ".join(w for w, on in (("forward (sum y, sum y^2 of a conv output)", f_clamp),
+                                                 ("backward (sum g, sum g*y)", b_clamp)) if on)
+            raise _lib.IeeeAmdError(
+                "BatchNorm statistics left the range of the fixed-point totals in the %s pass of a recent step (or were NaN): "
+                "the int64 totals hold sum y^2 up to 2.7e11 and backward sums up to 4.2e6 per channel; beyond that a tile sum is "
+                "clamped, so the statistics -- and the parameters updated from them -- are not what fp32 BatchNorm gives. "
+                "Activations / gradients of that size mean the run is diverging; to train through it anyway set "
+                "IEEE_BN_TOTALS_TILES=0 (per-tile partial sums, no range limit) and restart from the last checkpoint." % which)
+        if (f_half or b_half) and not getattr(self, "_bn_range_warned", False):
+            import warnings
+            self._bn_range_warned = True
+            warnings.warn("ieee_amd: a BatchNorm total of the bf16 train step is beyond half the range of its int64 fixed point "
+                          "(%s); the statistics are still exact, but a further doubling of the %s would be clamped and reported as "
+                          "an error (IEEE_BN_TOTALS_TILES=0 selects the unlimited partial-sum path)"
+                          % ("forward" if f_half else "backward", "activations" if f_half else "gradients"))
 
     def _generic_allreduce(self, params):
         """autograd path under data parallelism: sum the parameter gradients across ranks (one collective per tensor;

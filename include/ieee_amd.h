@@ -256,22 +256,28 @@ int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void
  * launch (every workgroup derives its channels' coefficients from the 2 x C integers in its prologue; workgroup 0 publishes
  * stats / running statistics / d(gamma), d(beta)), i.e. the separate finalize launch of ieee_bn2d_fwd / ieee_bn2d_bwd
  * disappears.  bf16 only, C / 8 must divide 256.  Same results as the partial-sum path up to the last bit of a float sum.
- * Range and resolution of the fixed point: forward sums up to 5.4e11 with 6e-8 absolute resolution (a 131 072-row map
- * overflows at an rms of 2 000 per channel), backward sums up to 8.3e6 with 9e-13 (finer than the float tile sum itself above
- * 1.5e-5); a tile's contribution saturates at +-9e18 units instead of wrapping, a NaN tile sum saturates too -- the NaN
- * itself still reaches the output through y.
+ * Range and resolution of the fixed point: totals stay inside +-2^62 units -- forward sums up to 2.7e11 with 6e-8 absolute
+ * resolution (a 131 072-row map reaches that at an rms of 1 400 per channel), backward sums up to 4.2e6 with 9e-13 (finer than
+ * the float tile sum itself above 1.5e-5).  Range guard: a tile contributes at most 2^62 / (row tiles of the launch) units, so
+ * the total of all tiles and replicas can NEVER wrap; a tile sum beyond that share, or a NaN one, is clamped and REPORTED:
+ * `overflow` (may be NULL) points to 4 ints the caller owns -- device or host-mapped memory, zero before the step -- and
+ * overflow[0] = 1: a forward tile sum was clamped, [1]: a backward one, [2] / [3]: a forward / backward total beyond half
+ * the range (2^61; written by ieee_bn2d_fwd_totals / _bwd_totals).  Any non-zero word means the statistics of that step are
+ * not the reference's (torch's fp32 batch_norm, torchreid/models/resnet.py:164-184, returns finite numbers or inf there):
+ * the executor raises through ieee_net_bn_overflow; the per-tile partial-sum path (ieee_bn2d_fwd / ieee_bn2d_bwd) has no
+ * such limit.
  * `replicas` (a power of two <= 64; 1 = plain) spreads the adders: totals[replica][group][2][C] (group_stride = 2 * C), row
  * tile t adds to replica t % replicas, and the BatchNorm passes add the replicas up in their prologue -- same-address atomics
  * retire at ~23 ns each, so a launch of 1 024 row tiles pays +24 us with one copy and +3 us with eight. */
-int ieee_conv_next_bn_totals(void* totals, int64_t group_stride, int replicas);
+int ieee_conv_next_bn_totals(void* totals, int64_t group_stride, int replicas, int* overflow);
 int ieee_bn2d_fwd_totals(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
                          int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
                          float* running_mean, float* running_var, int64_t buf_gs, float* stats, const void* totals,
-                         int replicas, float momentum, float eps, int relu, void* relu_bits, void* stream);
+                         int replicas, float momentum, float eps, int relu, void* relu_bits, int* overflow, void* stream);
 int ieee_bn2d_bwd_totals(const void* dout, const void* out_mask, const void* y, void* dy, void* g_out, int dtype,
                          int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
                          const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, const void* totals,
-                         int replicas, int mask_from_y, void* done_event, void* stream);
+                         int replicas, int mask_from_y, int* overflow, void* done_event, void* stream);
 /* backward through a FROZEN BatchNorm2d (module.eval() while the rest trains: open_specified_layers, utils/torchtools.py:
  * 183-221): `stats` holds the running-statistics scale / shift of the forward (ieee_bn2d_fwd with training = 0), the map
  * is a fixed affine one and dy = scale * g, g = dout * mask as in ieee_bn2d_bwd; no parameter gradient is produced. */
@@ -409,6 +415,12 @@ int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, float* dfeats
  * (torchreid/optim/optimizer.py:130-138) over a flat fp32 range */
 int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
                            float momentum, float weight_decay, int nesterov, void* stream);
+/* Gradient exchange in bf16 ("219 MB in bf16"; opt-in, IEEE_DP_GRAD_DTYPE=bf16): the slice of the flat
+ * fp32 gradient a rank is about to all-reduce, rounded to nearest even into a bf16 staging range, and the reduced bf16
+ * values widened back (exact).  The reference reduces fp32 gradients (nn.DataParallel's reduce_add,
+ * scripts/mainMultiModal.py:219-220): the default stays fp32. */
+int ieee_grad_pack_bf16(const float* grads, void* out_bf16, int64_t n, void* stream);
+int ieee_grad_unpack_bf16(const void* in_bf16, float* grads, int64_t n, void* stream);
 /* torch.optim.Adam / Adam(amsgrad=True) as the reference builds them for optim = 'adam' / 'amsgrad'
  * (torchreid/optim/optimizer.py:113-128): L2 weight decay, bias correction with `step` (1-based);
  * max_exp_avg_sq == NULL = plain Adam */
@@ -505,6 +517,14 @@ int ieee_net_sync_streams(void* handle, void* stream);
 #define IEEE_FROZEN_FC_N 32
 #define IEEE_FROZEN_FC_T 64
 int ieee_net_set_frozen(void* handle, int mask);
+/* Range guard of the fixed-point BatchNorm totals (bf16 training; see ieee_conv_next_bn_totals): out4 receives, and the call
+ * CLEARS, the four report words the kernels of the steps since the last call have set -- [0] a forward tile sum was clamped
+ * to its share of the int64 range (or was NaN), [1] a backward one, [2] / [3] a forward / backward total beyond half the
+ * range.  Host-side read of host-visible memory: synchronise with the step first (the Python engine calls it when it reads
+ * the step's loss summary); all zero = the statistics of those steps are the partial-sum path's up to the last bit of a float
+ * sum.  Non-zero: they are NOT what torch's fp32 batch_norm (torchreid/models/resnet.py:164-184) would have computed; train
+ * with IEEE_BN_TOTALS_TILES=0 (per-tile partial sums, no range limit) from the last good checkpoint. */
+int ieee_net_bn_overflow(void* handle, int* out4);
 /* Inference cache: after an eval-mode ieee_net_forward the workspace holds the packed weights and every BatchNorm's
  * scale / shift; the next eval forward on the same workspace reuses them (no packing launch, no finalize launches)
  * unless ieee_net_eval_cache(handle, 0) was called in between.  The CALLER must call it whenever parameters or

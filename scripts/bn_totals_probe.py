@@ -42,14 +42,14 @@ for (N, H, W, Ci, Co, R) in ((64, 8, 4, 2048, 512, 1), (64, 16, 8, 1024, 256, 1)
 
     def conv(use_totals):
         if use_totals:
-            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Co, REP))
+            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Co, REP, None))
         L.check(lib.ieee_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(y), L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad, x[0].numel(),
                                     wp.stride(0), y[0].numel(), L.ptr(part), L.stream()))
 
     def bn(use_totals):
         if use_totals:
             L.check(lib.ieee_bn2d_fwd_totals(L.ptr(y), None, L.ptr(a), L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co,
-                                             L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(tot), REP, 0.1, 1e-5, 1, None, L.stream()))
+                                             L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(tot), REP, 0.1, 1e-5, 1, None, None, L.stream()))
         else:
             L.check(lib.ieee_bn2d_fwd(L.ptr(y), None, L.ptr(a), L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co,
                                       L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, 1, rb, None, L.stream()))

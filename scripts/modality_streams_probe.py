@@ -33,12 +33,12 @@ class Unit:
     def run(self, x, res=None):
         G = self.G
         self.tot.zero_()
-        L.check(lib.ieee_conv_next_bn_totals(L.ptr(self.tot), 2 * self.Co, self.rep))
+        L.check(lib.ieee_conv_next_bn_totals(L.ptr(self.tot), 2 * self.Co, self.rep, None))
         L.check(lib.ieee_conv2d_fwd(L.ptr(x), L.ptr(self.wp), L.ptr(self.y), L.IEEE_BF16, G, N, self.H, self.W, self.Ci, self.Co, self.R, self.R,
                                     1, self.R // 2, x[0].numel(), self.wp.stride(0), self.y[0].numel(), L.ptr(self.part), L.stream()))
         L.check(lib.ieee_bn2d_fwd_totals(L.ptr(self.y), L.ptr(res) if res is not None else None, L.ptr(self.a), L.IEEE_BF16, G, self.M, self.Co,
                                          self.M * self.Co, L.ptr(self.gam), L.ptr(self.bet), self.Co, L.ptr(self.rm), L.ptr(self.rv), self.Co,
-                                         L.ptr(self.stats), L.ptr(self.tot), self.rep, 0.1, 1e-5, 1, None, L.stream()))
+                                         L.ptr(self.stats), L.ptr(self.tot), self.rep, 0.1, 1e-5, 1, None, None, L.stream()))
         return self.a
 
 

@@ -1,13 +1,13 @@
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")    # before the HIP runtime starts: see ieee_amd/__init__.py
-
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+import ieee_amd  # noqa: E402,F401  (before anything starts the HIP runtime: it picks GPU_MAX_HW_QUEUES, 1 under WORLD_SIZE > 1)
 
 
 def pytest_configure(config):

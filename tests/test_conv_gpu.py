@@ -440,6 +440,7 @@ def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co,
     rb = lib.ieee_conv2d_fwd_stats_rblocks(N, H, W)
     gam, bet = (torch.rand(G, Co, generator=g) + 0.5).cuda(), torch.randn(G, Co, generator=g).cuda()
     res = torch.randn(G, N, H, W, Co, generator=g).cuda().to(dt)
+    flags = torch.zeros(4, dtype=torch.int32, device="cuda")          # the range guard's report words: stay zero on O(1) data
 
     def forward(use_totals):
         part = torch.zeros(G, 2, Co, rb, device="cuda")
@@ -450,12 +451,12 @@ def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co,
         stats = torch.zeros(G, 4, Co, device="cuda")
         rm, rv = torch.zeros(G, Co, device="cuda"), torch.ones(G, Co, device="cuda")
         if use_totals:
-            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Co, REP))
+            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Co, REP, L.ptr(flags)))
         L.check(lib.ieee_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(y), L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad, x[0].numel(),
                                     wp.stride(0), y[0].numel(), L.ptr(part), L.stream()))
         if use_totals:
             L.check(lib.ieee_bn2d_fwd_totals(L.ptr(y), L.ptr(res), L.ptr(a), L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co,
-                                             L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(tot), REP, 0.1, 1e-5, 1, L.ptr(bits), L.stream()))
+                                             L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(tot), REP, 0.1, 1e-5, 1, L.ptr(bits), L.ptr(flags), L.stream()))
         else:
             L.check(lib.ieee_bn2d_fwd(L.ptr(y), L.ptr(res), L.ptr(a), L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co,
                                       L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, 1, rb, L.ptr(bits), L.stream()))
@@ -477,7 +478,7 @@ def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co,
     assert float((t["a"] != p["a"]).float().mean()) < 2e-3 and float((t["bits"] != p["bits"]).float().mean()) < 2e-3
     # a call that fails its argument checks leaves nothing armed for the next launch of the thread
     stale = torch.zeros(REP, G, 2, Co, dtype=torch.int64, device="cuda")
-    L.check(lib.ieee_conv_next_bn_totals(L.ptr(stale), 2 * Co, REP))
+    L.check(lib.ieee_conv_next_bn_totals(L.ptr(stale), 2 * Co, REP, None))
     assert lib.ieee_conv2d_fwd(None, L.ptr(wp), L.ptr(p["y"]), L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad, x[0].numel(), wp.stride(0),
                                p["y"][0].numel(), L.ptr(p["part"]), L.stream()) != 0
     again = forward(False)
@@ -498,13 +499,13 @@ def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co,
         dgam, dbet = torch.zeros(G, Ci, device="cuda"), torch.zeros(G, Ci, device="cuda")
         coef = torch.zeros(G, 3, Ci, device="cuda")
         if use_totals:
-            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Ci, REP))
+            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Ci, REP, L.ptr(flags)))
         L.check(lib.ieee_conv2d_dgrad(L.ptr(dyo), L.ptr(wpd), L.ptr(dx), None, L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, pad,
                                       dyo[0].numel(), wpd.stride(0), dx[0].numel(), L.ptr(part), L.ptr(ypre), None, L.ptr(pst), 0, 1,
                                       L.stream()))
         if use_totals:
             L.check(lib.ieee_bn2d_bwd_totals(L.ptr(dx), None, L.ptr(ypre), L.ptr(dyp), None, L.IEEE_BF16, G, M, Ci, M * Ci, L.ptr(pgam), Ci,
-                                             L.ptr(pst), L.ptr(dgam), L.ptr(dbet), Ci, L.ptr(tot), REP, 1, None, L.stream()))
+                                             L.ptr(pst), L.ptr(dgam), L.ptr(dbet), Ci, L.ptr(tot), REP, 1, L.ptr(flags), None, L.stream()))
         else:
             L.check(lib.ieee_bn2d_bwd(L.ptr(dx), None, L.ptr(ypre), L.ptr(dyp), None, L.IEEE_BF16, G, M, Ci, M * Ci, L.ptr(pgam), Ci,
                                       L.ptr(pst), L.ptr(dgam), L.ptr(dbet), Ci, L.ptr(part), L.ptr(coef), 0, 1, rb, L.stream()))
@@ -518,3 +519,109 @@ def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co,
     torch.testing.assert_close(t["dbet"], p["dbet"], rtol=1e-5, atol=1e-5)
     assert float((t["dy"].float() - p["dy"].float()).abs().max()) <= 2.0 ** -6 * float(p["dy"].float().abs().max())
     assert float((t["dy"] != p["dy"]).float().mean()) < 2e-3
+    assert flags.tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("direction", ["forward", "backward"])
+@pytest.mark.parametrize("REP", [1, 4])
+def test_fixed_point_totals_report_what_leaves_their_range(direction, REP):
+    """Range guard of the int64 BatchNorm totals (include/ieee_amd.h, ieee_conv_next_bn_totals): a tile may contribute at most
+    2^62 / (row tiles) units, so the total never wraps.  The operands are scaled so that the LARGEST tile sum sits at 0.4x,
+    0.9x and 2x that share (forward: sum y^2 against 2.7e11 / tiles; backward: sum g, sum g*y against 4.2e6 / tiles):
+      0.4x  nothing reported, every output equals the partial-sum path's (reference: torch's fp32 batch_norm,
+            torchreid/models/resnet.py:164-184, has no such range);
+      0.9x  still exact -- but the total is beyond half the range: word [2] (forward) / [3] (backward) is set;
+      2x    the tile is clamped and word [0] / [1] says so -- the caller must not trust these statistics."""
+    from ieee_amd import _lib as L, _ops
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(35)
+    G, N, H, W, Ci, Co, R = 3, 7, 16, 8, 64, 128, 1
+    dt = torch.bfloat16
+    M = N * H * W
+    tiles = (M + 127) // 128
+    x = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
+    w = (torch.randn(G, Co, Ci, R, R, generator=g) * 0.05).cuda()
+    rb = lib.ieee_conv2d_fwd_stats_rblocks(N, H, W)
+    gam, bet = (torch.rand(G, Co, generator=g) + 0.5).cuda(), torch.randn(G, Co, generator=g).cuda()
+
+    def forward(wscale, use_totals):
+        wp = _ops.pack_conv_weight(w * wscale, dt, 0)
+        part = torch.zeros(G, 2, Co, rb, device="cuda")
+        tot = torch.zeros(REP, G, 2, Co, dtype=torch.int64, device="cuda")
+        flags = torch.zeros(4, dtype=torch.int32, device="cuda")
+        y = torch.empty(G, N, H, W, Co, device="cuda", dtype=dt)
+        a = torch.empty_like(y)
+        stats = torch.zeros(G, 4, Co, device="cuda")
+        rm, rv = torch.zeros(G, Co, device="cuda"), torch.ones(G, Co, device="cuda")
+        if use_totals:
+            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Co, REP, L.ptr(flags)))
+        L.check(lib.ieee_conv2d_fwd(L.ptr(x), L.ptr(wp), L.ptr(y), L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, 0, x[0].numel(),
+                                    wp.stride(0), y[0].numel(), L.ptr(part), L.stream()))
+        if use_totals:
+            L.check(lib.ieee_bn2d_fwd_totals(L.ptr(y), None, L.ptr(a), L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co,
+                                             L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(tot), REP, 0.1, 1e-5, 1, None, L.ptr(flags), L.stream()))
+        else:
+            L.check(lib.ieee_bn2d_fwd(L.ptr(y), None, L.ptr(a), L.IEEE_BF16, G, M, Co, M * Co, L.ptr(gam), L.ptr(bet), Co,
+                                      L.ptr(rm), L.ptr(rv), Co, L.ptr(stats), L.ptr(part), 0.1, 1e-5, 1, 1, rb, None, L.stream()))
+        return dict(a=a, stats=stats, rv=rv, part=part, tot=tot, flags=flags.tolist())
+
+    # (backward: positive weights and gradients, so that the tile sums of sum g share a sign and ADD UP over the tiles the way
+    # the forward's sum y^2 does -- signed sums cancel and would never reach the "half the range" word)
+    wpd = _ops.pack_conv_weight(w.abs(), dt, 1)
+    dyo = torch.randn(G, N, H, W, Co, generator=g).abs().cuda().to(dt)
+    ypre = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dt)
+    pst = torch.randn(G, 4, Ci, generator=g).cuda()
+    pst[:, 1] = pst[:, 1].abs() + 0.5
+    pgam = (torch.rand(G, Ci, generator=g) + 0.5).cuda()
+
+    def backward(gscale, use_totals):
+        dys = (dyo.float() * gscale).to(dt)
+        part = torch.zeros(G, 2, Ci, rb, device="cuda")
+        tot = torch.zeros(REP, G, 2, Ci, dtype=torch.int64, device="cuda")
+        flags = torch.zeros(4, dtype=torch.int32, device="cuda")
+        dx = torch.empty(G, N, H, W, Ci, device="cuda", dtype=dt)
+        dyp = torch.empty_like(dx)
+        dgam, dbet = torch.zeros(G, Ci, device="cuda"), torch.zeros(G, Ci, device="cuda")
+        coef = torch.zeros(G, 3, Ci, device="cuda")
+        if use_totals:
+            L.check(lib.ieee_conv_next_bn_totals(L.ptr(tot), 2 * Ci, REP, L.ptr(flags)))
+        L.check(lib.ieee_conv2d_dgrad(L.ptr(dys), L.ptr(wpd), L.ptr(dx), None, L.IEEE_BF16, G, N, H, W, Ci, Co, R, R, 1, 0,
+                                      dys[0].numel(), wpd.stride(0), dx[0].numel(), L.ptr(part), L.ptr(ypre), None, L.ptr(pst), 0, 1,
+                                      L.stream()))
+        if use_totals:
+            L.check(lib.ieee_bn2d_bwd_totals(L.ptr(dx), None, L.ptr(ypre), L.ptr(dyp), None, L.IEEE_BF16, G, M, Ci, M * Ci, L.ptr(pgam), Ci,
+                                             L.ptr(pst), L.ptr(dgam), L.ptr(dbet), Ci, L.ptr(tot), REP, 1, L.ptr(flags), None, L.stream()))
+        else:
+            L.check(lib.ieee_bn2d_bwd(L.ptr(dx), None, L.ptr(ypre), L.ptr(dyp), None, L.IEEE_BF16, G, M, Ci, M * Ci, L.ptr(pgam), Ci,
+                                      L.ptr(pst), L.ptr(dgam), L.ptr(dbet), Ci, L.ptr(part), L.ptr(coef), 0, 1, rb, L.stream()))
+        return dict(dy=dyp, dgam=dgam, dbet=dbet, part=part, tot=tot, flags=flags.tolist())
+
+    run = forward if direction == "forward" else backward
+    share = 2.0 ** 62 / (2.0 ** 24 if direction == "forward" else 2.0 ** 40) / tiles     # a tile's share, in units of the sum
+    at_one = float(run(1.0, False)["part"].abs().max())                                     # largest tile sum at scale 1
+    power = 0.5 if direction == "forward" else 1.0                                          # sum y^2 is quadratic in the scale
+    for target, words in ((0.4, [0, 0, 0, 0]), (0.9, None), (2.0, None)):
+        scale = (target * share / at_one) ** power
+        p, t = run(scale, False), run(scale, True)
+        biggest = float(p["part"].abs().max())
+        assert 0.8 * target * share < biggest < 1.25 * target * share, (biggest, target * share)      # bf16 operands: roughly on target
+        clamp, half = (0, 2) if direction == "forward" else (1, 3)
+        if target < 1.0:
+            assert t["flags"][clamp] == 0
+            want = torch.round(p["part"].double() * (2.0 ** 24 if direction == "forward" else 2.0 ** 40)).to(torch.int64).sum(-1)
+            assert torch.equal(t["tot"].sum(0), want)
+            if direction == "forward":
+                torch.testing.assert_close(t["stats"], p["stats"], rtol=4e-6, atol=1e-30)
+                torch.testing.assert_close(t["rv"], p["rv"], rtol=4e-6, atol=1e-30)
+                assert float((t["a"] != p["a"]).float().mean()) < 2e-3
+            else:
+                torch.testing.assert_close(t["dgam"], p["dgam"], rtol=1e-5, atol=1e-5 * float(p["dgam"].abs().max()))
+                torch.testing.assert_close(t["dbet"], p["dbet"], rtol=1e-5, atol=1e-5 * float(p["dbet"].abs().max()))
+                assert float((t["dy"] != p["dy"]).float().mean()) < 2e-3
+        if words is not None:
+            assert t["flags"] == words
+        elif target < 1.0:      # exact, but close to the edge: the "beyond half the range" word of this direction
+            assert t["flags"][half] == 1 and t["flags"][clamp] == 0
+        else:                   # clamped: reported, and the total stayed inside +-2^62 (it did not wrap)
+            assert t["flags"][clamp] == 1
+            assert int(t["tot"].sum(0).abs().max()) <= 2 ** 62

@@ -165,8 +165,9 @@ def test_market1501_multimodal_parser(tmp_path):
 
 # ---- shard-aware sampler / loader
 def test_sharded_sampler_slices_the_single_process_batches():
-    data = _source(n_pid=17)
-    for world, B, K in ((2, 16, 4), (3, 32, 4), (4, 16, 4)):       # (3, 32): 8 identities = shards of 12, 12, 8 rows
+    # (3, 32): 8 identities = shards of 12, 12, 8 rows; (8, 512): BASELINE config 3 -- 8 ranks x 64 rows out of 171 identities
+    for world, B, K in ((2, 16, 4), (3, 32, 4), (4, 16, 4), (8, 512, 4)):
+        data = _source(n_pid=171 if B == 512 else 17)
         random.seed(5); np.random.seed(5)
         order = list(iter(smp.RandomIdentitySampler(data, B, K)))
         nb = len(order) // B
@@ -184,6 +185,7 @@ def test_sharded_sampler_slices_the_single_process_batches():
             for s, mine in parts:
                 got += mine[g * s.local_batch:(g + 1) * s.local_batch]
             assert got == order[g * B:(g + 1) * B]
+    data = _source(n_pid=17)
     with pytest.raises(ValueError):
         smp.build_train_sampler(data, 'RandomSampler', rank=0, world=2)
     with pytest.raises(ValueError):

@@ -83,7 +83,8 @@ def _worker(rank, world, port, ret, B=16, C=11, D=32):
 
 # (3, 32): 8 identities over 3 ranks = shards of 12, 12, 8 rows.  (4, 128, 750, 768): BASELINE config 5's shape -- 4 ranks x 32
 # triples, the 750 identities of Market1501-multimodal, the 768-wide per-modality descriptors the 3M loss sees
-@pytest.mark.parametrize("world,B,C,D", [(2, 16, 11, 32), (3, 32, 11, 32), (4, 128, 750, 768)])
+# (8, 512, 171, 768): BASELINE config 3 -- 8 ranks x 64 triples, the 171 identities of RGBNT201
+@pytest.mark.parametrize("world,B,C,D", [(2, 16, 11, 32), (3, 32, 11, 32), (4, 128, 750, 768), (8, 512, 171, 768)])
 def test_gloo_allreduce_and_loss_scaling(world, B, C, D):
     with mp.Manager() as mgr:
         ret = mgr.dict()
@@ -162,7 +163,7 @@ def _sync_worker(rank, world, port, ret):
     ret[rank] = 1
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_replica_sync_and_sharded_feature_gather(world):
     with mp.Manager() as mgr:
         ret = mgr.dict()
@@ -222,10 +223,145 @@ def test_query_shards_cover_all_rows():
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_query_sharded_evaluator_matches_single_process(world):
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_eval_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
         out = dict(ret)
         assert len(out) == world and all(out[r] == out[0] for r in out)      # every rank reports the same result
+
+
+# ---- launching N ranks from a plain `python` command (ieee_amd.dist.launch; what `python bench.py --gpus N` does) ----------
+_RANK_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from ieee_amd import dist as ddp
+world, rank, local = ddp.init_from_env(backend="gloo")
+assert os.environ["GPU_MAX_HW_QUEUES"] == %r, os.environ["GPU_MAX_HW_QUEUES"]
+if rank == int(os.environ.get("FAIL_RANK", "-1")):
+    sys.exit(7)
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+print("rank %%d of %%d: sum %%d" %% (rank, world, int(t.item())), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def _launch_parent(tmp_path, world, extra_env=None, queues="1", call_queues="None"):
+    """a fresh interpreter plays the launching process (launch() refuses a parent that holds a HIP context, and rank 0
+    inherits the launcher's stdout -- here a pipe)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % (root, queues))
+    parent = ("import sys; sys.path.insert(0, %r); from ieee_amd import dist as ddp; "
+              "sys.exit(ddp.launch([sys.executable, %r], %d, queues=%s, grace=3.0))" % (root, str(script), world, call_queues))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GPU_MAX_HW_QUEUES"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, "-c", parent], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+
+
+def test_launch_argv_starts_one_rank_per_process_and_relays_rank0(tmp_path):
+    r = _launch_parent(tmp_path, 4)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    # ONE line on the launcher's stdout (rank 0's); the other ranks' stdout went to stderr
+    # (gloo announces its connections on stdout; bench.py points descriptor 1 at stderr until its JSON line for that reason)
+    assert [l for l in r.stdout.decode().strip().splitlines() if not l.startswith("[Gloo]")] == ["rank 0 of 4: sum 10"]
+    err = r.stderr.decode()
+    assert all(("rank %d of 4: sum 10" % k) in err for k in (1, 2, 3))
+
+
+def test_launch_keeps_an_exported_queue_count(tmp_path):
+    r = _launch_parent(tmp_path, 2, queues="3", call_queues="'3'")
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+
+
+def test_launch_reports_the_failing_rank_and_ends_the_others(tmp_path):
+    import time
+    t0 = time.time()
+    r = _launch_parent(tmp_path, 3, extra_env={"FAIL_RANK": "1"})
+    assert r.returncode == 7, (r.returncode, r.stderr.decode()[-2000:])
+    assert time.time() - t0 < 120              # the surviving ranks sat in a collective with a dead peer: ended after `grace`
+
+
+def _launch_fn(rank, world, out_dir):
+    w, r, _ = ddp.init_from_env(backend="gloo")
+    assert (w, r) == (world, rank) and os.environ["GPU_MAX_HW_QUEUES"] == "1"
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    open(os.path.join(out_dir, "rank%d" % rank), "w").write(str(int(t.item())))
+    dist.destroy_process_group()
+
+
+def test_launch_callable_spawns_fresh_interpreters(tmp_path):
+    before = dict(os.environ)
+    assert ddp.launch(_launch_fn, 3, args=(str(tmp_path),)) == 0
+    assert dict(os.environ) == before          # the launcher's own environment is untouched
+    assert sorted(os.listdir(str(tmp_path))) == ["rank0", "rank1", "rank2"]
+    assert all(open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "3" for r in range(3))
+
+
+def test_bench_self_launch_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` from a plain interpreter: the launcher starts two ranks; on a box without a GPU every rank
+    stops at require_gpu() and the launcher hands that failure back (no hang, no silent CPU run)"""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IEEE_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0 and r.stdout.decode().strip() == ""
+    assert "no CPU fallback" in r.stderr.decode()
+
+
+# ---- opt-in bf16 gradient exchange (IEEE_DP_GRAD_DTYPE=bf16): what the halved wire format costs in accuracy ---------------
+def _bf16_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    ddp.init_from_env(backend="gloo")
+    # every rank's gradient slice: a shared component (the ranks see the same weights) plus a rank-local one, over six
+    # decades of magnitude like a real flat gradient (BatchNorm biases ~1e-1 ... layer1 weights ~1e-6)
+    g = torch.Generator().manual_seed(100)
+    n = 1 << 18
+    scale = 10.0 ** (-6.0 * torch.rand(n, generator=g))
+    common = torch.randn(n, generator=g)
+    local = torch.randn(n, generator=torch.Generator().manual_seed(rank))
+    grad = scale * (common + 0.7 * local)
+    exact = grad.double()
+    dist.all_reduce(exact)                                  # float64 sum of the fp32 slices: the yardstick
+    fp32 = grad.clone()
+    dist.all_reduce(fp32)
+    wire = grad.bfloat16()                                  # ieee_grad_pack_bf16: round to nearest even
+    dist.all_reduce(wire)                                   # the collective sums in bf16
+    got = wire.float()                                      # ieee_grad_unpack_bf16: exact
+    # per element against the sum of magnitudes (a sum that cancels has no relative accuracy in ANY format)
+    mags = grad.abs().double()
+    dist.all_reduce(mags)
+    rel32 = ((fp32.double() - exact).abs() / mags).max().item()
+    rel16 = ((got.double() - exact).abs() / mags).max().item()
+    cos = torch.nn.functional.cosine_similarity(got.double(), exact, dim=0).item()
+    ret[rank] = (rel32, rel16, cos)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bf16_gradient_allreduce_error_is_bounded(world):
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_bf16_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        out = dict(ret)
+    assert len(out) == world and all(out[r] == out[0] for r in out)          # replicas receive identical sums
+    rel32, rel16, cos = out[0]
+    assert rel32 < 1e-6
+    # one rounding per rank slice (2^-9 each, relative to that slice) + one per partial sum of the reduction
+    assert rel16 < 2.0 ** -8 * (1 + world.bit_length()), rel16
+    assert cos > 0.99999

@@ -209,3 +209,84 @@ def test_two_rank_sharded_engine_test_equals_reference(tmp_path, golden_dir):
     ref = [l for l in str(G["evalpipe/printed"]).splitlines() if l.startswith(("mAP", "Rank-"))]
     assert [l for l in got[0]["printed"].splitlines() if l.startswith(("mAP", "Rank-"))] == ref
     assert not [l for l in got[1]["printed"].splitlines() if l.startswith(("mAP", "Rank-", "Computing"))]
+
+
+# ---- opt-in bf16 gradient exchange (IEEE_DP_GRAD_DTYPE=bf16): pack -> bf16 all-reduce -> unpack, native kernels ---------
+def _worker_bf16(rank, world, port, out_path, wire):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), IEEE_DIST_BACKEND="gloo", IEEE_FORCE_DEVICE="0", IEEE_DP_GRAD_DTYPE=wire)
+    from ieee_amd import dist as ddp
+    ddp.init_from_env()
+    eng, m = _build(7 + rank)
+    eng.forward_backward(_batch(16, 7))
+    torch.cuda.synchronize()
+    torch.save(m._flat_grads.cpu(), out_path + str(rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_bf16_gradient_exchange_stays_within_its_bound(tmp_path):
+    got = {}
+    for wire in ("fp32", "bf16"):
+        out = str(tmp_path / ("g_%s_" % wire))
+        mp.spawn(_worker_bf16, args=(2, _free_port(), out, wire), nprocs=2, join=True)
+        got[wire] = [torch.load(out + str(r)) for r in range(2)]
+        assert torch.equal(got[wire][0], got[wire][1])                   # replicas hold the same reduced gradient
+    a, b = got["fp32"][0].double(), got["bf16"][0].double()
+    assert not torch.equal(a, b)                                         # the bf16 wire format was really used
+    # every reduced element is a bf16 value ...
+    assert torch.equal(got["bf16"][0], got["bf16"][0].bfloat16().float())
+    # ... within one rounding per rank slice + one for the sum (the slices may cancel: bound against what fp32 reduced,
+    # tile-wise so that cancelled elements are judged against their neighbourhood)
+    err = (a - b).abs()
+    tile = 4096
+    n = (a.numel() // tile) * tile
+    rel = err[:n].view(-1, tile).amax(1) / a[:n].view(-1, tile).abs().amax(1).clamp_min(1e-30)
+    assert float(rel.max()) < 3 * 2.0 ** -8, float(rel.max())
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+    assert cos > 0.99999, cos
+
+
+def test_grad_pack_unpack_bf16_any_slice():
+    """the pack / unpack kernels on slices that start and end anywhere (scalar peel + 8-wide body + tail)"""
+    from ieee_amd import _lib
+    lib = _lib.require_gpu()
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(100003, generator=g).cuda()
+    for a, b in ((0, 100003), (1, 100000), (7, 15), (8, 9), (13, 77777), (171, 171 + 171 * 384), (5, 5)):
+        assert b <= src.numel()
+        stage = torch.zeros(100003, dtype=torch.bfloat16, device="cuda")
+        back = torch.full((100003,), -7.0, device="cuda")
+        _lib.check(lib.ieee_grad_pack_bf16(_lib.ptr(src[a:b]), _lib.ptr(stage[a:b]), b - a, _lib.stream()))
+        _lib.check(lib.ieee_grad_unpack_bf16(_lib.ptr(stage[a:b]), _lib.ptr(back[a:b]), b - a, _lib.stream()))
+        want = src.bfloat16()
+        assert torch.equal(stage[a:b], want[a:b]) and torch.equal(back[a:b], want[a:b].float())
+        assert float(stage[:a].abs().sum()) == 0 and float(stage[b:].abs().sum()) == 0       # nothing outside the slice
+        assert torch.all(back[:a] == -7.0) and torch.all(back[b:] == -7.0)
+
+
+# ---- `python bench.py --gpus 2` from a plain interpreter: the file starts its own ranks (ieee_amd.dist.launch) -------------
+def test_bench_starts_its_own_ranks_from_plain_python():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IEEE_DIST_BACKEND="gloo", IEEE_FORCE_DEVICE="0")       # two ranks share this box's one GPU
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GPU_MAX_HW_QUEUES", "IEEE_DP_OVERLAP"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "8"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                        # ONE JSON line: rank 0's
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
+    assert line["value"] > 0 and abs(line["value"] - 3 * 16 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    cal = line["dp_calibration"]
+    assert cal["used"] in ("overlapped", "unoverlapped") and cal["overlapped_ms_per_step"] > 0 and cal["unoverlapped_ms_per_step"] > 0
+    rc = line["rccl"]
+    assert rc["ranks"] == 2 and rc["backend"] == "gloo"
+    assert sorted(rc["allreduce_ms_per_part"]) == ["0", "1", "2", "3", "4"] and all(v > 0 for v in rc["allreduce_ms_per_part"].values())
+    total = sum(rc["allreduce_bytes_per_part"].values())                 # one pass over the flat fp32 gradient (438 MB)
+    assert 0.99 * 4 * 109499337 <= total <= 4 * 109499337, total
+    assert line["launch"]["how"] == "self-spawned" and line["launch"]["hw_queues"] == 1

@@ -175,3 +175,68 @@ def test_bf16_ablation_leg_tail_gradients_and_short_trajectory(leg):
     assert drop > 0.1 * ref["loss"][0]                 # 20 steps at lr 1e-3 / 1e-4 move the loss
     assert d < 0.05 * drop + 2e-3 * ref["loss"][0], (d, drop)
     assert abs(b16["acc"][-5:].mean() - ref["acc"][-5:].mean()) < 5.0
+
+
+def test_bf16_trajectory_at_config2_batch_64():
+    """BASELINE config 2's shape -- 64 triples per step (16 identities x 4 instances), 171 classes -- for 30 real engine steps:
+    at this batch the fused BatchNorm sums of layer1 / layer2 run in the 4-replica form of the fixed-point totals and over
+    more than 64 row tiles per modality (ieee_conv_next_bn_totals; the B = 16 run above never reaches either), so this is
+    the multi-step check of those instantiations.  Same fixture, same control (fp32 from parameters jittered by 2^-12) and
+    the same band as the 120-step run; the range guard of the totals must stay silent on this healthy run.
+    Reference semantics: torch's fp32 batch_norm as called from torchreid/models/resnet.py:164-184."""
+    st = tamed_state(171)
+    kw = dict(n_ids=16, per_id=8, ids_per_batch=16, k=4, epochs=3, batches_per_epoch=10, milestones=(2,), eval_noise=0.5)
+    runs = {}
+    for name, dt, pert in (("fp32", torch.float32, 0.0), ("control", torch.float32, 2.0 ** -12), ("bf16", torch.bfloat16, 0.0)):
+        r = run_training(dt, st, perturb=pert, **kw)
+        if name == "bf16":
+            assert r["model"].native_net(64, 256, 128).bn_overflow() == (0, 0, 0, 0)
+        r.pop("model"), r.pop("engine")
+        runs[name] = r
+        torch.cuda.empty_cache()
+        print("%-8s loss %.3f -> %.3f, accuracy %.1f -> %.1f, evaluation %s" % (
+            name, r["loss"][0], r["loss"][-5:].mean(), r["acc"][:3].mean(), r["acc"][-5:].mean(), r["evals"]))
+    ref, ctl, b16 = runs["fp32"], runs["control"], runs["bf16"]
+    assert len(ref["loss"]) == 30 and abs(ref["lr_end"] - 1e-4) < 1e-12
+    drop = ref["loss"][0] - ref["loss"][-5:].mean()
+    assert drop > 0.3 * ref["loss"][0]                       # 30 steps move the loss substantially in both modes
+    assert b16["loss"][0] - b16["loss"][-5:].mean() > 0.3 * b16["loss"][0]
+    d_ctl, d_b16 = _dev(ctl["loss"], ref["loss"]), _dev(b16["loss"], ref["loss"])
+    print("B = 64: max |smoothed loss - fp32|: control %.3f (%.2f %% of the drop), bf16 %.3f (%.2f %%)" % (
+        d_ctl, 100 * d_ctl / drop, d_b16, 100 * d_b16 / drop))
+    assert d_ctl < 0.05 * drop, (d_ctl, drop)
+    assert d_b16 < 0.05 * drop and d_b16 < 3 * d_ctl + 0.01 * drop, (d_b16, d_ctl, drop)
+    assert abs(b16["loss"][0] - ref["loss"][0]) < 2e-3 * ref["loss"][0]
+    assert abs(b16["acc"][-5:].mean() - ref["acc"][-5:].mean()) < 3.0
+    assert abs(b16["mAP"] - ref["mAP"]) <= 1e-3 + abs(ctl["mAP"] - ref["mAP"]), (b16["mAP"], ref["mAP"], ctl["mAP"])
+
+
+def test_engine_raises_when_batchnorm_sums_leave_the_fixed_point_range():
+    """The range guard end to end: a layer1 convolution whose weights are blown up by 1e5 produces sum y^2 far beyond the 2.7e11
+    the int64 totals hold; the kernels clamp and report, and the engine raises when it reads that step's summary -- instead of
+    training on wrapped statistics (the reference's fp32 batch_norm, torchreid/models/resnet.py:164-184, has no such range)."""
+    from ieee_amd import _lib
+    from ieee_amd.engine import Image3MEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    from tests.util_trajectory import _DM, make_train_set
+    st = {k: v.clone() for k, v in tamed_state(171).items()}
+    m = build_model("ieee3modalPart", num_classes=171, loss="margin", pretrained=False, compute_dtype=torch.bfloat16)
+    m.load_state_dict(st)
+    m.train()
+    eng = Image3MEngine(_DM(171, [], {}), m, build_optimizer(m, optim="sgd", lr=0.0, weight_decay=0.0, momentum=0.0), margin=1,
+                        use_gpu=True)
+    xs, pids, cams = make_train_set(2, 4, 21, 0.5)
+    batch = {"img": xs, "pid": pids, "camid": cams, "impath": "", "timeid": pids * 0}
+    s = eng.forward_backward(batch)                          # a healthy step: nothing reported
+    assert np.isfinite(float(s["loss"]))
+    with torch.no_grad():
+        dict(m._param_items)["backbone.1.layer1.0.conv2.weight"].mul_(1e5)
+    with pytest.raises(_lib.IeeeAmdError, match="left the range of the fixed-point totals"):
+        eng.forward_backward(batch)
+    assert m.native_net(8, 256, 128).bn_overflow() == (0, 0, 0, 0)          # read and cleared by the engine
+    # deferred summaries (Engine.train's mode): the error surfaces when the summary is looked at
+    eng.defer_summary = True
+    pending = eng.forward_backward(batch)
+    with pytest.raises(_lib.IeeeAmdError):
+        float(pending["loss"])
