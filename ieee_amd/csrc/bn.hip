@@ -3,6 +3,7 @@
 // Semantics: torch.nn.BatchNorm2d defaults as used by the reference (torchreid/models/resnet.py:151,
 // 164-184; ieee3modalPart.py:38): eps 1e-5, momentum 0.1, biased variance for normalisation,
 // unbiased for the running estimate.  HBM-bound streaming kernels, 16 bytes per lane.
+#include <math.h>
 #include <stdlib.h>
 
 #include <hip/hip_ext.h>
@@ -659,6 +660,112 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_totals_kernel(const T* __res
   }
 }
 
+// The same pass for the LAST BatchNorm of a bottleneck block that has a downsample branch (out = relu(bn3(y3) + bn_ds(y_ds)):
+// both BatchNorm backwards are fed by the same masked gradient g).  While it walks g for dy3 it also reads the branch's conv
+// output y2 and leaves the branch's backward sums -- sum g (= this unit's own total) and sum g*y2 -- in the branch unit's
+// fixed-point totals, so that the branch's BatchNorm backward is ONE apply launch with its coefficients from a prologue: its
+// reduction pass (g and y2 read once more, ~67 us at B = 64) and its finalize launch disappear; this pass pays one more
+// operand stream.  A thread's channel chunk is fixed along its walk, so it keeps 8 running sums; the workgroup adds them up
+// through LDS and issues one no-return atomic per channel (workgroup w to replica w % rep2).  da = g (already masked by the
+// dgrad that wrote it), no g output: the only form the executor needs.
+__device__ __forceinline__ long long tot_to_fixed_bwd(float v, float lim, int* flag) {
+  float x = v * 1099511627776.0f;                // 2^40
+  if (!(fabsf(x) <= lim)) {                      // beyond this workgroup's share of +-2^62, or NaN (see conv.hip: to_fixed)
+    if (flag != nullptr) *(volatile int*)flag = 1;
+    x = fminf(fmaxf(x, -lim), lim);
+  }
+  return __float2ll_rn(x);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_totals_ds_kernel(const T* __restrict__ da, const T* __restrict__ y,
+                                                                     const T* __restrict__ y2, T* __restrict__ dy,
+                                                                     const long long* __restrict__ totals,
+                                                                     const float* __restrict__ gamma, int64_t param_gs,
+                                                                     const float* __restrict__ stats, float* dgamma,
+                                                                     float* dbeta, int64_t grad_gs, int M, int64_t total_chunks,
+                                                                     int cprw, int C, int64_t gs, double inv_m, int rep,
+                                                                     int64_t rep_stride, long long* __restrict__ totals2, int rep2,
+                                                                     int64_t rep2_stride, float lim2, int* overflow) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int z = blockIdx.y;
+  const int c0 = (threadIdx.x & (cprw - 1)) * VEC;
+  const float* st = stats + (int64_t)z * 4 * C;
+  const T* dd = da + z * gs;
+  const T* yy = y + z * gs;
+  const T* y2p = y2 + z * gs;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint4 dnext = make_uint4(0, 0, 0, 0), ynext = dnext, y2next = dnext;
+  if (i < total_chunks) {
+    dnext = *(const uint4*)(dd + i * VEC);
+    ynext = *(const uint4*)(yy + i * VEC);
+    y2next = *(const uint4*)(y2p + i * VEC);
+  }
+  extern __shared__ float tot_lds[];
+  float* s_k = tot_lds;                                      // [3][C]; reused as [VEC][256] reduction planes at the end
+  long long* t2 = totals2 + (int64_t)z * 2 * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    long long t1 = 0, tq = 0;
+    for (int r = 0; r < rep; ++r) {
+      t1 += totals[r * rep_stride + (int64_t)z * 2 * C + c];
+      tq += totals[r * rep_stride + (int64_t)z * 2 * C + C + c];
+    }
+    if (blockIdx.x == 0) {
+      if (overflow != nullptr && (tot_abs(t1) > TOT_HALF_RANGE || tot_abs(tq) > TOT_HALF_RANGE)) *(volatile int*)(overflow + 3) = 1;
+      // sum g of the branch's BatchNorm is this unit's own (same gradient, same channels): handed over as it is
+      (void)__hip_atomic_fetch_add(t2 + c, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double s1 = (double)t1 * TOT_INV_BWD, s2 = (double)tq * TOT_INV_BWD;
+    const double mean = st[c], invstd = st[C + c];
+    const double sgx = invstd * (s2 - mean * s1);
+    const double A = (double)gamma[z * param_gs + c] * invstd;
+    const double c1 = s1 * inv_m, c2 = sgx * inv_m;
+    s_k[c] = (float)A;
+    s_k[C + c] = (float)(-A * invstd * c2);
+    s_k[2 * C + c] = (float)(-A * c1 + A * invstd * c2 * mean);
+    if (blockIdx.x == 0 && dgamma != nullptr) {
+      dgamma[z * grad_gs + c] = (float)sgx;
+      dbeta[z * grad_gs + c] = (float)s1;
+    }
+  }
+  __syncthreads();
+  float k1[VEC], k2[VEC], k3[VEC], s3[VEC];
+  load_floats<VEC>(s_k + c0, k1);
+  load_floats<VEC>(s_k + C + c0, k2);
+  load_floats<VEC>(s_k + 2 * C + c0, k3);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s3[e] = 0.f;
+  T* oo = dy + z * gs;
+  for (; i < total_chunks; i += stride) {
+    float d[VEC], v[VEC], w[VEC];
+    Vec16<T>::unpack(dnext, d);
+    Vec16<T>::unpack(ynext, v);
+    Vec16<T>::unpack(y2next, w);
+    if (i + stride < total_chunks) {
+      dnext = *(const uint4*)(dd + (i + stride) * VEC);
+      ynext = *(const uint4*)(yy + (i + stride) * VEC);
+      y2next = *(const uint4*)(y2p + (i + stride) * VEC);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s3[e] += d[e] * w[e]; v[e] = k1[e] * d[e] + k2[e] * v[e] + k3[e]; }
+    *(uint4*)(oo + i * VEC) = Vec16<T>::pack(v);
+  }
+  __syncthreads();                                           // every thread has its coefficients: the planes may be reused
+  float* red = tot_lds;                                      // [VEC][256]: lane-contiguous stores
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[e * 256 + threadIdx.x] = s3[e];
+  __syncthreads();
+  const int rpp = 256 / cprw;
+  long long* dst = t2 + (int64_t)(blockIdx.x % rep2) * rep2_stride + C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int cc = c / VEC, e = c % VEC;
+    float s = 0.f;
+    for (int r = 0; r < rpp; ++r) s += red[e * 256 + r * cprw + cc];
+    (void)__hip_atomic_fetch_add(dst + c, tot_to_fixed_bwd(s, lim2, overflow != nullptr ? overflow + 1 : nullptr),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 struct PoolShifts { int pow2, lw, lh, lc, lq; };   // log2 of Wi, Hi, C, chunks per row when all are powers of two
 
 // ---- the stem's backward in two passes: d(out) of its ReLU(BatchNorm(y)) is the backward of MaxPool2d(3,2,1) applied
@@ -1204,6 +1311,33 @@ extern "C" int ieee_bn2d_bwd_totals(const void* dout, const void* out_mask, cons
   }
 #undef IEEE_BN_BWD_TOT
   return launch_status("bn_bwd_apply_totals_kernel");
+}
+
+/* the block-output BatchNorm's backward (dout = g, already masked) that also leaves the downsample branch's backward sums
+ * (sum g, sum g*y_ds) in that unit's totals: see bn_bwd_apply_totals_ds_kernel */
+extern "C" int ieee_bn2d_bwd_totals_ds(const void* dout, const void* y, const void* y_ds, void* dy, int dtype, int64_t groups,
+                                       int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
+                                       const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, const void* totals,
+                                       int replicas, void* totals_ds, int replicas_ds, int* overflow, void* done_event,
+                                       void* stream) {
+  IEEE_REQUIRE(replicas >= 1 && replicas <= 64 && replicas_ds >= 1 && replicas_ds <= 64, "bn2d_bwd_totals_ds: 1..64 replicas");
+  IEEE_REQUIRE(dout && y && y_ds && dy && gamma && stats && totals && totals_ds, "bn2d_bwd_totals_ds: null pointer");
+  IEEE_REQUIRE(dtype == IEEE_BF16, "bn2d_bwd_totals_ds: bf16 only");
+  const int cprw = (int)(C / 8);
+  IEEE_REQUIRE(C % 8 == 0 && cprw >= 1 && cprw <= 256 && 256 % cprw == 0, "bn2d_bwd_totals_ds: C / 8 must divide 256");
+  IEEE_REQUIRE((((uintptr_t)totals | (uintptr_t)gamma | (uintptr_t)stats) & 15) == 0 && param_gs % 4 == 0,
+               "bn2d_bwd_totals_ds: totals / gamma / stats must be 16-byte aligned (group stride a multiple of 4 floats)");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t chunks = M * C / 8;
+  dim3 grid(tot_blocks(chunks, groups), (unsigned)groups);
+  const size_t lds = std::max<size_t>(3 * C, 8 * 256) * sizeof(float);
+  // a workgroup's share of +-2^62 (rounded down): the branch's sum g*y_ds cannot wrap whatever the workgroups add
+  const float lim2 = nextafterf(4611686018427387904.0f / (float)grid.x, 0.f);
+  hipExtLaunchKernelGGL((bn_bwd_apply_totals_ds_kernel<bf16>), grid, dim3(256), (uint32_t)lds, st, nullptr, (hipEvent_t)done_event, 0,
+                        (const bf16*)dout, (const bf16*)y, (const bf16*)y_ds, (bf16*)dy, (const long long*)totals, gamma, param_gs,
+                        stats, dgamma, dbeta, grad_gs, (int)M, chunks, cprw, (int)C, act_gs, 1.0 / (double)M, replicas,
+                        groups * 2 * C, (long long*)totals_ds, replicas_ds, groups * 2 * C, lim2, overflow);
+  return launch_status("bn_bwd_apply_totals_ds_kernel");
 }
 
 extern "C" int ieee_bn2d_bwd_pooled(const void* dpool, const uint8_t* argmax, const void* y, void* dy, int dtype,

@@ -567,10 +567,19 @@ struct Run {
     }
     return n.side_ready[n.side_used++];
   }
+  // Block-output BatchNorm with a downsample branch beside it: set to the branch's unit before bn_bwd(c3) and that pass also
+  // leaves the branch's backward sums in its totals (ieee_bn2d_bwd_totals_ds); ds_totals_ready then tells bn_bwd(branch unit)
+  // that its sums are in u.tot_b already -- no reduction pass, no finalize launch (IEEE_DS_TOTALS=0: the separate passes)
+  const ConvUnit* ds_pending = nullptr;
+  const ConvUnit* ds_totals_ready = nullptr;
   int bn_bwd(const ConvUnit& u, const void* dout, const void* mask, void* dy, void* gout, int mask_from_y = 0,
              float* partial = nullptr, int64_t partial_rb = 0) {
     const int64_t rb = partial ? partial_rb : (fused_bwd ? (u.M(B) + 127) / 128 : 0);
-    const bool from_totals = !partial && fused_bwd && n.bwd_totals_state;
+    const bool ds_ready = !partial && ds_totals_ready == &u;
+    if (ds_ready) ds_totals_ready = nullptr;
+    const bool from_totals = (!partial && fused_bwd && n.bwd_totals_state) || ds_ready;
+    const ConvUnit* ds = ds_pending;
+    ds_pending = nullptr;
     if (!partial) partial = bnpart_cur;
     fused_bwd = false;
     n.bwd_totals_state = false;
@@ -584,6 +593,13 @@ struct Run {
     if (frz(u))
       return ieee_bn2d_bwd_frozen(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, F(u.stats), bncoef_cur,
                                   mask_from_y, (void*)bn_done, st);
+    if (from_totals && ds != nullptr && mask == nullptr && gout == nullptr && !mask_from_y && use_totals(*ds) && !frz(*ds) && ds->Co == u.Co &&
+        ds->M(B) == u.M(B)) {
+      ds_totals_ready = ds;
+      return ieee_bn2d_bwd_totals_ds(dout, P(u.y), P(ds->y), dy, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g), F(u.stats),
+                                     grd(u.s_g), grd(u.s_b), gs(u.s_g), P(u.tot_b), totals_rep(u), P(ds->tot_b), totals_rep(*ds),
+                                     n.bn_overflow, (void*)bn_done, st);
+    }
     if (from_totals)   // the dgrad that produced `dout` added sum g, sum g*y to u.tot_b: finalize + apply in one launch
       return ieee_bn2d_bwd_totals(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
                                   F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), P(u.tot_b), totals_rep(u), mask_from_y, n.bn_overflow,
@@ -1102,6 +1118,8 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     // the mask tensor), so the BatchNorm backward reads g and y3 only and writes dy3 into Q; the two names then swap.
     if (N.tap_base && bi + 1 == (int)N.blocks.size()) IEEE_TRY(tap(c3.name + ".dout", X, out_numel(c3)));
     if (dt == IEEE_BF16 && bi + 1 < (int)N.blocks.size()) {
+      static const bool ds_totals = !(getenv("IEEE_DS_TOTALS") && atoi(getenv("IEEE_DS_TOTALS")) == 0);
+      if (ds_totals && b.ds >= 0 && !branch_enabled(2)) ds_pending = &N.units[b.ds];
       IEEE_TRY(bn_bwd(c3, X, nullptr, Q, nullptr));
       std::swap(X, Q);
     } else {

@@ -278,6 +278,15 @@ int ieee_bn2d_bwd_totals(const void* dout, const void* out_mask, const void* y, 
                          int64_t groups, int64_t M, int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs,
                          const float* stats, float* dgamma, float* dbeta, int64_t grad_gs, const void* totals,
                          int replicas, int mask_from_y, int* overflow, void* done_event, void* stream);
+/* ieee_bn2d_bwd_totals for the LAST BatchNorm of a bottleneck block with a downsample branch (out = relu(bn3(y3) + bn_ds(y_ds)),
+ * torchreid/models/resnet.py:164-184: both BatchNorm backwards see the same masked gradient g = dout): dy = the backward of
+ * bn3 as above (no mask, no g output), and -- while g streams by -- the branch's backward sums, sum g and sum g*y_ds, are ADDED to
+ * totals_ds [replicas_ds][groups][2][C] (2^40 fixed point, zero beforehand; same range guard: overflow[1] / [3]), so that the
+ * branch's BatchNorm backward is one ieee_bn2d_bwd_totals launch without a reduction pass or a finalize launch. */
+int ieee_bn2d_bwd_totals_ds(const void* dout, const void* y, const void* y_ds, void* dy, int dtype, int64_t groups, int64_t M,
+                            int64_t C, int64_t act_gs, const float* gamma, int64_t param_gs, const float* stats,
+                            float* dgamma, float* dbeta, int64_t grad_gs, const void* totals, int replicas, void* totals_ds,
+                            int replicas_ds, int* overflow, void* done_event, void* stream);
 /* backward through a FROZEN BatchNorm2d (module.eval() while the rest trains: open_specified_layers, utils/torchtools.py:
  * 183-221): `stats` holds the running-statistics scale / shift of the forward (ieee_bn2d_fwd with training = 0), the map
  * is a fixed affine one and dy = scale * g, g = dout * mask as in ieee_bn2d_bwd; no parameter gradient is produced. */

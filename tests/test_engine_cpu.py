@@ -1,0 +1,66 @@
+"""CPU: host logic of the engine that needs no device -- the guard for reference-side loaders that fork() the training
+process (torchreid/data/datamanager.py:214-229 builds DataLoader(num_workers=workers) with the default start method;
+scripts/default_config.py:20: workers = 1)."""
+import warnings
+
+import pytest
+import torch
+
+from ieee_amd.engine import Engine
+
+
+class _DS(torch.utils.data.Dataset):
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, i):
+        return i
+
+
+class _DM(object):
+    num_train_pids = 3
+    sources = ["synthetic"]
+    test_loader = {}
+
+    def __init__(self, loader):
+        self.train_loader = loader
+
+
+def _engine(loader, monkeypatch, live=True):
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: live)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: live)
+    return Engine(_DM(loader), use_gpu=False)
+
+
+def test_forking_dataloader_beside_a_live_hip_context_warns_once(monkeypatch):
+    eng = _engine(torch.utils.data.DataLoader(_DS(), batch_size=2, num_workers=1, multiprocessing_context="fork"), monkeypatch)
+    with pytest.warns(RuntimeWarning, match="forkserver") as rec:
+        eng._warn_forking_loader()
+    assert "364 ms" in str(rec[0].message) and "1 worker" in str(rec[0].message)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        eng._warn_forking_loader()                      # once per engine
+
+
+def test_default_start_method_on_linux_counts_as_fork(monkeypatch):
+    import multiprocessing
+    if multiprocessing.get_start_method(allow_none=True) not in (None, "fork"):
+        pytest.skip("this interpreter's default start method is not fork")
+    eng = _engine(torch.utils.data.DataLoader(_DS(), batch_size=2, num_workers=2), monkeypatch)
+    with pytest.warns(RuntimeWarning, match="2 worker"):
+        eng._warn_forking_loader()
+
+
+@pytest.mark.parametrize("kw,live", [(dict(num_workers=0), True), (dict(num_workers=1, multiprocessing_context="forkserver"), True),
+                                     (dict(num_workers=1, multiprocessing_context="spawn"), True),
+                                     (dict(num_workers=1, multiprocessing_context="fork"), False)])
+def test_no_warning_without_the_hazard(monkeypatch, kw, live):
+    eng = _engine(torch.utils.data.DataLoader(_DS(), batch_size=2, **kw), monkeypatch, live=live)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        eng._warn_forking_loader()
+    # any other iterable (a list of batches, ieee_amd.data's DeviceLoader) is not a forking loader
+    eng = _engine([{"img": None}], monkeypatch)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        eng._warn_forking_loader()
