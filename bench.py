@@ -594,8 +594,10 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "scripts"))
                 import loader_probe
+                # three INTERLEAVED rounds per worker count: median and min - max per setting; recommended = the smallest
+                # count whose worst round keeps >= 0.97 of the resident-batch rate
                 line["loader"] = loader_probe.measure(tuple(int(w) for w in args.loader_workers.split(",")), steps=40, B=B,
-                                                      device=device, engine=engine)
+                                                      device=device, engine=engine, rounds=3)
             except Exception as e:      # informative leg: never costs the headline line
                 line["loader"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:

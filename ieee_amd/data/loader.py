@@ -98,15 +98,26 @@ class _SlotDataset(torch.utils.data.Dataset):
 
 class _SlotSampler(object):
     """(slot, dataset indices) per batch; the slot counter runs on across epochs, so a slot is rewritten only after
-    `slots` further batches have been handed out"""
+    `slots` further batches have been handed out.
+    continuous: the index stream does not end with the epoch -- epoch k + 1's batches follow epoch k's at once, so the workers
+    (each decodes a WHOLE batch: ~55 ms for 64 triples) are already busy with the next epoch while the consumer finishes this
+    one.  With an iterator per epoch the pipeline drains and refills at every boundary: one 50-60 ms stall per epoch, measured
+    (scripts/loader_probe.py: the single longest wait of every 40-step window, 3-4 steps of GPU time).  The next epoch's order
+    is then drawn ~2 x workers batches EARLY, from the same generators in the same order -- the sequence of batches is the
+    reference sampler's as long as nothing else consumes python's / numpy's global generators in between."""
 
-    def __init__(self, batches, slots):
-        self.batches, self.slots, self.k = batches, slots, 0
+    def __init__(self, batches, slots, continuous=False):
+        self.batches, self.slots, self.k, self.continuous = batches, slots, 0, continuous
 
     def __iter__(self):
-        for idx in self.batches:
-            yield (self.k % self.slots, list(idx))
-            self.k += 1
+        while True:
+            n = 0
+            for idx in self.batches:
+                yield (self.k % self.slots, list(idx))
+                self.k += 1
+                n += 1
+            if not self.continuous or n == 0:
+                return
 
     def __len__(self):
         return len(self.batches)
@@ -125,7 +136,7 @@ class DeviceLoader(object):
     shards of, stamped on every batch so the engine needs no collective to scale the cross entropy."""
 
     def __init__(self, data, transform, batch_size, sampler=None, shuffle=False, workers=4, drop_last=False, rank=0, world=1,
-                 global_rows=None, prefetch=0):
+                 global_rows=None, prefetch=0, persistent=False):
         self.dataset = MultiModalImageDataset(data)
         self.transform = transform
         # prefetch = k > 0: a background thread keeps up to k batches READY ON THE DEVICE -- it takes the decoded batch from
@@ -136,6 +147,10 @@ class DeviceLoader(object):
         self.rank, self.world = int(rank), int(world)
         self.global_rows = global_rows
         self.batch_size = int(batch_size)
+        # persistent: keep the worker processes between epochs (the train loader: an epoch of RGBNT201 is a few hundred batches,
+        # respawning W processes that import torch at every epoch costs seconds).  Off for the query / gallery loaders: their
+        # workers would sit resident -- 2 x W processes preloaded with torch -- through the whole run for one pass per evaluation.
+        persistent = bool(persistent) and workers > 0
         self._owned = None
         if self.world > 1 and sampler is None and not shuffle:
             n = len(self.dataset)
@@ -144,16 +159,14 @@ class DeviceLoader(object):
                 self._all.pop()
             self._owned = list(range(self.rank, len(self._all), self.world))
             self.loader = DataLoader(self.dataset, batch_sampler=[self._all[b] for b in self._owned], num_workers=workers,
-                                     collate_fn=_collate, pin_memory=self._pin(), persistent_workers=workers > 0,
+                                     collate_fn=_collate, pin_memory=self._pin(), persistent_workers=persistent,
                                      multiprocessing_context=_worker_context(workers))
         elif self.prefetch > 0 and workers > 0 and torch.cuda.is_available() and self._make_ring(sampler, shuffle, drop_last, workers):
             pass                                                         # self.loader / self.ring set by _make_ring
         else:
             self.loader = DataLoader(self.dataset, batch_size=batch_size, sampler=sampler, shuffle=shuffle and sampler is None,
                                      num_workers=workers, collate_fn=_collate, drop_last=drop_last, pin_memory=self._pin(),
-                                     multiprocessing_context=_worker_context(workers),
-                                     persistent_workers=workers > 0)     # (an epoch of RGBNT201 is a few hundred batches:
-                                     # respawning W processes that import torch at every epoch costs seconds)
+                                     multiprocessing_context=_worker_context(workers), persistent_workers=persistent)
 
     ring = None
 
@@ -178,7 +191,11 @@ class DeviceLoader(object):
         base = torch.utils.data.RandomSampler(self.dataset) if (shuffle and sampler is None) else (
             sampler if sampler is not None else torch.utils.data.SequentialSampler(self.dataset))
         batches = torch.utils.data.BatchSampler(base, self.batch_size, drop_last)
-        self._slot_sampler = _SlotSampler(batches, slots)
+        # (a rank-sharded sampler exchanges its epoch order with a collective in prepare(): that stays at the epoch boundary,
+        # in the consumer's thread, in step with the other ranks)
+        self._continuous = os.environ.get("IEEE_LOADER_CONTINUOUS", "1") != "0" and not hasattr(base, "prepare")
+        self._it, self._epoch_pos = None, 0
+        self._slot_sampler = _SlotSampler(batches, slots, continuous=self._continuous)
         self.loader = DataLoader(_SlotDataset(self.dataset, ring), batch_size=None, sampler=self._slot_sampler, num_workers=workers,
                                  collate_fn=_identity, pin_memory=False, persistent_workers=True,
                                  multiprocessing_context=_worker_context(workers))
@@ -225,6 +242,16 @@ class DeviceLoader(object):
         if cuda and getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=dev, priority=-1)
         side = self._side_stream if cuda else None
+        # one producer at a time: a prefetch thread of an earlier, abandoned iteration (the consumer broke out of the epoch) may
+        # still be inside the DataLoader waiting for a worker -- it sees its stop flag at the next batch.  A second thread on the
+        # same persistent loader would iterate it concurrently and interleave the flip draws: wait for the old one, and refuse
+        # to go on if it does not end.
+        old = getattr(self, "_prefetch_thread", None)
+        if old is not None and old.is_alive():
+            old.join(timeout=120.0)
+            if old.is_alive():
+                raise RuntimeError("DeviceLoader: the prefetch thread of the previous iteration is still running (a decode worker "
+                                   "does not answer); not starting a second producer on the same loader")
         box = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
 
@@ -261,7 +288,7 @@ class DeviceLoader(object):
             except BaseException as e:          # hand the failure to the consumer instead of dying silently
                 put(e)
 
-        th = threading.Thread(target=work, name="ieee-loader-prefetch", daemon=True)
+        th = self._prefetch_thread = threading.Thread(target=work, name="ieee-loader-prefetch", daemon=True)
         th.start()
         try:
             while True:
@@ -280,14 +307,31 @@ class DeviceLoader(object):
                 yield batch
         finally:
             stop.set()
-            th.join(timeout=5.0)
+            th.join(timeout=5.0)          # (normally immediate; if it is still inside the DataLoader the next __iter__ waits for it)
+
+    def _epoch_source(self):
+        """the decoded batches of ONE epoch.  Continuous ring path: exactly len(self) items of the one iterator that lives
+        across epochs (an epoch the consumer abandoned half way is dropped: fresh iterator, fresh draw of the order)"""
+        if self.ring is None or not getattr(self, "_continuous", False):
+            return iter(self.loader)
+
+        def one_epoch():
+            if self._it is None or self._epoch_pos != 0:
+                self._it = iter(self.loader)
+            n = len(self._slot_sampler)
+            self._epoch_pos = 0
+            for k in range(n):
+                self._epoch_pos = k + 1          # (a consumer that stops here leaves a position != 0 behind)
+                yield next(self._it)
+            self._epoch_pos = 0
+        return one_epoch()
 
     def _batches(self):
         sampler = getattr(self, "loader_base_sampler", None) if self.ring is not None else getattr(self.loader, "sampler", None)
         if hasattr(sampler, "prepare"):          # rank-sharded identity sampler: draw / exchange the epoch's order here, in
             sampler.prepare()                    # the main process, not at the DataLoader's first prefetch
         lo, hi = getattr(sampler, "lo", None), getattr(sampler, "hi", None)
-        for k, batch in enumerate(self.loader):
+        for k, batch in enumerate(self._epoch_source()):
             raw = batch['img']
             if raw is None:                                          # ring path: the images sit in the pinned ring slot
                 rows, slot = int(batch.pop('rows')), int(batch.pop('slot'))
@@ -335,10 +379,10 @@ def build_loaders(dataset, height=256, width=128, transforms='random_flip', batc
                                   rank=rank, world=world)
     if world > 1:
         train = DeviceLoader(dataset.train, tr, sampler.local_batch, sampler=sampler, workers=workers, drop_last=True,
-                             global_rows=sampler.global_batch, prefetch=prefetch)
+                             global_rows=sampler.global_batch, prefetch=prefetch, persistent=True)
     else:
         train = DeviceLoader(dataset.train, tr, batch_size_train, sampler=sampler, workers=workers, drop_last=True,
-                             prefetch=prefetch)
+                             prefetch=prefetch, persistent=True)
     query = DeviceLoader(dataset.query, te, batch_size_test, workers=workers, rank=rank, world=world)
     gallery = DeviceLoader(dataset.gallery, te, batch_size_test, workers=workers, rank=rank, world=world)
     return train, query, gallery

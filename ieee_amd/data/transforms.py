@@ -131,12 +131,20 @@ class DeviceTransform(object):
             src = images.to(dev, non_blocking=True)
             # the flip flags through a small ring of pinned buffers: a pageable source would make this copy synchronous --
             # the prefetch thread would stall until its stream has drained behind the train step's kernels
-            ring = self.__dict__.setdefault("_flip_ring", {"at": 0, "bufs": [None] * 8})
+            # (a slot is rewritten 8 calls later -- under three batches; the copy out of it may still be queued behind other
+            # streams' work then, e.g. with one hardware queue per priority in a data-parallel job: an event per slot, recorded
+            # behind the copy and waited for before the host writes the slot again, makes the reuse safe whatever the backlog)
+            ring = self.__dict__.setdefault("_flip_ring", {"at": 0, "bufs": [None] * 8, "done": [None] * 8})
             slot = ring["at"] = (ring["at"] + 1) % 8
+            if ring["done"][slot] is not None:
+                ring["done"][slot].synchronize()
             if ring["bufs"][slot] is None or ring["bufs"][slot].numel() < n:
                 ring["bufs"][slot] = torch.empty(max(n, 256), dtype=torch.uint8).pin_memory()
             ring["bufs"][slot][:n].copy_(torch.from_numpy(flips))
             fl = ring["bufs"][slot][:n].to(dev, non_blocking=True)
+            if ring["done"][slot] is None:
+                ring["done"][slot] = torch.cuda.Event()
+            ring["done"][slot].record(torch.cuda.current_stream(dev))
             tmp = torch.empty((n, t["tmp_rows"], self.width, 3), dtype=torch.uint8, device=dev) if t["need_h"] else None
             mean = (_lib.ctypes.c_float * 3)(*self.mean.tolist())
             std = (_lib.ctypes.c_float * 3)(*self.std.tolist())

@@ -67,7 +67,7 @@ def _cycle(loader):
             yield batch
 
 
-def measure(workers=(4, 8, 16, 32), steps=40, warm=8, B=64, size=(256, 128), engine=None, device=None, root=None, prefetch=None):
+def measure(workers=(4, 8, 16, 32), steps=40, warm=8, B=64, size=(256, 128), engine=None, device=None, root=None, prefetch=None, rounds=3):
     """returns the `loader` object of the bench line"""
     import contextlib
     import io
@@ -103,11 +103,15 @@ def measure(workers=(4, 8, 16, 32), steps=40, warm=8, B=64, size=(256, 128), eng
         step_ms = (time.time() - t0) / steps * 1e3
         out["resident_step_ms"] = step_ms
         out["host_to_device_MB_per_step"] = B * 3 * size[0] * size[1] * 3 / 1e6        # decoded uint8 HWC, before the resize
+        # one loader per worker count, built once and kept (persistent workers); the worker counts are measured in
+        # INTERLEAVED rounds -- W1, W2, W3, W1, W2, W3, ... -- so that a drift of the box hits every setting alike, and every
+        # setting is reported as median and min - max over the rounds
+        loaders, its, alone = {}, {}, {}
         for W in workers:
             with contextlib.redirect_stdout(io.StringIO()):
                 kw = {} if prefetch is None else {"prefetch": prefetch}
-                train, _, _ = build_loaders(ds, height=256, width=128, batch_size_train=B, num_instances=4, workers=W, **kw)
-            it = _cycle(train)
+                loaders[W], _, _ = build_loaders(ds, height=256, width=128, batch_size_train=B, num_instances=4, workers=W, **kw)
+            it = its[W] = _cycle(loaders[W])
             for _ in range(warm):          # worker start-up, table upload
                 b = next(it)
             torch.cuda.synchronize()
@@ -115,26 +119,46 @@ def measure(workers=(4, 8, 16, 32), steps=40, warm=8, B=64, size=(256, 128), eng
             for _ in range(steps):
                 b = next(it)
             torch.cuda.synchronize()
-            alone = steps * B / (time.time() - t0)
-            for _ in range(3):
-                eng.forward_backward(next(it))
-            torch.cuda.synchronize()
-            t0, waited = time.time(), 0.0
-            for _ in range(steps):
-                t1 = time.time()
-                b = next(it)
-                waited += time.time() - t1
-                eng.forward_backward(b)
-            torch.cuda.synchronize()
-            dt = time.time() - t0
-            out["per_workers"][str(W)] = {"loader_alone_triples_per_s": alone, "with_train_step_triples_per_s": steps * B / dt,
-                                          "ms_per_step": dt / steps * 1e3, "host_wait_for_batch_ms_per_step": waited / steps * 1e3,
-                                          "frac_of_resident_step_rate": step_ms / (dt / steps * 1e3)}
-            del it, train
-        best = max(out["per_workers"].items(), key=lambda kv: kv[1]["with_train_step_triples_per_s"])
-        ok = [int(w) for w, v in out["per_workers"].items() if v["frac_of_resident_step_rate"] >= 0.97]
+            alone[W] = steps * B / (time.time() - t0)
+        per_epoch = len(loaders[workers[0]])
+        runs = {W: [] for W in workers}
+        for r in range(rounds):
+            for W in workers:
+                it = its[W]
+                for _ in range(3):
+                    eng.forward_backward(next(it))
+                torch.cuda.synchronize()
+                t0, waits = time.time(), []
+                for _ in range(steps):
+                    t1 = time.time()
+                    b = next(it)
+                    waits.append(time.time() - t1)
+                    eng.forward_backward(b)
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+                runs[W].append({"ms_per_step": dt / steps * 1e3, "frac": step_ms / (dt / steps * 1e3),
+                                "wait_ms_per_step": sum(waits) / steps * 1e3, "longest_wait_ms": max(waits) * 1e3,
+                                "waits_over_2ms": sum(1 for w in waits if w > 2e-3)})
+        med = lambda v: sorted(v)[len(v) // 2]
+        for W in workers:
+            fr = [x["frac"] for x in runs[W]]
+            out["per_workers"][str(W)] = {
+                "loader_alone_triples_per_s": alone[W],
+                "with_train_step_triples_per_s": B / (med([x["ms_per_step"] for x in runs[W]]) * 1e-3),
+                "ms_per_step": med([x["ms_per_step"] for x in runs[W]]),
+                "frac_of_resident_step_rate": med(fr), "frac_min": min(fr), "frac_max": max(fr),
+                "spread_between_rounds": (max(fr) - min(fr)) / med(fr),
+                "host_wait_for_batch_ms_per_step": med([x["wait_ms_per_step"] for x in runs[W]]),
+                "longest_single_wait_ms": max(x["longest_wait_ms"] for x in runs[W]),
+                "waits_over_2ms_per_round": [x["waits_over_2ms"] for x in runs[W]], "rounds": rounds}
+        out["batches_per_epoch"] = per_epoch
+        del its, loaders
+        # the smallest worker count whose WORST round keeps the GPU step at >= 97 % of the resident-batch rate
+        ok = [int(w) for w, v in out["per_workers"].items() if v["frac_min"] >= 0.97]
+        best = max(out["per_workers"].items(), key=lambda kv: kv[1]["frac_min"])
         out["recommended_workers"] = min(ok) if ok else int(best[0])
         out["gpu_step_stops_waiting_at_workers"] = min(ok) if ok else None
+        out["recommendation_rule"] = "smallest worker count whose minimum over %d interleaved rounds is >= 0.97 of the resident-batch rate" % rounds
         out["host_logical_cpus"] = os.cpu_count()
     finally:
         if own_root:
@@ -148,6 +172,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--size", default="256x128")
     ap.add_argument("--prefetch", type=int, default=None)
+    ap.add_argument("--rounds", type=int, default=3)
     a = ap.parse_args()
     h, w = (int(v) for v in a.size.split("x"))
-    print(json.dumps(measure(tuple(int(v) for v in a.workers.split(",")), steps=a.steps, size=(h, w), prefetch=a.prefetch), indent=1))
+    print(json.dumps(measure(tuple(int(v) for v in a.workers.split(",")), steps=a.steps, size=(h, w), prefetch=a.prefetch, rounds=a.rounds), indent=1))

@@ -102,12 +102,25 @@ def test_prefetched_loader_yields_the_same_batches_bit_for_bit(tmp_path):
     for prefetch in (0, 2):
         random.seed(3); np.random.seed(3); torch.manual_seed(3)
         train, _, _ = D.build_loaders(ds, 256, 128, "random_flip", batch_size_train=8, workers=2, prefetch=prefetch)
+        assert getattr(train, "_continuous", False) == (prefetch > 0)
         out = []
-        for b in train:
-            junk = torch.randn(512, 512, device="cuda") @ torch.randn(512, 512, device="cuda")    # the consumer's own work
-            out.append((b['pid'].clone(), [x.clone() for x in b['img']], junk.sum()))
+        # THREE epochs: the prefetching loader keeps ONE index stream across epochs (the workers start on epoch k + 1 while
+        # epoch k is still being consumed, its order drawn early) -- same batches, same flips, same pixels, epoch after epoch
+        for epoch in range(3):
+            n = 0
+            for b in train:
+                junk = torch.randn(512, 512, device="cuda") @ torch.randn(512, 512, device="cuda")    # the consumer's own work
+                out.append((b['pid'].clone(), [x.clone() for x in b['img']], junk.sum()))
+                n += 1
+            assert n == len(train)
         torch.cuda.synchronize()
         seen[prefetch] = out
-    assert len(seen[0]) == len(seen[2]) >= 2
+    assert len(seen[0]) == len(seen[2]) >= 6
     for (p0, x0, _), (p2, x2, _) in zip(seen[0], seen[2]):
         assert torch.equal(p0, p2) and all(torch.equal(a, b) for a, b in zip(x0, x2))
+    # an epoch abandoned half way is dropped: the next one starts with a fresh draw, complete and in order
+    it = iter(train)
+    first = next(it)
+    del it
+    again = [b['pid'].clone() for b in train]
+    assert len(again) == len(train) and sorted(torch.cat(again).tolist()) == sorted(torch.cat([p for p, _, _ in seen[2][:len(train)]]).tolist())
