@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_tiled_kernel(const T* __res
 
 // the totals kernels pay a prologue per workgroup: fewer, longer-lived workgroups than the plain passes -- ONE resident wave of
 // them (256 CUs x 8 workgroups of 256 threads, over the modalities of the launch).  B = 64 step, three interleaved rounds:
-// 256 per modality 14.60 ms, 384 14.50, 512 14.45, 682 14.43, 1024 14.46, 2048 14.80, 4096 15.05 (scripts/r4_ab.sh)
+// 256 per modality 14.60 ms, 384 14.50, 512 14.45, 682 14.43, 1024 14.46, 2048 14.80, 4096 15.05 (scripts/experiments/r4_ab.sh)
 static int tot_blocks(int64_t chunks, int64_t groups) {
   static const int64_t fixed = getenv("IEEE_BN_TOTALS_BLOCKS") ? atoll(getenv("IEEE_BN_TOTALS_BLOCKS")) : 0;
   const int64_t cap = fixed > 0 ? fixed : std::max<int64_t>(256, 2048 / std::max<int64_t>(groups, 1));
@@ -980,7 +980,7 @@ static int tot_blocks(int64_t chunks, int64_t groups) {
 }
 
 static int ew_blocks(int64_t chunks) {
-  static const int64_t cap = getenv("IEEE_EW_BLOCKS") ? atoll(getenv("IEEE_EW_BLOCKS")) : 8192;   // 4096: +0.13 ms per step; 16384 and more: same as 8192 (scripts/scan_ew.sh)
+  static const int64_t cap = getenv("IEEE_EW_BLOCKS") ? atoll(getenv("IEEE_EW_BLOCKS")) : 8192;   // 4096: +0.13 ms per step; 16384 and more: same as 8192 (scripts/experiments/scan_ew.sh)
   int64_t b = (chunks + 255) / 256;
   if (b > cap) b = cap;
   if (b < 1) b = 1;

@@ -1676,7 +1676,7 @@ static void launch_gather_mode(int mode, dim3 grid, size_t smem, hipStream_t st,
 
 // Tile / pipeline choice of one gather launch (bf16 vector path).  wgs = workgroups of the 128x128 tiling.
 struct GatherPlan { int bn, pipe; };
-// Measured on the full training step (profiles/r01 notes, scripts/variant_scan.sh): the single-stage LDS-DMA
+// Measured on the full training step (profiles/r01 notes, scripts/experiments/variant_scan.sh): the single-stage LDS-DMA
 // pipeline (PIPE 1: 118 VGPRs, 35 KB LDS -> 4 workgroups per CU) beats register staging (3 per CU) on almost every
 // layer (-7 % gather time); launches of <= 512 workgroups (Cout or Cin = 256 on the 16x8 maps) run faster still on
 // 128x64 tiles (twice the workgroups).  Deeper rings (PIPE 2-4) and the 128x256 tile lose: fewer workgroups per CU.
@@ -1796,7 +1796,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
       static const int f_style_env = getenv("IEEE_PATCH_STYLE") ? atoi(getenv("IEEE_PATCH_STYLE")) : -1;
       static const int f_bn = getenv("IEEE_PATCH_BN") ? atoi(getenv("IEEE_PATCH_BN")) : 0;
       const int bn = (N <= 64) ? 64 : (f_bn ? f_bn : plan.bn);
-      // measured per layer (scripts/scan_r3g.sh): the two-stage weight ring wins where the tile is 128 x 64 (39 KB of LDS keeps
+      // measured per layer (scripts/experiments/scan_r3g.sh): the two-stage weight ring wins where the tile is 128 x 64 (39 KB of LDS keeps
       // 4 workgroups per CU: 256->256 755 -> 923 TFLOP/s, 64->64 608 -> 650) and loses at 128 x 128 (55 KB -> 2 per CU:
       // 512->512 1 320 -> 1 234, 128->128 871 -> 767)
       const int f_style = f_style_env >= 0 ? f_style_env : (bn == 64 ? 0 : 1);
@@ -2094,7 +2094,7 @@ static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups,
   static const int64_t f_small = getenv("IEEE_WGRAD_TARGET_SMALL") ? atoll(getenv("IEEE_WGRAD_TARGET_SMALL")) : 448;
   const int64_t per_split_bytes = groups * Co * ncols * 4;
   // round 2 (parallel slab reduce): the small-weight layers WITH taps (layer1 3x3, the stem: X is re-read per tap from
-  // L2, few output tiles) gain 20-25 % from twice the workgroups; the 1x1 ones still lose (scripts/scan_wt.sh)
+  // L2, few output tiles) gain 20-25 % from twice the workgroups; the 1x1 ones still lose (scripts/experiments/scan_wt.sh)
   static const int64_t f_small_taps = getenv("IEEE_WGRAD_TARGET_SMALL_TAPS") ? atoll(getenv("IEEE_WGRAD_TARGET_SMALL_TAPS")) : 896;
   const int64_t small = taps > 1 ? f_small_taps : f_small;
   static const int64_t f_big = getenv("IEEE_WGRAD_TARGET_BIG") ? atoll(getenv("IEEE_WGRAD_TARGET_BIG")) : 448;

@@ -82,6 +82,9 @@ struct DistEpi {
           for (int e = 0; e < 4; ++e) v[e] *= sq * gsv[e];
         }
         float* o = out + (int64_t)row * ldo + col;
+#ifdef IEEE_DIST_NOSTORE_PROBE   // measurement build only (scripts/distmat_nostore_probe.sh): the GEMM with everything but its 4 GB of stores
+        if (!(value(v[0], a, gnv[0]) != value(v[0], a, gnv[0]))) continue;
+#endif
         if (vec_ok) {
           typedef float f32x4v __attribute__((ext_vector_type(4)));
           const f32x4v ov = {value(v[0], a, gnv[0]), value(v[1], a, gnv[1]), value(v[2], a, gnv[2]), value(v[3], a, gnv[3])};

@@ -1,4 +1,4 @@
-"""compare per-launch conv tables (scripts/variant_scan.sh) and print, per (layer shape, kind), each variant's time"""
+"""compare per-launch conv tables (scripts/experiments/variant_scan.sh) and print, per (layer shape, kind), each variant's time"""
 import collections
 import csv
 import glob
