@@ -35,7 +35,7 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICR
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 TRAIN_GFLOP_PER_TRIPLE = 92.24
-# Algorithmic HBM floor of one train step (SURVEY.md §8d's counting): every conv output written once and
+# Algorithmic HBM floor of one train step (LABNOTES.md §5, SURVEY.md §8d's counting): every conv output written once and
 # read once in the forward (26.47 M elements per triple, bf16), the same bytes again for the dgrad pass (dY read, dX
 # written) and for the wgrad operands (dY and X read); SGD-nesterov reads p, g, momentum and writes p, momentum (20 B per
 # parameter); the packed bf16 operands (forward + dgrad form) are written and read once each.
@@ -418,7 +418,7 @@ def main():
             # which form of the data-parallel step runs: the overlapped one (5 backward parts, gradient slices all-reduced
             # from a communication stream while the next part computes, optimizer slices behind them) unless the plain one
             # (whole backward, one all-reduce pass, one update) is clearly faster HERE -- how the runtime maps the step's
-            # streams and RCCL's onto hardware queues decides whether the overlap materialises ("Round 4"), and a
+            # streams and RCCL's onto hardware queues decides whether the overlap materialises (LABNOTES.md, "Round 4"), and a
             # single-GPU box cannot tell.  Timed on every rank, decided on the slowest rank's figures.
             def cal_steps(n):
                 barrier()
@@ -521,7 +521,7 @@ def main():
                     "frac_of_hbm_peak": (pmc_bytes / step_s / 1e9 / PEAK_HBM_GBS) if pmc_bytes else None,
                     "floor_TBps_at_this_step_time": floor / step_s / 1e12,
                     "floor": "3 passes x (conv outputs written + read once, bf16) + SGD 20 B/param + packed operands "
-                             "written + read once (DESIGN.md section 5)"}
+                             "written + read once (LABNOTES.md section 5)"}
 
     # N = 1: the fixed cost of the N > 1 code path.  The SAME engine runs the staged data-parallel step -- backward in 5
     # parts, every part's gradient slices all-reduced over a 1-rank RCCL group from the communication stream, the

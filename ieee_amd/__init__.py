@@ -12,7 +12,7 @@ import os as _os
 # (compute, weight gradients at low priority, branch, optimizer / communication, torch's high-priority collective stream);
 # with 4 or more queues per priority, and the collective stream created BEFORE the executor's streams -- the order of a
 # torchrun job -- the two main streams of the step stop overlapping on this runtime: 22.9 ms per step instead of 14.7
-# (8 and 16: 20.5-21 ms in either order; 1, 2 and 3: 14.5-15.1 in every order tried; scripts/dp_order_probe.py, DESIGN.md
+# (8 and 16: 20.5-21 ms in either order; 1, 2 and 3: 14.5-15.1 in every order tried; scripts/dp_order_probe.py, LABNOTES.md
 # section 6).  In a data-parallel job (WORLD_SIZE > 1) ONE queue per priority: the compute stream then never shares a queue
 # with the communication stream (which runs at high priority there, beside torch's collective stream), so the gradient
 # all-reduces overlap the backward whatever order the streams were created in -- with 2 queues they overlap only when the

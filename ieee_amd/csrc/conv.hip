@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ?
 
 // ------------------------------------------------------------------ 3x3 / stride 1 / pad 1 with the input patch in LDS
 // The implicit-GEMM kernel above fetches the A operand of a 3x3 conv once PER TAP: nine L2 -> LDS transfers of (mostly)
-// the same pixels per 64-channel chunk, and the per-CU L2 -> LDS path is what bounds it.  Here a
+// the same pixels per 64-channel chunk, and the per-CU L2 -> LDS path is what bounds it (LABNOTES.md section 4).  Here a
 // workgroup's 128 GEMM rows are RT whole rows of one image (RT x Wm = 128: 16 x 8, 8 x 16 or 4 x 32 pixels) and the input
 // patch those rows see -- (RT + 2) x (Wm + 2) pixels x 64 channels, zero halo included -- is brought into LDS ONCE per
 // channel chunk; the nine taps read their A fragments from it at shifted addresses (tap (dr, ds) = a constant byte offset

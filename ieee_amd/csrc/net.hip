@@ -30,7 +30,7 @@ struct Tensor {
 // Same-address atomics retire at ~23 ns each -- a conv of 64 / 256 / 1 024 row tiles pays +1 / +4.5 / +24 us for its sums
 // with one copy of the totals -- so units of more than 64 tiles spread their adders over IEEE_BN_TOTALS_REP copies
 // (default 4; the prologue that adds the copies up costs +1.3 us at 4, +3.6 at 8: scripts/bn_totals_probe.py).
-// Returns the copies to use, 0 = not on this path.  Measurements: DESIGN.md, "Round 4".
+// Returns the copies to use, 0 = not on this path.  Measurements: LABNOTES.md, "Round 4".
 static constexpr int TOT_REP_MAX = 8;
 static int totals_tiles() {
   static const int t = getenv("IEEE_BN_TOTALS_TILES") ? atoi(getenv("IEEE_BN_TOTALS_TILES")) : 1024;
@@ -787,7 +787,7 @@ struct Run {
             bool prev_mask_tensor = false, int addend_stride = 1, const ConvUnit* prev_ds = nullptr) {
     const int64_t ldd = ieee_conv_packed_ld(n.dtype, u.Co, u.R, u.S);
     const bool fuse = prev != nullptr && n.dtype == IEEE_BF16;
-    static const bool ds_sums = getenv("IEEE_DS_SUMS") && atoi(getenv("IEEE_DS_SUMS")) != 0;   // measured: no gain
+    static const bool ds_sums = getenv("IEEE_DS_SUMS") && atoi(getenv("IEEE_DS_SUMS")) != 0;   // measured: no gain (LABNOTES.md)
     const bool fuse2 = fuse && prev_ds != nullptr && ds_sums && !branch_enabled(2);
     fused_bwd = fuse;
     n.bwd_totals_state = fuse && !fuse2 && use_totals(*prev) && !frz(*prev);

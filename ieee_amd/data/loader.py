@@ -238,7 +238,7 @@ class DeviceLoader(object):
         dev = torch.cuda.current_device() if cuda else None
         # high priority: the copy + transform of a batch is ~0.1 ms of GPU work that must not queue behind a 15 ms step
         # (one stream per loader, kept across epochs: stream churn in the middle of training re-shuffles the runtime's
-        # hardware-queue assignment, DESIGN.md round-4 log)
+        # hardware-queue assignment, LABNOTES.md round-4 log)
         if cuda and getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=dev, priority=-1)
         side = self._side_stream if cuda else None

@@ -327,7 +327,7 @@ def launch(target, nprocs, args=(), port=None, queues=None, timeout=None, grace=
                                                        rank 0 keeps this process's stdout, the others write theirs to stderr
       launch(fn, 8, args=(cfg,))                       a picklable callable: fn(rank, world, *args) in freshly SPAWNED
                                                        interpreters (never fork: a forked child of a process with a live HIP
-                                                       context costs 364 ms per step while it lives)
+                                                       context costs 364 ms per step while it lives, LABNOTES.md)
 
     The calling process must not have touched the GPU and is not replaced (nothing is exec'd): it only waits, and returns
     the worst exit code (0 = every rank succeeded).  When a rank dies the others are given `grace` seconds, then ended."""

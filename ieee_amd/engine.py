@@ -149,7 +149,7 @@ class Engine(object):
         (torchreid/data/datamanager.py:214-229; scripts/default_config.py:20: workers = 1 by default) -- on Linux that fork()s
         the training process at the start of every epoch.  Beside a live HIP context the fork write-protects the page tables,
         the driver re-validates the process's GPU-visible host memory, and the queues stand still meanwhile: measured
-        364 ms per train step (instead of 14.5) while a forked child lives, 78 ms per 1 KB copy ("fork() beside a
+        364 ms per train step (instead of 14.5) while a forked child lives, 78 ms per 1 KB copy (LABNOTES.md, "fork() beside a
         live HIP context").  Warn once, with the fix."""
         if getattr(self, "_fork_warned", False):
             return
@@ -485,7 +485,7 @@ class _FusedStepMixin(object):
             main = torch.cuda.current_stream()
             if not hasattr(self, "_comm_stream"):
                 # high priority in a real data-parallel job (with ONE hardware queue per priority, ieee_amd/__init__.py, it
-                # then shares torch's collective stream's queue and never the compute stream's: DESIGN.md section 6); normal
+                # then shares torch's collective stream's queue and never the compute stream's: LABNOTES.md section 6); normal
                 # priority in the single-GPU 1-rank leg of bench.py, where two queues per priority are on
                 prio = os.environ.get("IEEE_COMM_PRIO")
                 # (with two or more queues per priority a busy high-priority communication stream beside torch's busy

@@ -90,7 +90,7 @@ def test_oracle_run_loop_matches_reference(G):
     ref = G["run2/summaries"]
     got = np.array([[s[k] for k in KEYS_3M] for s in summaries])
     # the first epoch agrees to rounding; later steps inherit the gradient noise floor of the earlier ones through the
-    # updated weights (a flipped ReLU mask changes a gradient by O(|g|): DESIGN.md "Parity"), measured 6e-4 here
+    # updated weights (a flipped ReLU mask changes a gradient by O(|g|): LABNOTES.md "Parity"), measured 6e-4 here
     np.testing.assert_allclose(got[:2, :6], ref[:2, :6], rtol=2e-5, atol=1e-4)
     np.testing.assert_allclose(got[2:, :6], ref[2:, :6], rtol=4e-3, atol=1e-3)
     np.testing.assert_allclose(got[:2, 6:], ref[:2, 6:], atol=1e-6)

@@ -97,7 +97,7 @@ def test_softmax_engine_step_matches_reference(G):
     np.testing.assert_allclose([float(s[k]) for k in KEYS_SM], G["softmax8/summary"], rtol=1e-4, atol=1e-4)
     names = [str(n) for n in G["softmax8/param_names"]]
     assert [n in m._no_grad_names() for n in names] == list(G["softmax8/grad_none"])
-    # noise floor of this quantity between two runs of the reference itself: ~0.14 (DESIGN.md "Parity")
+    # noise floor of this quantity between two runs of the reference itself: ~0.14 (LABNOTES.md "Parity")
     assert sampled_update_error(m, state, names, G["softmax8/post_param_stats"]) < 0.25
     sd = m.state_dict()
     bnames = [str(n) for n in G["softmax8/buffer_names"]]
@@ -159,7 +159,7 @@ def test_750_classes_softmax_leg_matches_reference(G):
 @pytest.mark.parametrize("leg", ["full", "noatt", "nocim", "norem", "3m_off"])
 def test_config5_bf16_b32_ablation_sweep(leg):
     """config 5 as it is run: 32 triples per rank, 750 classes, bf16, one leg per ablation.  bf16 on this random-init net
-    cannot be held to fp32 values (DESIGN.md "Parity"), so the bar is the one of the headline configuration: the step's
+    cannot be held to fp32 values (LABNOTES.md "Parity"), so the bar is the one of the headline configuration: the step's
     loss within 2 % of the fp32 parity mode on the same inputs, finite gradients everywhere, parameters moved."""
     C, B = 750, 32
     flags = {"noatt": dict(attention=False), "nocim": dict(interaction=False), "norem": dict(using_REM=False)}.get(leg, {})

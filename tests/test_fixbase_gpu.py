@@ -58,7 +58,7 @@ def test_frozen_children_match_the_reference_step(golden_dir, tag, seed):
     assert [bool(torch.equal(sd[n], before[n])) for n in names] == list(G[tag + "/param_unchanged"])
     # the updates of the open children: every sampled entry of (parameter after - before) against the reference's, relative to
     # the tensor's largest sampled update -- the bar of the other engine tests (the ReLU-flip noise floor of a gradient on
-    # these inputs, DESIGN.md section 4, is a few per cent of the tensor's scale)
+    # these inputs, LABNOTES.md section 4, is a few per cent of the tensor's scale)
     from tests.test_engine_r2_gpu import sampled_update_error
     state = {k: v.cpu() for k, v in before.items()}
     assert sampled_update_error(m, state, names, G[tag + "/post_param_stats"]) < 0.25
@@ -72,7 +72,7 @@ def test_frozen_children_match_the_reference_step(golden_dir, tag, seed):
     assert all(p.requires_grad for p in m.parameters()) and m._frozen_mask == 0
     s2 = eng.forward_backward(batch())
     # second step: the parameters already carry the first step's gradient noise (ReLU flips on this untamed random-init net:
-    # DESIGN.md section 4 -- the reference against ITSELF with another thread count moves a step-3 loss by 1e-3 and single
+    # LABNOTES.md section 4 -- the reference against ITSELF with another thread count moves a step-3 loss by 1e-3 and single
     # tensors by 5 %); measured here: total loss 0.6 %, one modality's cross entropy 1.3 % from the reference.  Losses to
     # 3 %, accuracies to three (sample, head) flips of the 8 x 6 that make one modality's number.
     got2, want2 = np.array([float(s2[k]) for k in KEYS]), G[tag + "/summary_step2"]

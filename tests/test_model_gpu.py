@@ -68,7 +68,7 @@ def test_train_forward_backward_matches_reference(G, tag, B, seed):
     # Gradient tolerance = the reference's OWN reproducibility on these inputs: the same reference code run
     # with 1 vs 8 CPU threads differs by 1.5 % (median) / 14 % (max) of each tensor's max|g| — single ReLU
     # masks flip where a pre-activation sits within fp32 rounding of 0 (measured while building the
-    # fixtures; DESIGN.md "Parity").  Forward outputs and losses above are held to 1e-3 / 1e-4; the
+    # fixtures; LABNOTES.md "Parity").  Forward outputs and losses above are held to 1e-3 / 1e-4; the
     # backward kernels are each held to tight tolerances in tests/test_kernels_gpu.py on flip-free data.
     for k in ("classifier_R.0.weight", "backbone.0.bn1.weight", "reduce_layer.2.layers.1.weight", "fc_T.3.1.bias",
               "backbone.1.conv1.weight"):
@@ -283,7 +283,7 @@ def test_fixed_point_batchnorm_totals_through_the_whole_backward(tmp_path):
     its own gradient buffer bit for bit and (b) the number of copies the adders are spread over (1 / 4 / 8) does not change a
     bit.  (c) The totals path and the partial-sum path differ by the last bit of a float sum per channel: the first block's
     statistics agree to 1e-6 and its output to a bf16 rounding on a few elements.  (Further down this random-init trunk
-    multiplies any difference by 1.3-2 per unit -- 3e-8 in the first statistics is 1e-2 by layer3, DESIGN.md section 4 --
+    multiplies any difference by 1.3-2 per unit -- 3e-8 in the first statistics is 1e-2 by layer3, LABNOTES.md section 4 --
     so the whole-gradient comparison between the two paths says nothing; the backward of the totals path is held to
     autograd unit by unit in test_backward_units_gpu.py, where it is the default.)"""
     import subprocess

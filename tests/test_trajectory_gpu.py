@@ -7,7 +7,7 @@ weight decay 5e-4), optim/lr_scheduler.py:46-60 (MultiStepLR), engine.py:339-441
 recipe of configs/RGBNT_ieee_part_margin.yaml:17-38 (lr 1e-3, two tenfold decays) compressed to 120 steps.
 
 Fixture: the tamed generated state (tests/util_model.py: tame_ -- on the untamed random-init net train-mode BatchNorm is
-chaotic and no two arithmetic modes of ANY implementation agree on a gradient) and identity-separable
+chaotic and no two arithmetic modes of ANY implementation agree on a gradient, LABNOTES.md section 4) and identity-separable
 synthetic triples (detgen.generate_identity_images): 8 identities x 8 triples, batches of 4 identities x 4 instances as
 RandomIdentitySampler hands them out.  The band around the fp32 curve is justified by a control: the SAME fp32 mode started
 from parameters jittered by 2^-12 relative -- what a perturbation far below bf16's own rounding does to the curve."""
