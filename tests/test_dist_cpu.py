@@ -276,6 +276,13 @@ def test_launch_argv_starts_one_rank_per_process_and_relays_rank0(tmp_path):
     assert all(("rank %d of 4: sum 10" % k) in err for k in (1, 2, 3))
 
 
+def test_launch_eight_ranks_like_one_node(tmp_path):
+    """BASELINE config 3's rank count through the same path `python bench.py --gpus 8` takes"""
+    r = _launch_parent(tmp_path, 8)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert [l for l in r.stdout.decode().strip().splitlines() if not l.startswith("[Gloo]")] == ["rank 0 of 8: sum 36"]
+
+
 def test_launch_keeps_an_exported_queue_count(tmp_path):
     r = _launch_parent(tmp_path, 2, queues="3", call_queues="'3'")
     assert r.returncode == 0, r.stderr.decode()[-2000:]

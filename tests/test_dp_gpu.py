@@ -289,4 +289,12 @@ def test_bench_starts_its_own_ranks_from_plain_python():
     assert sorted(rc["allreduce_ms_per_part"]) == ["0", "1", "2", "3", "4"] and all(v > 0 for v in rc["allreduce_ms_per_part"].values())
     total = sum(rc["allreduce_bytes_per_part"].values())                 # one pass over the flat fp32 gradient (438 MB)
     assert 0.99 * 4 * 109499337 <= total <= 4 * 109499337, total
-    assert line["launch"]["how"] == "self-spawned" and line["launch"]["hw_queues"] == 1
+    assert line["launch"]["how"] == "self-spawned" and line["launch"]["hw_queues"] == 1 and line["launch"]["grad_dtype"] == "fp32"
+    # the same launch with the bf16 wire format: half the bytes per part, says so in the line
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "8"], env=dict(env, IEEE_DP_GRAD_DTYPE="bf16", IEEE_DP_OVERLAP="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    half = json.loads([l for l in r.stdout.decode().splitlines() if l.strip()][0])
+    assert half["launch"]["grad_dtype"] == "bf16" and "dp_calibration" not in half           # IEEE_DP_OVERLAP set: no calibration
+    assert 2 * sum(half["rccl"]["allreduce_bytes_per_part"].values()) == total

@@ -64,3 +64,44 @@ def test_no_warning_without_the_hazard(monkeypatch, kw, live):
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         eng._warn_forking_loader()
+
+
+# ---- range guard of the fixed-point BatchNorm totals: what the engine does with the executor's report words ----------------
+class _FakeNet(object):
+    def __init__(self, words):
+        self.words, self.reads = list(words), 0
+
+    def bn_overflow(self):
+        self.reads += 1
+        w, self.words = tuple(self.words), [0, 0, 0, 0]          # read AND clear, like ieee_net_bn_overflow
+        return w
+
+
+def _fused_engine():
+    from ieee_amd.engine import _FusedStepMixin
+    return _FusedStepMixin()
+
+
+def test_clamped_batchnorm_tile_raises_and_names_the_switch():
+    from ieee_amd._lib import IeeeAmdError
+    eng = _fused_engine()
+    with pytest.raises(IeeeAmdError, match="IEEE_BN_TOTALS_TILES=0") as e:
+        eng._check_bn_range(_FakeNet([1, 0, 0, 0]))
+    assert "forward" in str(e.value) and "backward (" not in str(e.value)
+    with pytest.raises(IeeeAmdError, match="backward"):
+        eng._check_bn_range(_FakeNet([0, 1, 1, 1]))
+
+
+def test_half_range_total_warns_once_and_healthy_steps_are_silent():
+    eng = _fused_engine()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        eng._check_bn_range(_FakeNet([0, 0, 0, 0]))
+        eng._check_bn_range(None)                                 # the generic (autograd) step has no executor
+    with pytest.warns(UserWarning, match="beyond half the range"):
+        eng._check_bn_range(_FakeNet([0, 0, 1, 0]))
+    net = _FakeNet([0, 0, 0, 1])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        eng._check_bn_range(net)                                  # warned once per engine
+    assert net.reads == 1 and net.words == [0, 0, 0, 0]
