@@ -889,7 +889,10 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
       IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev, (int64_t)N.pack_eval.size(), N.pack_blocks_eval, dt, st));
     if (training) N.eval_cache_valid = false;     // the step that follows changes parameters and running statistics
   }
-  if (training) IEEE_HIP(hipMemsetAsync(P(N.tickets), 0, 512 * 4, (hipStream_t)st));   // arrival tickets of the fused finalizes
+  {   // arrival tickets of the convs that finalize their BatchNorm themselves: only that (off by default) form reads them
+    static const bool f_fin = getenv("IEEE_BN_FIN_FUSE") && atoi(getenv("IEEE_BN_FIN_FUSE")) != 0;
+    if (training && f_fin) IEEE_HIP(hipMemsetAsync(P(N.tickets), 0, 512 * 4, (hipStream_t)st));
+  }
   if (training && dt == IEEE_BF16 && totals_tiles() > 0) {   // the units' fixed-point BatchNorm totals (forward AND backward) start at zero
     if (N.bn_overflow == nullptr) {
       IEEE_HIP(hipHostMalloc((void**)&N.bn_overflow, 4 * sizeof(int), hipHostMallocMapped));
