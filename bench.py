@@ -557,7 +557,7 @@ def main():
     # with event pairs on the communication stream; not part of the timed region)
     rccl = None
     if world > 1:
-        used_overlap = engine.dp_overlap
+        used_overlap = getattr(engine, "dp_overlap", None)     # (None: IEEE_DP_OVERLAP decided, no calibration ran)
         engine.dp_overlap = True             # the per-part event pairs exist in the overlapped form
         engine.time_collectives = []
         for _ in range(min(args.steps, 10)):
