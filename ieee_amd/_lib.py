@@ -78,6 +78,11 @@ def load():
         raise IeeeAmdError(
             "ieee_amd HIP library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C ieee_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # torch first: its wheel carries its own copy of the HIP runtime (libamdhip64.so under torch/lib).  Loaded before torch, this
+    # library binds the system copy instead, the process then holds TWO runtimes, and the one this library talks to does not
+    # see the device torch initialised (ieee_device_is_gfx950() = 0 -- met by `python __graft_entry__.py smoke`, whose build()
+    # loaded the library before smoke() imported torch).  Importing torch does not start the runtime.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)

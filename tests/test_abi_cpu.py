@@ -50,3 +50,16 @@ def test_product_fails_loudly_without_gpu():
     from ieee_amd.metrics import compute_distance_matrix
     with pytest.raises(_lib.IeeeAmdError):
         compute_distance_matrix(torch.zeros(2, 8), torch.zeros(3, 8))
+
+
+def test_loading_the_library_brings_torch_in_first():
+    """torch's wheel carries its own HIP runtime; loaded before torch, libieee_amd.so would bind the system copy and the process
+    would hold two runtimes (the one the library talks to then does not see torch's device: ieee_device_is_gfx950() = 0).
+    _lib.load() therefore imports torch before it opens the library -- checked in a fresh interpreter."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import ieee_amd; assert 'torch' not in sys.modules; "
+            "from ieee_amd import _lib; _lib.load(); assert 'torch' in sys.modules; print('ok')" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
