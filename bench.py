@@ -360,6 +360,70 @@ def bench_distmat(device):
     return out
 
 
+METRIC = "3-modal images/s (train fwd+bwd)"
+# BASELINE config 5's sweep (reference README.md:44-101): model flags of models/ieee3modalPart.py:312-314, and the CE-only
+# engine of engine/image/softmax.py:81-132 for "3M off"
+ABLATIONS = {"full": {}, "noatt": {"attention": False}, "nocim": {"interaction": False}, "norem": {"using_REM": False},
+             "3m_off": {}}
+
+
+def make_engine(C, ablation, cdt, device):
+    """(model, engine) of one leg: `ablation` picks the model flags and, for 3m_off, the CE-only engine"""
+    from ieee_amd.engine import Image3MEngine, MultiModalImageSoftmaxEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    softmax = ablation == "3m_off"
+    model = build_model("ieee3modalPart", num_classes=C, loss="softmax" if softmax else "margin", pretrained=False, use_gpu=True,
+                        compute_dtype=cdt, device=device, **ABLATIONS[ablation])
+    opt = build_optimizer(model, optim="sgd", lr=1e-3, weight_decay=5e-4, momentum=0.9)
+    if softmax:
+        engine = MultiModalImageSoftmaxEngine(_FakeDM(C), model, opt, use_gpu=True, label_smooth=True)
+    else:
+        engine = Image3MEngine(_FakeDM(C), model, opt, margin=1, weight_m=1, weight_x=1, use_gpu=True, label_smooth=True)
+    return model, engine
+
+
+def workload_text(B, C, ablation):
+    what = {"full": "full CIM+REM+3M", "noatt": "attention off (CIM without the channel attention), REM+3M",
+            "nocim": "CIM off (interaction=False), REM+3M", "norem": "REM off, CIM+3M",
+            "3m_off": "3M off (CE-only MultiModalImageSoftmaxEngine), CIM+REM"}[ablation]
+    data = "RGBNT201-shaped" if C == 171 else ("Market1501-multimodal-shaped" if C == 750 else "synthetic")
+    return "IEEE3modalPart train step, %s 256x128 triples, batch %d per GPU, %d classes, %s, SGD-nesterov" % (data, B, C, what)
+
+
+def config5_legs(device, peak_tflops, steps=10, warmup=3, B=32, C=750):
+    """BASELINE config 5 on ONE GPU: Market1501-multimodal's 750 identities, 32 triples per GPU, the reference's ablation sweep
+    {full, attention off, CIM off, REM off, 3M off}, bf16 -- five short legs (fresh model + engine each), images/s and
+    the whole step's fraction of the bf16 MFMA peak (the full model's 92.24 GFLOP per triple for every leg: the ablated
+    legs do a little less work, so their fraction is an upper bound)."""
+    out = {"workload": "IEEE3modalPart train step, 256x128 triples, batch %d per GPU, %d classes, bf16; one leg per ablation" % (B, C),
+           "steps": steps, "warmup": warmup, "legs": {}}
+    batch = make_batch(B, seed=5, device=device)
+    for name in ("full", "noatt", "nocim", "norem", "3m_off"):
+        try:
+            model, engine = make_engine(C, name, torch.bfloat16, device)
+            engine.resident_batch = True
+            engine.defer_summary = True
+            model.train()
+            for _ in range(warmup):
+                engine.forward_backward(batch)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(steps):
+                summary = engine.forward_backward(batch)
+            torch.cuda.synchronize()
+            dt = (time.time() - t0) / steps
+            loss = float(summary["loss_all" if name == "3m_off" else "loss"])
+            out["legs"][name] = {"value": B / dt, "unit": "3-modal images/s", "ms_per_step": dt * 1e3, "loss_last_step": loss,
+                                 "engine": type(engine).__name__,
+                                 "whole_step_frac_of_peak": B / dt * TRAIN_GFLOP_PER_TRIPLE * 1e9 / (peak_tflops * 1e12)}
+            del engine, model
+        except Exception as e:      # informative leg: never costs the headline line
+            out["legs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -375,18 +439,41 @@ def main():
     ap.add_argument("--no-dp-path", action="store_true", help="skip the staged data-parallel step over a 1-rank RCCL group (N = 1)")
     ap.add_argument("--no-loader", action="store_true", help="skip the input-pipeline leg (JPEG tree -> loader -> train step)")
     ap.add_argument("--loader-workers", default="8,16,32", help="worker counts of the input-pipeline leg")
+    ap.add_argument("--classes", type=int, default=171, help="identities = classifier width (RGBNT201: 171; Market1501-multimodal, "
+                    "BASELINE config 5: 750)")
+    ap.add_argument("--ablation", default="full", choices=sorted(ABLATIONS), help="BASELINE config 5's sweep: full, noatt "
+                    "(attention=False), nocim (interaction=False), norem (using_REM=False), 3m_off (the CE-only "
+                    "MultiModalImageSoftmaxEngine); reference models/ieee3modalPart.py:312-314, engine/image/softmax.py:81-132")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 object of the default N = 1 line (5 short legs "
+                    "at 750 classes, 32 triples)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 from a plain `python`: seconds the self-started "
+                    "ranks get before they are ended and an error line is printed (exit code 124)")
     args = ap.parse_args()
 
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1") or 1) == 1:
         # plain `python bench.py --gpus N`: this process becomes the launcher -- N child interpreters, one rank per GPU, with
         # the environment torchrun would give them (ieee_amd.dist.launch).  It never touches the GPU and nothing is exec'd;
         # rank 0 inherits stdout (the JSON line), the other ranks' stdout goes to stderr; exit code = the first failure.
+        # A rank that hangs (its first RCCL collective has never met real hardware) cannot hang the job silently: after
+        # --launch-timeout seconds, or when a rank fails, every rank is ended and ONE JSON error line goes to stdout.
         from ieee_amd import dist as ddp
-        sys.exit(ddp.launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, queues=_USER_QUEUES))
+        report = {}
+        rc = ddp.launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, queues=_USER_QUEUES,
+                        timeout=args.launch_timeout, report=report, capture_stderr=True)
+        if rc != 0:
+            what = ("timeout: the ranks were still running after %.0f s and were ended" % args.launch_timeout) if report.get("timed_out") \
+                else ("the launcher received signal %d" % (rc - 128) if report.get("rank") is None and rc > 128
+                      else "rank %s exited with code %d" % (report.get("rank"), rc))
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "3-modal images/s", "n_gpus": args.gpus,
+                              "error": what, "rank": report.get("rank"), "exit_code": rc,
+                              "elapsed_s": report.get("elapsed_s"), "stderr_tail": report.get("stderr_tail", "")}), flush=True)
+        sys.exit(rc)
 
     # Only the JSON line may reach the caller's stdout: RCCL prints a version banner (through C stdio, flushed at exit) when
     # a communicator is created, and other libraries chat too.  From here on file descriptor 1 IS stderr; the line is written
     # to the saved descriptor at the very end.
+    if os.environ.get("IEEE_BENCH_TEST_HANG_RANK") in (os.environ.get("RANK", "0"), "all"):
+        time.sleep(1e6)          # test hook (tests/test_dist_cpu.py): this rank never arrives -- the launcher's timeout must end the job
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
@@ -400,13 +487,11 @@ def main():
     from ieee_amd.engine import Image3MEngine
     from ieee_amd.models import build_model
     from ieee_amd.optim import build_optimizer
-    C = 171
+    C = args.classes
     torch.manual_seed(0)
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, use_gpu=True,
-                        compute_dtype=cdt, device=device)
-    opt = build_optimizer(model, optim="sgd", lr=1e-3, weight_decay=5e-4, momentum=0.9)
-    engine = Image3MEngine(_FakeDM(C), model, opt, margin=1, weight_m=1, weight_x=1, use_gpu=True, label_smooth=True)
+    model, engine = make_engine(C, args.ablation, cdt, device)
+    headline = C == 171 and args.ablation == "full"     # BASELINE config 2 / 3: what the committed profiles describe
     engine.dp_presharded = True          # weak scaling: every rank generates its own 64 triples (identity-aligned)
     engine.dp_total_rows = args.batch * world    # ... so the global batch is known without asking the other ranks
     engine.resident_batch = True         # the same batch object every step: its 3M chunk check runs once
@@ -445,16 +530,27 @@ def main():
                     engine.forward_backward(batch)
                 barrier()
                 return (time.time() - t0) / n * 1e3
-            cal = []
+            cal, cal_err = [], None
             for ov in (True, False):
                 engine.dp_overlap = ov
-                cal_steps(6)
-                cal.append(cal_steps(8))
+                try:
+                    cal_steps(6)
+                    cal.append(cal_steps(8))
+                except Exception as e:
+                    # the overlapped form (collectives from a communication stream beside the backward) threw: the plain
+                    # form is the fallback.  (A throw of the plain form has no fallback: it propagates.)
+                    if not ov:
+                        raise
+                    cal_err = "%s: %s" % (type(e).__name__, e)
+                    cal.append(float("inf"))
             t = torch.tensor(cal, dtype=torch.float64, device=device)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             engine.dp_overlap = bool(float(t[0]) <= 1.02 * float(t[1]))
-            dp_calibration = {"overlapped_ms_per_step": float(t[0]), "unoverlapped_ms_per_step": float(t[1]),
+            dp_calibration = {"overlapped_ms_per_step": float(t[0]) if float(t[0]) != float("inf") else None,
+                              "unoverlapped_ms_per_step": float(t[1]),
                               "used": "overlapped" if engine.dp_overlap else "unoverlapped", "steps_each": 8}
+            if cal_err is not None:
+                dp_calibration["overlapped_error"] = cal_err
     if os.environ.get("IEEE_BENCH_HIPRIO") == "1":       # experiment: the step's launch stream as a high-priority stream
         torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=-1))
     for _ in range(args.warmup):
@@ -496,11 +592,11 @@ def main():
     ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
     ser = sg_fl / (sg_ms * 1e-3) / 1e12 if sg_ms > 0 else 0.0
     traffic = traffic_src = None
-    if args.dtype == "bf16" and B == 64:
+    if args.dtype == "bf16" and B == 64 and headline:
         traffic, traffic_src = committed_traffic("conv_fwd_dgrad")          # gather + LDS-patch + direct-stem launches (round 3)
         if traffic is None:
             traffic, traffic_src = committed_traffic("conv_gather")
-    stats_line = committed_kernel_stats(TRAIN_GFLOP_PER_TRIPLE) if args.dtype == "bf16" and B == 64 else None
+    stats_line = committed_kernel_stats(TRAIN_GFLOP_PER_TRIPLE) if args.dtype == "bf16" and B == 64 and headline else None
     ceiling = committed_layer_ceiling(B) if args.dtype == "bf16" else None
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "measured": "in situ: every launch of the family carries a HIP event pair as its own start / stop signals "
@@ -534,7 +630,7 @@ def main():
     # whole-step HBM traffic: PMC bytes per step (committed summary of separate rocprofv3 --pmc passes) against the
     # algorithmic floor, and the rate / fraction of the 8 TB/s peak they mean at THIS run's step time
     step_hbm = None
-    if args.dtype == "bf16" and B == 64:
+    if args.dtype == "bf16" and B == 64 and headline:
         pmc_bytes, pmc_src = committed_traffic("_step", "hbm_bytes_per_step")
         floor = step_floor_bytes(B)
         step_s = dt / args.steps
@@ -550,7 +646,7 @@ def main():
     # parts, every part's gradient slices all-reduced over a 1-rank RCCL group from the communication stream, the
     # optimizer slices behind them (engine.py: _fused_step, `staged`) -- interleaved with the plain step.
     dp_path = None
-    if world == 1 and not args.no_dp_path and args.dtype == "bf16":
+    if world == 1 and not args.no_dp_path and args.dtype == "bf16" and headline:
         dp_path = dp_path_leg(engine, batch, model)
 
     # N > 1: what RCCL saw -- rank count and the time of each backward part's gradient all-reduce (a short extra leg
@@ -575,7 +671,7 @@ def main():
                         "communication stream; the slices overlap the next part's backward"}
 
     line = {
-        "metric": "3-modal images/s (train fwd+bwd)",
+        "metric": METRIC,
         "value": value,
         "unit": "3-modal images/s",
         "n_gpus": world,
@@ -587,10 +683,10 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": "IEEE3modalPart train step, RGBNT201-shaped 256x128 triples, batch %d per GPU, "
-                               "171 classes, full CIM+REM+3M, SGD-nesterov" % B,
-                   "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "loss_last_step": float(summary["loss"]),
+        "config": {"workload": workload_text(B, C, args.ablation),
+                   "global_batch": B * world, "parallelism": "dp%d" % world, "classes": C, "ablation": args.ablation,
+                   "engine": type(engine).__name__,
+                   "loss_last_step": float(summary["loss_all" if args.ablation == "3m_off" else "loss"]),
                    "summary_readback": "on first look (engine.defer_summary)" if engine.defer_summary else "inside every step"},
         "roofline": roofline,
     }
@@ -611,7 +707,7 @@ def main():
         if dp_calibration is not None:
             line["dp_calibration"] = dp_calibration
     if rank == 0:
-        if world == 1 and not args.no_loader and args.dtype == "bf16":
+        if world == 1 and not args.no_loader and args.dtype == "bf16" and headline:
             # input pipeline at step rate: JPEG tree -> worker decode -> device transform -> real steps,
             # with THIS engine (the timed one), before the CPU-baseline leg fills the process with OpenMP threads
             try:
@@ -629,13 +725,14 @@ def main():
             del engine, net
             model._nets.clear()
             torch.cuda.empty_cache()
+        if world == 1 and args.dtype == "bf16" and headline and not args.no_config5:
+            # BASELINE config 5 (Market1501-multimodal, 750 classes, 32 triples per GPU, the ablation sweep) on this GPU; the
+            # 4-GPU form is `python bench.py --gpus 4 --classes 750 --batch 32 --ablation <leg>`, one line per leg
+            line["config5"] = config5_legs(device, PEAK_BF16_TFLOPS)
         if world == 1 and args.dtype == "bf16" and not args.no_fp32:
             # the fp32 PARITY mode (exact fp32 MFMA end to end: the mode that meets north_star's 1e-3 contract), same
             # workload, a short run: the headline `value` above is the bf16 speed mode
-            m32 = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, use_gpu=True,
-                              compute_dtype=torch.float32, device=device)
-            e32 = Image3MEngine(_FakeDM(C), m32, build_optimizer(m32, optim="sgd", lr=1e-3, weight_decay=5e-4, momentum=0.9),
-                                margin=1, weight_m=1, weight_x=1, use_gpu=True, label_smooth=True)
+            m32, e32 = make_engine(C, args.ablation, torch.float32, device)
             m32.train()
             for _ in range(2):
                 e32.forward_backward(batch)

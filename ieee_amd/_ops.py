@@ -66,7 +66,19 @@ def conv2d_dgrad(dy, wpd, in_hw, Ci, R, S, stride, pad, addend=None):
     return dx
 
 
-def conv2d_wgrad(dy, x, R, S, stride, pad, out=None, accumulate=False):
+_FOLD_TICKETS = {}
+
+
+def _fold_tickets(device):
+    """int32 ticket words of ieee_conv2d_wgrad_fold: zero before the first call, left zero by every completed launch"""
+    key = (device.type, device.index)
+    if key not in _FOLD_TICKETS:
+        _FOLD_TICKETS[key] = torch.zeros(_lib.load().ieee_conv2d_wgrad_fold_ticket_words(), dtype=torch.int32, device=device)
+    return _FOLD_TICKETS[key]
+
+
+def conv2d_wgrad(dy, x, R, S, stride, pad, out=None, accumulate=False, fold=False):
+    """fold=True: ieee_conv2d_wgrad_fold (split-K slabs folded inside the GEMM launch) instead of GEMM + reduction launch"""
     lib = _lib.require_gpu()
     dy, x = dy.contiguous(), x.contiguous()
     G, dygs = _g(dy, 4)
@@ -77,6 +89,12 @@ def conv2d_wgrad(dy, x, R, S, stride, pad, out=None, accumulate=False):
         out = torch.zeros(shape, dtype=torch.float32, device=dy.device)
     nbytes = lib.ieee_conv2d_wgrad_workspace_bytes(_dt(dy), G, N, Ho, Wo, Ci, Co, R, S)
     work = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    if fold:
+        _lib.check(lib.ieee_conv2d_wgrad_fold(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(out), _lib.ptr(work),
+                                              _lib.ptr(_fold_tickets(dy.device)), _dt(dy), G, N, H, W, Ci, Co, R, S, stride,
+                                              pad, dygs, x.stride(0) if x.dim() == 5 else 0, Co * Ci * R * S,
+                                              1 if accumulate else 0, _lib.stream()))
+        return out
     _lib.check(lib.ieee_conv2d_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(out), _lib.ptr(work), _dt(dy), G, N, H, W,
                                      Ci, Co, R, S, stride, pad, dygs, x.stride(0) if x.dim() == 5 else 0,
                                      Co * Ci * R * S, 1 if accumulate else 0, _lib.stream()))

@@ -9,6 +9,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include <hip/hip_ext.h>
 
 #include "gemm_core.h"
@@ -504,6 +507,175 @@ struct SlabEpi {
           for (int e = 0; e < 4 && col + e < N; ++e) o[e] = f[e];
         }
       }
+    }
+  }
+};
+
+// ------------------------------------------------------------------ split-K fold INSIDE the weight-gradient launch (round 6)
+// The plain path writes nsplit fp32 slabs and a second launch (wgrad_reduce*) adds them up: 53 launches per step, every slab
+// written, read back, the OIHW gradient written.  Here the workgroups of one output tile fold their partials themselves
+// (cdna_hip_programming.md, "In-launch split-K reduction" / Guideline 16): every workgroup stores its tile WRITE-THROUGH
+// (sc1: no release fence, nothing stays dirty in its XCD's L2), drains, takes a ticket; the arriver that completes the
+// count acquires once and adds the slabs of its group IN SPLIT ORDER -- the same bits whoever arrives last, no float
+// atomics -- and either writes the OIHW gradient or, for the many-split small-weight layers (layer1 / layer2: 17-147
+// splits), a level-1 slab that the last of the n1 group reducers folds the same way (radix ~ sqrt(nsplit): the serial
+// tail of one reducer stays <= ~2 x 13 slab tiles instead of 147).  Tickets: int32 words the caller zeroes ONCE; every
+// launch that completes leaves them zero (the last arriver resets its word).
+struct FoldArgs {
+  int32_t* tickets;      // [groups][tiles][n1 + 1]: word g < n1 = level-0 group g, word n1 = the level-1 fold
+  float* lvl1;           // [groups][n1][Co][ncols] (unused when n1 == 1)
+  float* dw;             // OIHW gradient
+  int64_t dw_gs, lvl1_gs;
+  int nsplit, radix, n1; // level-0 group g = splits [g * radix, min(nsplit, (g + 1) * radix))
+  int accumulate, RS, Ci;
+  int tiles;
+};
+
+typedef float __attribute__((address_space(1))) * gfloat_p;
+
+__device__ __forceinline__ void store16_sc1(float* p, f32x4 v) {
+  // write-through: the line leaves this XCD's L2 at once and is visible to every other XCD after the wave's vmcnt(0)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// Every wave has drained its stores; ONE lane adds to the group's ticket.  Returns (workgroup-uniform) whether this
+// workgroup completed the count; it has then acquired (this CU's L1 dropped) and reset the word for the next launch.
+__device__ __forceinline__ bool fold_arrive(int32_t* word, int count, int* lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == count - 1;
+    if (last) {
+      __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *lds_flag = last;
+  }
+  __syncthreads();
+  const bool r = *lds_flag != 0;
+  return r;
+}
+
+// sum over `count` slabs (stride `ss` floats) of NV float4 per thread at p0 + offs[i], slab order, two slabs in flight.
+// Every load is unconditional (callers clamp the offsets of rows / columns outside the matrix): a per-element "load or
+// not" on a run-time condition makes hipcc branch around each load and wait for it alone (guide, GEMM trap (c)).
+template <int NV>
+__device__ __forceinline__ void fold_sum(const float* p0, const int (&offs)[NV], int64_t ss, int count, f32x4 (&sum)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) sum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+#pragma unroll 1
+  for (; k + 1 < count; k += 2) {
+    f32x4 a[NV], b[NV];
+    const float* pa = p0 + (int64_t)k * ss;
+    const float* pb = pa + ss;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] = *(const f32x4*)(pa + offs[i]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) b[i] = *(const f32x4*)(pb + offs[i]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { sum[i] += a[i]; sum[i] += b[i]; }
+  }
+  if (k < count) {
+    const float* pa = p0 + (int64_t)k * ss;
+    f32x4 a[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] = *(const f32x4*)(pa + offs[i]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sum[i] += a[i];
+  }
+}
+
+// the folded tile leaves: OIHW gradient.  (row, col) = (output channel, (rs, ci) column of the slab order)
+__device__ __forceinline__ void fold_write_dw(const FoldArgs& fa, float* dw, int row, int col, int ncols, f32x4 v) {
+  if (fa.RS == 1) {
+    f32x4* d = (f32x4*)(dw + (int64_t)row * ncols + col);
+    if (fa.accumulate) v += *d;
+    *d = v;
+  } else {
+    const int rs = col / fa.Ci, ci = col - rs * fa.Ci;
+    float* d = dw + ((int64_t)row * fa.Ci + ci) * fa.RS + rs;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e * fa.RS] = fa.accumulate ? d[e * fa.RS] + v[e] : v[e];
+  }
+}
+
+// The TN kernel's epilogue in fold form.  Tile = WROWS * 2 (or 1) x 128 of [Co][ncols]; a thread owns chunk ch = t & 31 of
+// rows r0 + 8 i of each 64-row half, exactly the row form SlabEpi::finish stores in.
+struct SlabFoldEpi {
+  static constexpr bool kStaged = true;
+  float* out;          // this split's level-0 slab [Co][ncols]
+  float* slab0;        // split 0's slab of this group (modality)
+  int64_t ld;
+  int M, N;
+  FoldArgs fa;
+  int ks, tile, z;
+  __device__ __forceinline__ void operator()(int, int, f32x4) const {}
+  template <int WROWS, int FM>
+  __device__ __forceinline__ void finish(f32x4 (&acc)[FM][4], char* smem, int m0, int n0) const {
+    constexpr int HALVES = WROWS == 64 ? 2 : 1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int ch = t & 31, r0 = t >> 5;
+    const int col = n0 + ch * 4;
+    const bool col_ok = col + 3 < N;
+    // 1. this split's tile -> its level-0 slab, write-through, as full 512-byte rows out of LDS
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+      __syncthreads();
+      if (HALVES == 1 || wm == h) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = (HALVES == 1 ? wm * WROWS : 0) + i * 16 + (lane & 15);
+            const int c = wn * 16 + j * 4 + (lane >> 4);
+            *(f32x4*)(smem + r * 512 + ((c ^ (r & 31)) << 4)) = acc[i][j];
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pss = 0; pss < 8; ++pss) {
+        const int r = r0 + 8 * pss;
+        const int row = m0 + h * 64 + r;
+        if (row >= M || !col_ok) continue;
+        store16_sc1(out + (int64_t)row * ld + col, *(const f32x4*)(smem + r * 512 + ((ch ^ (r & 31)) << 4)));
+      }
+    }
+    // 2. arrive at this split's level-0 group
+    int* flag = (int*)smem;
+    const int g = ks / fa.radix;
+    const int gfirst = g * fa.radix, gcount = min(fa.radix, fa.nsplit - gfirst);
+    int32_t* words = fa.tickets + ((int64_t)z * fa.tiles + tile) * (fa.n1 + 1);
+    if (!fold_arrive(words + g, gcount, flag)) return;
+    // 3. fold the group (and, as the last group reducer, the level-1 slabs); 4 rows x 16 bytes per thread and pass
+    const int64_t ss = (int64_t)M * ld;
+    float* dwz = fa.dw + (int64_t)z * fa.dw_gs;
+    float* l1 = fa.lvl1 + (int64_t)z * fa.lvl1_gs;
+    const int colc = col_ok ? col : 0;
+#pragma unroll 1
+    for (int level = 0; level < 2; ++level) {
+      const float* src = level == 0 ? slab0 + (int64_t)gfirst * ss : l1;
+      const int count = level == 0 ? gcount : fa.n1;
+      const bool final_level = level == 1 || fa.n1 == 1;
+#pragma unroll 1
+      for (int pass = 0; pass < HALVES * 2; ++pass) {
+        int offs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) offs[i] = min(m0 + pass * 32 + r0 + 8 * i, M - 1) * (int)ld + colc;
+        f32x4 sum[4];
+        fold_sum<4>(src, offs, ss, count, sum);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = m0 + pass * 32 + r0 + 8 * i;
+          if (row >= M || !col_ok) continue;
+          if (final_level) fold_write_dw(fa, dwz, row, col, N, sum[i]);
+          else store16_sc1(l1 + (int64_t)g * ss + offs[i], sum[i]);
+        }
+      }
+      if (final_level) return;
+      if (!fold_arrive(words + fa.n1, fa.n1, flag)) return;
     }
   }
 };
@@ -1115,9 +1287,9 @@ struct WgradPatchArgs {
   int64_t dy_gs, x_gs, slab_gs;
 };
 
-template <int WLOG, bool HALF_M>
+template <int WLOG, bool HALF_M, bool FOLD = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_patch_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
-                                                                     float* __restrict__ slab, WgradPatchArgs a) {
+                                                                     float* slab, WgradPatchArgs a, FoldArgs fa) {
   typedef WPatch<WLOG> WP;
   typedef ImgTN<bf16> Img;
   typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
@@ -1135,12 +1307,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_patch_kernel(const bf16*
   const int m0 = tm * 128;
   dy += z * a.dy_gs;
   x += z * a.x_gs;
-  slab += z * a.slab_gs + (int64_t)ks * a.Co * a.ncols;
+  float* slab0 = slab + z * a.slab_gs;
+  slab = slab0 + (int64_t)ks * a.Co * a.ncols;
   const int kbeg = ks * a.kchunk, kend = min(a.npix, kbeg + a.kchunk);
   const int ktiles = (kend - kbeg) >> 6;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   constexpr int FM = HALF_M ? 2 : 4, WROWS = FM * 16;
+  const int tile_id = (tm * a.nchunks + cq) * 3 + r;
   char* dtile = smem;                 // [64 k-rows][128 columns] bf16: the TN core's image (16 KB)
   char* patch = smem + 64 * 256;
   for (int i = t * 16; i < WP::BYTES; i += 256 * 16) *(uint4*)(patch + i) = make_uint4(0, 0, 0, 0);
@@ -1204,7 +1378,57 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_patch_kernel(const bf16*
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int col = (r * 3 + (j >> 1)) * Cs + cq * 64 + (wn * 2 + (j & 1)) * 16 + (lane >> 4) * 4;
-      *(float4*)(slab + (int64_t)co * a.ncols + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if constexpr (FOLD) store16_sc1(slab + (int64_t)co * a.ncols + col, acc[i][j]);
+      else *(float4*)(slab + (int64_t)co * a.ncols + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  }
+  if constexpr (FOLD) {
+    // split-K fold inside the launch (FoldArgs): a thread owns 4 input channels (chunk t & 15) of rows (t >> 4) + 16 i, and
+    // for them the three taps of filter row r -- which are 3 consecutive floats per (co, ci) of the OIHW gradient
+    int* flag = (int*)smem;
+    const int g = ks / fa.radix;
+    const int gfirst = g * fa.radix, gcount = min(fa.radix, fa.nsplit - gfirst);
+    int32_t* words = fa.tickets + ((int64_t)z * fa.tiles + tile_id) * (fa.n1 + 1);
+    if (!fold_arrive(words + g, gcount, flag)) return;
+    const int64_t ss = (int64_t)a.Co * a.ncols;
+    float* dwz = fa.dw + (int64_t)z * fa.dw_gs;
+    float* l1 = fa.lvl1 + (int64_t)z * fa.lvl1_gs;
+    const int ci4 = (t & 15) * 4, rr = t >> 4;
+    constexpr int ROWS = HALF_M ? 64 : 128;
+#pragma unroll 1
+    for (int level = 0; level < 2; ++level) {
+      const float* src = level == 0 ? slab0 + (int64_t)gfirst * ss : l1;
+      const int count = level == 0 ? gcount : fa.n1;
+      const bool final_level = level == 1 || fa.n1 == 1;
+#pragma unroll 1
+      for (int pass = 0; pass < ROWS / 32; ++pass) {
+        int offs[6];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int sx = 0; sx < 3; ++sx)
+            offs[i * 3 + sx] = (m0 + rr + 16 * (pass * 2 + i)) * a.ncols + (r * 3 + sx) * Cs + cq * 64 + ci4;
+        f32x4 sum[6];
+        fold_sum<6>(src, offs, ss, count, sum);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int co = m0 + rr + 16 * (pass * 2 + i);
+          if (final_level) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float* d = dwz + ((int64_t)co * Cs + cq * 64 + ci4 + e) * 9 + r * 3;
+              float v0 = sum[i * 3][e], v1 = sum[i * 3 + 1][e], v2 = sum[i * 3 + 2][e];
+              if (fa.accumulate) { v0 += d[0]; v1 += d[1]; v2 += d[2]; }
+              d[0] = v0; d[1] = v1; d[2] = v2;
+            }
+          } else {
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) store16_sc1(l1 + (int64_t)g * ss + offs[i * 3 + sx], sum[i * 3 + sx]);
+          }
+        }
+      }
+      if (final_level) return;
+      if (!fold_arrive(words + fa.n1, fa.n1, flag)) return;
     }
   }
 }
@@ -1222,9 +1446,9 @@ struct WgradArgs {
 #ifndef IEEE_WGRAD_OCC
 #define IEEE_WGRAD_OCC 4
 #endif
-template <typename T, bool SLOW, int PIPE = 0, bool HALF_M = false>
-__global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                         float* __restrict__ slab, WgradArgs a) {
+template <typename T, bool SLOW, int PIPE, bool HALF_M, class Epi>
+__device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const T* __restrict__ x, float* slab, const WgradArgs& a,
+                                                const FoldArgs* fa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware order: every tile of one (k-split, modality) reads the same pixel range of dY and X, so all of
   // them go to ONE XCD (blocks b, b+8, ... share an XCD/L2) and that range is fetched into one L2 only.
@@ -1255,10 +1479,13 @@ __global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wg
   const int m0 = tm * 128, n0 = tn * 128;
   dy += z * a.dy_gs;
   x += z * a.x_gs;
-  slab += z * a.slab_gs + (int64_t)ks * a.Co * a.ncols;
+  float* slab0 = slab + z * a.slab_gs;
+  slab = slab0 + (int64_t)ks * a.Co * a.ncols;
   const int kbeg = ks * a.kchunk, kend = min(a.npix, kbeg + a.kchunk);
   const int ktiles = (kend - kbeg + ImgTN<T>::BK - 1) / ImgTN<T>::BK;
-  SlabEpi epi{slab, a.ncols, a.Co, a.ncols};
+  Epi epi;
+  if constexpr (std::is_same<Epi, SlabFoldEpi>::value) epi = SlabFoldEpi{slab, slab0, a.ncols, a.Co, a.ncols, *fa, ks, tile, z};
+  else epi = SlabEpi{slab, a.ncols, a.Co, a.ncols};
   if constexpr (PIPE > 0) {   // LDS-DMA ring (see conv_gather_kernel)
     static_assert(!SLOW && sizeof(T) == 2, "the LDS-DMA ring is the bf16 vector path");
     const int ch = tn_dma_chunk(threadIdx.x);
@@ -1306,6 +1533,19 @@ __global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wg
     lb.init(x, a.g, n0, kbeg, kend);
     gemm_tn<T, (sizeof(T) == 2 ? 1 : 2)>(la, lb, epi, ktiles, m0, n0, smem);
   }
+}
+
+template <typename T, bool SLOW, int PIPE = 0, bool HALF_M = false>
+__global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         float* __restrict__ slab, WgradArgs a) {
+  conv_wgrad_body<T, SLOW, PIPE, HALF_M, SlabEpi>(dy, x, slab, a, nullptr);
+}
+// the same GEMM with the split-K fold inside the launch (FoldArgs, SlabFoldEpi); bf16 LDS-DMA path only.  `slab` is not
+// __restrict__ / const here: other workgroups' stores to it are read back behind the acquire.
+template <bool HALF_M>
+__global__ __launch_bounds__(256, IEEE_WGRAD_OCC) void conv_wgrad_fold_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                                              float* slab, WgradArgs a, FoldArgs fa) {
+  conv_wgrad_body<bf16, false, 1, HALF_M, SlabFoldEpi>(dy, x, slab, a, &fa);
 }
 
 // dW[z][co][ci][r][s] (OIHW fp32, the reference's parameter layout) = sum over splits of
@@ -2107,6 +2347,30 @@ static int wgrad_splitk(int64_t npix, int64_t Co, int64_t ncols, int64_t groups,
   return (int)want;
 }
 
+// In-launch fold of the split-K slabs (FoldArgs): level-0 groups of `radix` splits, n1 of them; one level (n1 = 1) up to
+// 16 splits, else radix ~ sqrt(nsplit) so that no reducer adds more than ~2 sqrt(nsplit) tiles in a row.
+constexpr int FOLD_MAX_SPLITS = 256;
+constexpr int64_t FOLD_TICKET_WORDS = 8192;
+static void fold_plan(int nsplit, int* radix, int* n1) {
+  static const int f_one = getenv("IEEE_WGRAD_FOLD_ONE") ? atoi(getenv("IEEE_WGRAD_FOLD_ONE")) : 16;
+  if (nsplit <= f_one) { *radix = nsplit; *n1 = 1; return; }
+  const int r = (int)ceil(sqrt((double)nsplit));
+  const int groups = cdiv(nsplit, r);
+  *radix = cdiv(nsplit, groups);
+  *n1 = cdiv(nsplit, *radix);
+}
+// floats behind the level-0 slabs of `nsplit_max` splits that cover the level-1 slabs of ANY actual split count up to it
+// (the launch may end up with fewer splits than the heuristic asked for)
+static int64_t fold_lvl1_floats(int64_t nsplit_max, int64_t groups, int64_t Co, int64_t ncols) {
+  int64_t extra = 0;
+  for (int s = 2; s <= nsplit_max && s <= FOLD_MAX_SPLITS; ++s) {
+    int radix, n1;
+    fold_plan(s, &radix, &n1);
+    if (n1 > 1) extra = std::max<int64_t>(extra, s + n1 - nsplit_max);
+  }
+  return extra > 0 ? extra * groups * Co * ncols : 0;
+}
+
 /* floats of BN partial sums per group that ieee_conv2d_fwd emits when bn_partial != NULL, and the row-block
  * count to hand to ieee_bn2d_fwd(stats_rblocks) */
 extern "C" int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t Wo) { return (N * Ho * Wo + 127) / 128; }
@@ -2114,11 +2378,13 @@ extern "C" int64_t ieee_conv2d_fwd_stats_rblocks(int64_t N, int64_t Ho, int64_t 
 extern "C" int64_t ieee_conv2d_wgrad_workspace_bytes(int dtype, int64_t groups, int64_t N, int64_t Ho, int64_t Wo,
                                                      int64_t Ci, int64_t Co, int64_t R, int64_t S) {
   const int64_t npix = N * Ho * Wo, ncols = R * S * Ci;
-  const int64_t generic = (int64_t)wgrad_splitk(npix, Co, ncols, groups, dtype, R * S) * groups * Co * ncols * 4;
+  const int64_t gsplit = wgrad_splitk(npix, Co, ncols, groups, dtype, R * S);
+  const int64_t generic = gsplit * groups * Co * ncols * 4 + fold_lvl1_floats(gsplit, groups, Co, ncols) * 4;
   // (the direct stem form: stride 2, no padding -> Hi = 2 Ho + 6; the query has no Hi / stride, so both sizes are covered)
   const int64_t stem = stem_wgrad_splits(dtype, N, 2 * Ho + 6, 2 * Wo + 6, Ho, Wo, Ci, Co, R, S, 2, 0) * groups * Co * ncols * 4;
   // (3x3 / stride 1 / pad 1: Hi = Ho, Wi = Wo)
-  const int64_t wp = wpatch_splits(dtype, N, Ho, Wo, Ci, Co, R, S, 1, 1, groups) * groups * Co * ncols * 4;
+  const int64_t psplit = wpatch_splits(dtype, N, Ho, Wo, Ci, Co, R, S, 1, 1, groups);
+  const int64_t wp = psplit * groups * Co * ncols * 4 + fold_lvl1_floats(psplit, groups, Co, ncols) * 4;
   return std::max(generic, std::max(stem, wp));
 }
 
@@ -2132,7 +2398,7 @@ static void fill_reduce_desc(ieee_wgrad_reduce_desc* o, const float* slab, float
 static int wgrad_impl(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
                       int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
                       int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs,
-                      int accumulate, void* stream, ieee_wgrad_reduce_desc* defer) {
+                      int accumulate, void* stream, ieee_wgrad_reduce_desc* defer, int32_t* tickets = nullptr) {
   IEEE_REQUIRE(dy && x && dw_oihw && work, "conv2d_wgrad: null pointer");
   Dims d;
   IEEE_TRY(check_dims("conv2d_wgrad", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
@@ -2214,6 +2480,29 @@ static int wgrad_impl(const void* dy, const void* x, float* dw_oihw, void* work,
   const int64_t wsplits = wpatch_splits(dtype, N, Hi, Wi, Ci, Co, R, S, stride, pad, groups);
   const bool wpatch = wsplits > 0;
   int nsplit_used = nsplit;
+  // the split-K fold inside the launch (FoldArgs): bf16 LDS-DMA forms with 16-byte aligned slabs / gradient
+  FoldArgs fa{};
+  bool fold = false;
+  {
+    const int ns = wpatch ? (int)wsplits : nsplit;
+    const int tiles = wpatch ? cdiv(d.Co, 128) * (d.Ci / 64) * 3 : a.tiles;
+    if (tickets != nullptr && defer == nullptr && dtype == IEEE_BF16 && !slow && (wpatch || pipe == 1) && !direct && ns >= 2 &&
+        ns <= FOLD_MAX_SPLITS && a.ncols % 4 == 0 && ((uintptr_t)slab & 15) == 0 && ((uintptr_t)dw_oihw & 15) == 0 &&
+        (dw_gs & 3) == 0 && (d.Co % 128 == 0 || d.Co == 64)) {
+      fold_plan(ns, &fa.radix, &fa.n1);
+      fa.nsplit = ns;
+      fa.tiles = tiles;
+      fold = (int64_t)groups * tiles * (fa.n1 + 1) <= FOLD_TICKET_WORDS;
+      fa.tickets = tickets;
+      fa.dw = dw_oihw;
+      fa.dw_gs = dw_gs;
+      fa.lvl1_gs = (int64_t)fa.n1 * d.Co * a.ncols;
+      fa.lvl1 = slab + (int64_t)groups * ns * d.Co * a.ncols;
+      fa.accumulate = accumulate;
+      fa.RS = d.R * d.S;
+      fa.Ci = d.Ci;
+    }
+  }
   if (wpatch) {
     WgradPatchArgs pa;
     const int64_t ktiles_all = a.npix / 64, per = (ktiles_all + wsplits - 1) / wsplits;
@@ -2230,8 +2519,10 @@ static int wgrad_impl(const void* dy, const void* x, float* dw_oihw, void* work,
     const int wlog = d.Wi == 8 ? 3 : (d.Wi == 16 ? 4 : 5);
     const bool half = d.Co == 64;
 #define IEEE_WP_CASE(W_) \
-    if (half) conv3x3_wgrad_patch_kernel<W_, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa); \
-    else conv3x3_wgrad_patch_kernel<W_, false><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa)
+    if (half && fold) conv3x3_wgrad_patch_kernel<W_, true, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa); \
+    else if (fold) conv3x3_wgrad_patch_kernel<W_, false, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa); \
+    else if (half) conv3x3_wgrad_patch_kernel<W_, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa); \
+    else conv3x3_wgrad_patch_kernel<W_, false><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa)
     if (wlog == 3) { IEEE_WP_CASE(3); } else if (wlog == 4) { IEEE_WP_CASE(4); } else { IEEE_WP_CASE(5); }
 #undef IEEE_WP_CASE
   } else if (dtype == IEEE_F32) {
@@ -2239,6 +2530,8 @@ static int wgrad_impl(const void* dy, const void* x, float* dw_oihw, void* work,
     else conv_wgrad_kernel<float, false><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
   } else if (dtype == IEEE_BF16) {
     if (slow) conv_wgrad_kernel<bf16, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
+    else if (fold && d.Co <= 64) conv_wgrad_fold_kernel<true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, fa);
+    else if (fold) conv_wgrad_fold_kernel<false><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, fa);
     else if (pipe == 1 && d.Co <= 64) conv_wgrad_kernel<bf16, false, 1, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
     else if (pipe == 1) conv_wgrad_kernel<bf16, false, 1><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
     else if (pipe == 2) conv_wgrad_kernel<bf16, false, 2><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
@@ -2250,7 +2543,7 @@ static int wgrad_impl(const void* dy, const void* x, float* dw_oihw, void* work,
   }
   IEEE_TRY(launch_status("conv_wgrad_kernel"));
   if (defer) fill_reduce_desc(defer, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
-  if (direct) return IEEE_OK;
+  if (direct || fold) return IEEE_OK;
   const int64_t total = (int64_t)d.Co * d.Ci * d.R * d.S;
   const bool vec4 = d.R * d.S == 1 && (total & 3) == 0 && (dw_gs & 3) == 0 && (a.slab_gs & 3) == 0 &&
                     ((uintptr_t)dw_oihw & 15) == 0 && ((uintptr_t)slab & 15) == 0;
@@ -2288,6 +2581,17 @@ extern "C" int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, 
                                  int accumulate, void* stream) {
   return wgrad_impl(dy, x, dw_oihw, work, dtype, groups, N, Hi, Wi, Ci, Co, R, S, stride, pad, dy_gs, x_gs, dw_gs, accumulate,
                     stream, nullptr);
+}
+
+extern "C" int64_t ieee_conv2d_wgrad_fold_ticket_words(void) { return FOLD_TICKET_WORDS; }
+
+extern "C" int ieee_conv2d_wgrad_fold(const void* dy, const void* x, float* dw_oihw, void* work, int32_t* tickets, int dtype,
+                                      int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
+                                      int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs,
+                                      int accumulate, void* stream) {
+  IEEE_REQUIRE(tickets, "conv2d_wgrad_fold: null ticket words");
+  return wgrad_impl(dy, x, dw_oihw, work, dtype, groups, N, Hi, Wi, Ci, Co, R, S, stride, pad, dy_gs, x_gs, dw_gs, accumulate,
+                    stream, nullptr, tickets);
 }
 
 extern "C" int ieee_conv2d_wgrad_deferred(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,

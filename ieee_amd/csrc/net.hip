@@ -79,6 +79,12 @@ static int gbuf_sets() {
   return n == 2 ? 2 : 3;
 }
 
+// IEEE_WGRAD_FOLD (default 1): the weight gradients fold their split-K slabs inside the GEMM launch (ieee_conv2d_wgrad_fold):
+// the ~50 wgrad_reduce launches of a step disappear.  0: GEMM + reduction launch (round 5).
+static bool wgrad_fold() {
+  static const bool on = !(getenv("IEEE_WGRAD_FOLD") && atoi(getenv("IEEE_WGRAD_FOLD")) == 0);
+  return on;
+}
 static int wgrad_batch_mode() {
   static const int m = getenv("IEEE_WGRAD_BATCH") ? atoi(getenv("IEEE_WGRAD_BATCH")) : 0;
   return m;
@@ -121,6 +127,7 @@ struct Net {
   const void* rtab_ws[RT_SLOTS] = {};
   ConvUnit reduce_unit;   // profiling label of the batched reductions
   size_t tot_begin = 0, tot_end = 0;   // the units' totals are one contiguous region: ONE memset per training forward
+  Tensor wtickets;  // arrival tickets of the weight gradients that fold their split-K slabs themselves (ieee_conv2d_wgrad_fold)
   Tensor tickets;   // 2 x 256 int32: arrival tickets of the convs that finalize their BatchNorm themselves (launch / branch stream)
   std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
   int pack_blocks_train = 0, pack_blocks_eval = 0;
@@ -354,6 +361,7 @@ void Net::plan() {
     u.tot_f = alloc("", (int64_t)rep * 3 * 2 * u.Co * 2, IEEE_F32);   // [replicas][3][2][Co] int64 = 2 floats' worth each
     u.tot_b = alloc("", (int64_t)rep * 3 * 2 * u.Co * 2, IEEE_F32);
   }
+  wtickets = alloc("", ieee_conv2d_wgrad_fold_ticket_words(), IEEE_F32);   // zeroed with the totals; every launch leaves them zero
   tot_end = ws_bytes;
   const ConvUnit& st = units[u_stem];
   const int ph = (st.Ho + 2 - 3) / 2 + 1, pw = (st.Wo + 2 - 3) / 2 + 1;
@@ -737,6 +745,9 @@ struct Run {
       return ieee_unpad_weight_grad(F(u.dwpad), grd(u.s_w), 3, u.Co, u.Ci, u.R, u.S, u.Ci_src, u.R_src, u.S_src, npad, gs(u.s_w), 0,
                                     st);
     }
+    if (wgrad_batch_mode() == 0 && wgrad_fold() && n.dtype == IEEE_BF16)
+      return ieee_conv2d_wgrad_fold(dy, x, grd(u.s_w), P(n.slab), (int32_t*)P(n.wtickets), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co,
+                                    u.R, u.S, u.stride, u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, gs(u.s_w), 0, st);
     if (wgrad_batch_mode() == 0)
       return ieee_conv2d_wgrad(dy, x, grd(u.s_w), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride,
                                u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, gs(u.s_w), 0, st);
@@ -893,7 +904,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
     static const bool f_fin = getenv("IEEE_BN_FIN_FUSE") && atoi(getenv("IEEE_BN_FIN_FUSE")) != 0;
     if (training && f_fin) IEEE_HIP(hipMemsetAsync(P(N.tickets), 0, 512 * 4, (hipStream_t)st));
   }
-  if (training && dt == IEEE_BF16 && totals_tiles() > 0) {   // the units' fixed-point BatchNorm totals (forward AND backward) start at zero
+  if (training && dt == IEEE_BF16 && (totals_tiles() > 0 || wgrad_fold())) {   // the units' fixed-point BatchNorm totals (forward AND backward) and the fold tickets start at zero
     if (N.bn_overflow == nullptr) {
       IEEE_HIP(hipHostMalloc((void**)&N.bn_overflow, 4 * sizeof(int), hipHostMallocMapped));
       for (int i = 0; i < 4; ++i) N.bn_overflow[i] = 0;
@@ -1093,7 +1104,7 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
   if (part <= 0) {
     // a SECOND backward over the same forward (e.g. two loss terms differentiated one after the other) must not add to
     // the first one's totals: zero them again (the forward's totals were consumed by its BatchNorm passes)
-    if (dt == IEEE_BF16 && totals_tiles() > 0) {
+    if (dt == IEEE_BF16 && (totals_tiles() > 0 || wgrad_fold())) {
       if (!N.bwd_totals_fresh) IEEE_HIP(hipMemsetAsync(ws + N.tot_begin, 0, N.tot_end - N.tot_begin, (hipStream_t)st));
       N.bwd_totals_fresh = false;
     }

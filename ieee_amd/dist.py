@@ -32,7 +32,12 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # a dead or stuck peer must surface as an exception in the survivors, not as a hang: collectives time out after
+        # IEEE_DIST_TIMEOUT_S seconds (default 300) and RCCL's watchdog tears the process down when one does
+        import datetime
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        timeout = datetime.timedelta(seconds=float(os.environ.get("IEEE_DIST_TIMEOUT_S", "300")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return world, rank, local
@@ -289,36 +294,103 @@ def rank_env(rank_, world, port, base=None, queues=None):
     return env
 
 
-def _reap(procs, alive, poll, grace, timeout, kill):
-    """wait for the children; when one fails the others (stuck in a collective with a dead peer) get `grace` seconds and are
-    then ended through their own handles.  Returns 0 when every rank succeeded, else the exit code of the rank that failed
-    FIRST (128 + signal number when a signal ended it), 124 when `timeout` seconds ran out."""
+class _Interrupted(Exception):
+    def __init__(self, signum):
+        self.signum = signum
+
+
+def _reap(procs, alive, poll, grace, timeout, kill, term=None):
+    """Wait for the children.  Returns (code, rank, timed_out):
+      code 0          every rank exited 0;
+      the exit code of the rank that was seen failed FIRST (the lowest-numbered one when several are found dead in one
+      50 ms poll; 128 + signal number when a signal ended it) -- the survivors, stuck in a collective with a dead peer, get
+      `grace` seconds and are then ended through their own handles;
+      124             `timeout` seconds ran out: every rank still running is ended at once.
+    `rank` is that first failing rank (None on success / timeout).  SIGTERM / SIGINT received by THIS process while it
+    waits end every rank (terminate, `grace` seconds, kill) and come back as 128 + signal number: no rank outlives its
+    launcher (torchrun, which this replaces, forwards signals too)."""
+    import signal
     import time
-    t0, first_bad, deadline, timed_out = time.time(), None, None, False
-    while True:
-        running = [p for p in procs if alive(p)]
-        if first_bad is None:
-            bad = [poll(p) for p in procs if not alive(p) and poll(p) not in (0, None)]
-            if bad:
-                first_bad, deadline = bad[0], time.time() + grace
-        if not running:
-            break
-        now = time.time()
-        if timeout and deadline is None and now - t0 > timeout:
-            timed_out, deadline = True, now
-        if deadline is not None and now >= deadline:
-            for p in running:
-                kill(p)
-            deadline = float("inf")                      # ended once: now only wait for them to go
-        time.sleep(0.05)
+
+    def on_signal(signum, frame):
+        raise _Interrupted(signum)
+
+    old = {}
+    try:
+        for sg in (signal.SIGTERM, signal.SIGINT):
+            old[sg] = signal.signal(sg, on_signal)
+    except ValueError:          # not the main thread: no handlers; the try / finally below still ends the ranks on an exception
+        old = {}
+    t0, first_bad, bad_rank, deadline, timed_out = time.time(), None, None, None, False
+    try:
+        while True:
+            running = [p for p in procs if alive(p)]
+            if first_bad is None:
+                bad = [(i, poll(p)) for i, p in enumerate(procs) if not alive(p) and poll(p) not in (0, None)]
+                if bad:
+                    (bad_rank, first_bad), deadline = bad[0], time.time() + grace
+            if not running:
+                break
+            now = time.time()
+            if timeout and deadline is None and now - t0 > timeout:
+                timed_out, deadline = True, now
+            if deadline is not None and now >= deadline:
+                for p in running:
+                    kill(p)
+                deadline = float("inf")                      # ended once: now only wait for them to go
+            time.sleep(0.05)
+    except (_Interrupted, KeyboardInterrupt) as e:
+        signum = getattr(e, "signum", signal.SIGINT)
+        _end_all(procs, alive, term or kill, kill, grace)
+        return 128 + int(signum), None, False
+    except BaseException:
+        _end_all(procs, alive, term or kill, kill, grace)
+        raise
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
     if timed_out:
-        return 124
+        return 124, None, True
     if first_bad is None:
-        return 0
-    return 128 - first_bad if first_bad < 0 else first_bad
+        return 0, None, False
+    return (128 - first_bad if first_bad < 0 else first_bad), bad_rank, False
 
 
-def launch(target, nprocs, args=(), port=None, queues=None, timeout=None, grace=15.0):
+def _end_all(procs, alive, term, kill, grace):
+    """terminate every live child, give it `grace` seconds, then kill it; returns when none is left"""
+    import time
+    for p in procs:
+        if alive(p):
+            try:
+                term(p)
+            except Exception:
+                pass
+    t_end = time.time() + grace
+    while any(alive(p) for p in procs) and time.time() < t_end:
+        time.sleep(0.05)
+    for p in procs:
+        if alive(p):
+            try:
+                kill(p)
+            except Exception:
+                pass
+    t_end = time.time() + 10.0
+    while any(alive(p) for p in procs) and time.time() < t_end:
+        time.sleep(0.05)
+
+
+def _tail(path, nbytes=2000):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            n = f.tell()
+            f.seek(max(0, n - nbytes))
+            return f.read().decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
+def launch(target, nprocs, args=(), port=None, queues=None, timeout=None, grace=15.0, report=None, capture_stderr=False):
     """Start `nprocs` ranks on this node, one process per GPU, and wait for them: the replacement for the reference's
     single-process `nn.DataParallel(model).cuda()` (scripts/mainMultiModal.py:219-220) that needs no launcher.
 
@@ -329,10 +401,19 @@ def launch(target, nprocs, args=(), port=None, queues=None, timeout=None, grace=
                                                        interpreters (never fork: a forked child of a process with a live HIP
                                                        context costs 364 ms per step while it lives, LABNOTES.md)
 
-    The calling process must not have touched the GPU and is not replaced (nothing is exec'd): it only waits, and returns
-    the worst exit code (0 = every rank succeeded).  When a rank dies the others are given `grace` seconds, then ended."""
+    The calling process must not have touched the GPU and is not replaced (nothing is exec'd): it only waits.
+    Return value, ONE contract (`_reap`): 0 when every rank exited 0; else the exit code of the rank that was seen failed
+    first (128 + signal number when a signal ended it; the other ranks get `grace` seconds, then are ended); 124 when
+    `timeout` seconds ran out (every rank is ended); 128 + signal number when THIS process received SIGTERM / SIGINT while
+    waiting -- the ranks are terminated (then killed after `grace` seconds) before it returns, so no rank outlives the
+    launcher.  `report` (a dict) receives {"code", "rank", "timed_out", "elapsed_s", "stderr_tail"}.
+    capture_stderr (argv form): every rank's stderr goes to a temporary file that is copied to this process's stderr when
+    the job ends (so the tail of the failing rank can be reported); default: the ranks write to this process's stderr
+    directly."""
     import subprocess
     import sys
+    import tempfile
+    import time
     nprocs = int(nprocs)
     if nprocs < 1:
         raise ValueError("launch: nprocs must be >= 1")
@@ -340,6 +421,28 @@ def launch(target, nprocs, args=(), port=None, queues=None, timeout=None, grace=
         raise RuntimeError("ieee_amd.dist.launch: this process already holds a HIP context; start the ranks before touching "
                            "the GPU (the parent only waits for them)")
     port = port or _free_port()
+    t0 = time.time()
+
+    def finish(result, err_files=None):
+        code, bad_rank, timed_out = result
+        tail = ""
+        if err_files:
+            for r, path in enumerate(err_files):
+                txt = _tail(path, 1 << 20)
+                if txt:
+                    sys.stderr.write(txt if nprocs == 1 else "".join("[rank %d] %s\n" % (r, ln) for ln in txt.splitlines()))
+            sys.stderr.flush()
+            pick = bad_rank if bad_rank is not None else 0
+            tail = _tail(err_files[pick])
+            for path in err_files:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+        if report is not None:
+            report.update(code=code, rank=bad_rank, timed_out=timed_out, elapsed_s=time.time() - t0, stderr_tail=tail)
+        return code
+
     if callable(target):
         import multiprocessing
         ctx = multiprocessing.get_context("spawn")
@@ -352,16 +455,38 @@ def launch(target, nprocs, args=(), port=None, queues=None, timeout=None, grace=
                 p = ctx.Process(target=_call_rank, args=(target, r, nprocs, tuple(args)), daemon=False)
                 p.start()
                 procs.append(p)
+        except BaseException:
+            _end_all(procs, lambda p: p.is_alive(), lambda p: p.terminate(), lambda p: p.kill(), grace)
+            raise
         finally:
             os.environ.clear()
             os.environ.update(saved)
-        return _reap(procs, lambda p: p.is_alive(), lambda p: p.exitcode, grace, timeout, lambda p: p.kill())
+        return finish(_reap(procs, lambda p: p.is_alive(), lambda p: p.exitcode, grace, timeout, lambda p: p.kill(),
+                            term=lambda p: p.terminate()))
     argv = list(target) + list(args)
-    procs = []
-    for r in range(nprocs):
-        out = None if r == 0 else sys.stderr         # one JSON line / one report on stdout, not one per rank
-        procs.append(subprocess.Popen(argv, env=rank_env(r, nprocs, port, queues=queues), stdout=out))
-    return _reap(procs, lambda p: p.poll() is None, lambda p: p.poll(), grace, timeout, lambda p: p.kill())
+    procs, err_files, handles = [], [], []
+    try:
+        others_out = sys.stderr.fileno()             # one JSON line / one report on stdout, not one per rank
+    except (AttributeError, OSError, ValueError):    # sys.stderr replaced by an object without a descriptor (a capture)
+        others_out = 2
+    try:
+        for r in range(nprocs):
+            err = None
+            if capture_stderr:
+                fd, path = tempfile.mkstemp(prefix="ieee_rank%d_" % r, suffix=".err")
+                err_files.append(path)
+                err = os.fdopen(fd, "wb")
+                handles.append(err)
+            procs.append(subprocess.Popen(argv, env=rank_env(r, nprocs, port, queues=queues),
+                                          stdout=None if r == 0 else others_out, stderr=err))
+    except BaseException:
+        _end_all(procs, lambda p: p.poll() is None, lambda p: p.terminate(), lambda p: p.kill(), grace)
+        raise
+    finally:
+        for h in handles:
+            h.close()
+    return finish(_reap(procs, lambda p: p.poll() is None, lambda p: p.poll(), grace, timeout, lambda p: p.kill(),
+                        term=lambda p: p.terminate()), err_files)
 
 
 def _call_rank(fn, rank_, world, args):

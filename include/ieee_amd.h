@@ -190,6 +190,21 @@ int ieee_conv2d_wgrad(const void* dy, const void* x, float* dw_oihw, void* work,
                       int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
                       int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs, int accumulate,
                       void* stream);
+/* The same weight gradient with the split-K fold INSIDE the launch (round 6; same semantics: autograd of
+ * torchreid/models/resnet.py:164-184's convs).  The workgroups of an output tile store their fp32 partial tiles write-through,
+ * take a ticket, and the one that completes the count adds the tiles up IN SPLIT ORDER (two levels for more than 16 splits) and
+ * writes the OIHW gradient: bit-reproducible from run to run (no float atomics), no reduction launch, no second pass over the
+ * slabs from a cold cache.  The association differs from ieee_conv2d_wgrad's (groups of ~sqrt(nsplit) splits instead of 16
+ * strided lanes), so the two agree to fp32 rounding, not bit for bit.
+ * tickets: ieee_conv2d_wgrad_fold_ticket_words() int32 words, ZERO before the first call; every completed launch leaves them
+ * zero, so consecutive calls on one stream may share them (calls on different streams may not).  `work` as for
+ * ieee_conv2d_wgrad (the query covers the level-1 slabs).  Shapes the fold does not cover (fp32, the stem, a single split,
+ * unaligned gradients) take ieee_conv2d_wgrad's path and leave the tickets untouched. */
+int64_t ieee_conv2d_wgrad_fold_ticket_words(void);
+int ieee_conv2d_wgrad_fold(const void* dy, const void* x, float* dw_oihw, void* work, int32_t* tickets, int dtype,
+                           int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+                           int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs, int accumulate,
+                           void* stream);
 /* The same weight gradient with its slab reduction DEFERRED: the launch leaves the split-K slabs in `work` (which must then
  * stay untouched until the reduction has run) and describes the reduction in *reduce; ieee_wgrad_reduce_batch runs the
  * reductions of many weight gradients in ONE launch.  Usage: collect the descriptors of a group of layers, drop those

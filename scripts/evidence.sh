@@ -8,7 +8,7 @@
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 TAG=${1:-r05}; PART=${2:-bench}
 O=gpurun_out/final_$TAG; mkdir -p $O
-LEAN="--no-cpu-baseline --no-distmat --no-fp32 --no-loader --no-dp-path"
+LEAN="--no-cpu-baseline --no-distmat --no-fp32 --no-loader --no-dp-path --no-config5"
 case $PART in
 tests)
   timeout 2400 python -m pytest tests -m gpu -q --durations=12 > $O/pytest_gpu.log 2>&1; tail -n 16 $O/pytest_gpu.log | cut -c1-200 ;;

@@ -6,7 +6,7 @@ i=0
 for e in "$@"; do
   i=$((i+1))
   for kv in $e; do export "$kv"; done
-  rocprofv3 --kernel-trace --output-format csv -d $O/t$i -- python3 bench.py --steps 12 --warmup 5 --no-roofline-pass --no-cpu-baseline --no-distmat --no-fp32 --no-dp-path --no-loader > $O/t$i.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d $O/t$i -- python3 bench.py --steps 12 --warmup 5 --no-roofline-pass --no-cpu-baseline --no-distmat --no-fp32 --no-dp-path --no-loader --no-config5 > $O/t$i.log 2>&1
   for kv in $e; do unset "${kv%%=*}"; done
   python scripts/phase_table.py $O/t$i > $O/phase$i.txt 2>&1
   find $O/t$i -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $O/trace$i.csv

@@ -52,6 +52,14 @@ def test_conv_kernels_at_config2_shapes(layer):
                                 x[0].numel(), wp.stride(0), y[0].numel(), L.ptr(part), L.stream()))
     dx = _ops.conv2d_dgrad(dy, wpd, (H, W), Ci, R, R, stride, pad)
     dw = _ops.conv2d_wgrad(dy, x, R, R, stride, pad)
+    # the same gradient with the split-K fold inside the launch (ieee_conv2d_wgrad_fold: what the executor runs): same
+    # tolerance against autograd below, bit-identical from run to run, `accumulate` adds to what is there
+    dwf = _ops.conv2d_wgrad(dy, x, R, R, stride, pad, fold=True)
+    for _ in range(3):
+        assert torch.equal(_ops.conv2d_wgrad(dy, x, R, R, stride, pad, fold=True), dwf), "fold: not reproducible"
+    dwf2 = _ops.conv2d_wgrad(dy, x, R, R, stride, pad, out=dwf.clone(), accumulate=True, fold=True)
+    assert torch.equal(dwf2, dwf + dwf), "fold: accumulate"
+    assert int(_ops._fold_tickets(dy.device).abs().sum()) == 0, "fold: a launch left its tickets behind"
     for i in range(G):
         xi = x[i].float().permute(0, 3, 1, 2).requires_grad_(True)
         wi = w[i].clone().requires_grad_(True)
@@ -62,6 +70,7 @@ def test_conv_kernels_at_config2_shapes(layer):
         assert float((y[i].float() - yr).abs().max()) <= 2 ** -7 * float(yr.abs().max()) + 1e-3
         assert _rel(dx[i].float(), xi.grad.permute(0, 2, 3, 1)) < 3e-3, "dgrad"
         assert _rel(dw[i], wi.grad) < 2e-4, "wgrad"                     # fp32 output: summation order only
+        assert _rel(dwf[i], wi.grad) < 2e-4, "wgrad (in-launch fold)"
         yf = y[i].float().view(-1, Co)
         torch.testing.assert_close(part[i, 0].sum(-1), yf.sum(0), rtol=2e-4, atol=0.5)
         torch.testing.assert_close(part[i, 1].sum(-1), (yf * yf).sum(0), rtol=2e-4, atol=0.5)
@@ -159,3 +168,34 @@ def test_b64_bf16_engine_step_is_the_bench_step():
         del eng, m
     assert losses["bf16_a"] == losses["bf16_b"]
     assert abs(losses["bf16_a"] - losses["fp32"]) / losses["fp32"] < 0.02, losses
+
+
+def test_wgrad_fold_hand_off_under_load_and_with_warm_caches():
+    """The in-launch split-K fold hands fp32 tiles from workgroup to workgroup (write-through stores, ticket, acquire): a stale
+    line read by a reducer would show as a wrong gradient only sometimes.  So: alternate two layer shapes that share ONE
+    workspace and ONE ticket block (what the executor does), keep a bandwidth-heavy kernel running on a second stream, and
+    require every repetition to return the bits of the first."""
+    from ieee_amd import _ops
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    shapes = [(256, 1024, 1, 16, 8), (64, 256, 1, 64, 32), (256, 256, 3, 16, 8), (128, 128, 3, 32, 16), (512, 2048, 1, 16, 8)]
+    ops = []
+    for Ci, Co, R, H, W in shapes:
+        x = torch.randn(3, B, H, W, Ci, generator=g, device="cuda").to(dt)
+        dy = torch.randn(3, B, H, W, Co, generator=g, device="cuda").to(dt)
+        ops.append((x, dy, R))
+    first = [_ops.conv2d_wgrad(dy, x, R, R, 1, R // 2, fold=True).clone() for x, dy, R in ops]
+    ref = [_ops.conv2d_wgrad(dy, x, R, R, 1, R // 2) for x, dy, R in ops]
+    for a, b in zip(first, ref):
+        assert _rel(a, b) < 1e-5        # same partial tiles, another association of the fp32 adds
+    big = torch.empty(256 << 20, device="cuda")
+    side = torch.cuda.Stream()
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(8):
+                big.add_(1.0)          # 2 GB of traffic per pass beside the folds
+        for (x, dy, R), want in zip(ops, first):
+            got = _ops.conv2d_wgrad(dy, x, R, R, 1, R // 2, fold=True)
+            assert torch.equal(got, want), "fold: hand-off returned different bits (rep %d)" % rep
+    torch.cuda.synchronize()
+    assert int(_ops._fold_tickets(big.device).abs().sum()) == 0

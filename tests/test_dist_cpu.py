@@ -326,8 +326,103 @@ def test_bench_self_launch_fails_loudly_without_a_gpu():
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert r.returncode != 0 and r.stdout.decode().strip() == ""
-    assert "no CPU fallback" in r.stderr.decode()
+    assert r.returncode != 0
+    lines = r.stdout.decode().strip().splitlines()
+    assert len(lines) == 1                         # ONE JSON line: the launcher's error report
+    import json
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and d["rank"] in (0, 1) and d["exit_code"] == r.returncode
+    assert "exited with code" in d["error"] and "no CPU fallback" in d["stderr_tail"]
+    assert "no CPU fallback" in r.stderr.decode()  # ... and the ranks' stderr still reaches the caller's
+
+
+def test_bench_self_launch_cannot_hang_silently():
+    """ranks that never arrive (the first multi-GPU collective has never met real hardware): after --launch-timeout the
+    launcher ends them, prints ONE JSON error line and exits 124"""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IEEE_DIST_BACKEND="gloo", IEEE_BENCH_TEST_HANG_RANK="all")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--launch-timeout", "25"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 124, (r.returncode, r.stderr.decode()[-2000:])
+    assert 25 <= time.time() - t0 < 120
+    lines = r.stdout.decode().strip().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["exit_code"] == 124 and d["error"].startswith("timeout") and d["n_gpus"] == 2
+
+
+_SLEEPER = """
+import os, sys, time
+open(os.path.join(%r, "pid%%s" %% os.environ["RANK"]), "w").write(str(os.getpid()))
+time.sleep(1e6)
+"""
+
+
+def _pid_alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    try:                                   # a zombie still answers kill(0)
+        return open("/proc/%d/stat" % pid).read().split(")")[-1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_launch_timeout_ends_the_ranks_and_returns_124(tmp_path):
+    import time
+    script = tmp_path / "sleeper.py"
+    script.write_text(_SLEEPER % str(tmp_path))
+    import sys
+    report = {}
+    t0 = time.time()
+    assert ddp.launch([sys.executable, str(script)], 3, timeout=4.0, grace=2.0, report=report) == 124
+    assert time.time() - t0 < 60 and report["timed_out"] and report["rank"] is None and report["code"] == 124
+    pids = [int(open(str(tmp_path / ("pid%d" % r))).read()) for r in range(3)]
+    assert not any(_pid_alive(p) for p in pids)
+
+
+def test_a_signal_to_the_launcher_ends_every_rank(tmp_path):
+    """SIGTERM to the launching process (a scheduler's kill, `timeout ... python bench.py --gpus 8`): the ranks are terminated
+    before the launcher exits with 128 + 15 -- none keeps training or holding a GPU"""
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sleeper.py"
+    script.write_text(_SLEEPER % str(tmp_path))
+    parent = ("import sys; sys.path.insert(0, %r); from ieee_amd import dist as ddp; "
+              "sys.exit(ddp.launch([sys.executable, %r], 3, grace=3.0))" % (root, str(script)))
+    p = subprocess.Popen([sys.executable, "-c", parent], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t_end = time.time() + 120
+    while time.time() < t_end and not all((tmp_path / ("pid%d" % r)).exists() and (tmp_path / ("pid%d" % r)).read_text() for r in range(3)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / ("pid%d" % r)).read_text()) for r in range(3)]
+    assert all(_pid_alive(q) for q in pids)
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    time.sleep(0.2)
+    assert not any(_pid_alive(q) for q in pids)
+
+
+def test_launch_survives_a_stderr_without_a_descriptor(tmp_path, monkeypatch):
+    """argv form with sys.stderr replaced by a capture object (no fileno()): the other ranks' stdout falls back to fd 2"""
+    import io
+    import sys
+    script = tmp_path / "ok.py"
+    script.write_text("print('hello')\n")
+    monkeypatch.setattr(sys, "stderr", io.StringIO())
+    assert ddp.launch([sys.executable, str(script)], 2) == 0
 
 
 # ---- opt-in bf16 gradient exchange (IEEE_DP_GRAD_DTYPE=bf16): what the halved wire format costs in accuracy ---------------
