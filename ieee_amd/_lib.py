@@ -61,6 +61,12 @@ class WgradReduceDesc(ctypes.Structure):
                 ("accumulate", ctypes.c_int32), ("block_begin", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
 
 
+class ConvExtras(ctypes.Structure):
+    """struct ieee_conv_extras of include/ieee_amd.h (ieee_conv2d_fwd_ex / ieee_conv2d_dgrad_ex): the options of ONE conv call"""
+    _fields_ = [("totals", c_void_p), ("group_stride", c_int64), ("replicas", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+                ("overflow", c_void_p), ("start", c_void_p), ("stop", c_void_p)]
+
+
 class IeeeAmdError(RuntimeError):
     pass
 

@@ -104,6 +104,10 @@ class NativeNet:
         _lib.check(self.lib.ieee_net_bn_overflow(self.handle, out))
         return tuple(out)
 
+    def set_bn_totals(self, on):
+        """on=False: every BatchNorm on the per-tile partial-sum path from the next forward on (ieee_net_set_bn_totals)"""
+        _lib.check(self.lib.ieee_net_set_bn_totals(self.handle, 1 if on else 0))
+
     def debug_taps(self, nbytes):
         """parity tests: allocate a tap buffer of nbytes and make the backward copy its gradient tensors into it
         (include/ieee_amd.h: ieee_net_debug_taps); nbytes = 0 switches the taps off"""

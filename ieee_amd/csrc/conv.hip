@@ -1257,6 +1257,35 @@ static int64_t stem_wgrad_splits(int dtype, int64_t N, int64_t Hi, int64_t Wi, i
 }
 
 
+// ------------------------------------------------------------------ the PREVIOUS weight gradient's slab reduction as this launch's prologue
+// (round 6) 53 wgrad_reduce launches of 10-30 us sat between the weight-gradient GEMMs of the side stream.  A reduction
+// folded into the tail of its own GEMM launch (SlabFoldEpi above) needs one reducer per output tile -- measured +0.68 ms per
+// step: a single workgroup has ~32 KB of loads in flight and reads its 0.5 MB of slabs at ~20 GB/s while the chip idles.
+// Folded into the HEAD of the NEXT weight-gradient launch instead, every workgroup of that launch takes a share
+// (blocks bx, bx + grid, ... of the reduction's own grid), the kernel boundary in between is the only synchronisation
+// (no tickets, no fences, plain stores), the arithmetic is wgrad_reduce_body / wgrad_reduce_taps_body unchanged -- the
+// same bits as the reduction launch -- and the slabs are read while they are still cache-resident.  The caller alternates
+// between two slab regions and flushes the last pending reduction of a group of layers with ieee_wgrad_reduce_pending.
+template <int VEC>
+__device__ __forceinline__ void wgrad_reduce_body(float* part, int bx, int z, const float* __restrict__ slab, float* __restrict__ dw,
+                                                  int splitk, int Co, int Ci, int RS, int64_t slab_gs, int64_t dw_gs,
+                                                  int accumulate, int sl_log2);
+__device__ __forceinline__ void wgrad_reduce_taps_body(float* tile, int bx, int z, const float* __restrict__ slab,
+                                                       float* __restrict__ dw, int splitk, int Co, int Ci, int RS, int64_t slab_gs,
+                                                       int64_t dw_gs, int accumulate);
+__device__ __forceinline__ void wgrad_prologue(const ieee_wgrad_reduce_desc& d, int groups, char* smem) {
+  if (d.kind == 0) return;
+  float* lds = (float*)smem;                 // >= 256 * 4 floats (split-lane forms) / [128][9] floats (taps form): < 5 KB
+  const int total = d.blocks * groups;
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const int z = w / d.blocks, bx = w - z * d.blocks;
+    if (d.kind == 1) wgrad_reduce_body<4>(lds, bx, z, d.slab, d.dw, d.nsplit, d.Co, d.Ci, d.RS, d.slab_gs, d.dw_gs, d.accumulate, d.sl_log2);
+    else if (d.kind == 2) wgrad_reduce_body<1>(lds, bx, z, d.slab, d.dw, d.nsplit, d.Co, d.Ci, d.RS, d.slab_gs, d.dw_gs, d.accumulate, d.sl_log2);
+    else wgrad_reduce_taps_body(lds, bx, z, d.slab, d.dw, d.nsplit, d.Co, d.Ci, d.RS, d.slab_gs, d.dw_gs, d.accumulate);
+    __syncthreads();                         // the staging floats are reused by the next share / the GEMM's operand stage
+  }
+}
+
 // ------------------------------------------------------------------ 3x3 / stride 1 weight gradient over LDS patches
 // dW[co][(r, s, ci)] = sum over pixels of dY[pix][co] * X[pix + (r - 1, s - 1)][ci].  The TN kernel above treats the 9 taps as 9
 // independent column blocks: X is fetched from L2 once per tap and dY once per 128 columns.  Here a workgroup owns
@@ -1289,12 +1318,14 @@ struct WgradPatchArgs {
 
 template <int WLOG, bool HALF_M, bool FOLD = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_patch_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
-                                                                     float* slab, WgradPatchArgs a, FoldArgs fa) {
+                                                                     float* slab, WgradPatchArgs a, FoldArgs fa,
+                                                                     ieee_wgrad_reduce_desc prev) {
   typedef WPatch<WLOG> WP;
   typedef ImgTN<bf16> Img;
   typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  wgrad_prologue(prev, a.groups, smem);
   // every tile of one (k-split, modality) goes to ONE XCD (blocks b, b + 8, ... share an L2): they read the same pixels
   const int bid = blockIdx.x, xcd = bid & 7, jb = bid >> 3;
   const int kzi = (jb / a.tiles) * 8 + xcd;
@@ -1448,8 +1479,9 @@ struct WgradArgs {
 #endif
 template <typename T, bool SLOW, int PIPE, bool HALF_M, class Epi>
 __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const T* __restrict__ x, float* slab, const WgradArgs& a,
-                                                const FoldArgs* fa) {
+                                                const FoldArgs* fa, const ieee_wgrad_reduce_desc& prev) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  wgrad_prologue(prev, a.groups, smem);
   // XCD-aware order: every tile of one (k-split, modality) reads the same pixel range of dY and X, so all of
   // them go to ONE XCD (blocks b, b+8, ... share an XCD/L2) and that range is fetched into one L2 only.
   int kzi, tile;
@@ -1537,15 +1569,16 @@ __device__ __forceinline__ void conv_wgrad_body(const T* __restrict__ dy, const 
 
 template <typename T, bool SLOW, int PIPE = 0, bool HALF_M = false>
 __global__ __launch_bounds__(256, (PIPE == 1 ? IEEE_WGRAD_OCC : 3)) void conv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                         float* __restrict__ slab, WgradArgs a) {
-  conv_wgrad_body<T, SLOW, PIPE, HALF_M, SlabEpi>(dy, x, slab, a, nullptr);
+                                                         float* __restrict__ slab, WgradArgs a, ieee_wgrad_reduce_desc prev) {
+  conv_wgrad_body<T, SLOW, PIPE, HALF_M, SlabEpi>(dy, x, slab, a, nullptr, prev);
 }
 // the same GEMM with the split-K fold inside the launch (FoldArgs, SlabFoldEpi); bf16 LDS-DMA path only.  `slab` is not
 // __restrict__ / const here: other workgroups' stores to it are read back behind the acquire.
 template <bool HALF_M>
 __global__ __launch_bounds__(256, IEEE_WGRAD_OCC) void conv_wgrad_fold_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
-                                                                              float* slab, WgradArgs a, FoldArgs fa) {
-  conv_wgrad_body<bf16, false, 1, HALF_M, SlabFoldEpi>(dy, x, slab, a, &fa);
+                                                                              float* slab, WgradArgs a, FoldArgs fa,
+                                                                              ieee_wgrad_reduce_desc prev) {
+  conv_wgrad_body<bf16, false, 1, HALF_M, SlabFoldEpi>(dy, x, slab, a, &fa, prev);
 }
 
 // dW[z][co][ci][r][s] (OIHW fp32, the reference's parameter layout) = sum over splits of
@@ -1578,17 +1611,19 @@ __device__ __forceinline__ void wgrad_reduce_body(float* part, int bx, int z, co
       }
     }
   }
+  // (no early return: the body also runs as the prologue of the NEXT weight-gradient launch, wgrad_prologue)
   if (SL > 1) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) part[(lane * per + x) * VEC + e] = acc[e];
     __syncthreads();
-    if (lane != 0) return;
-    for (int y = 1; y < SL; ++y) {
+    if (lane == 0) {
+      for (int y = 1; y < SL; ++y) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) acc[e] += part[(y * per + x) * VEC + e];
+        for (int e = 0; e < VEC; ++e) acc[e] += part[(y * per + x) * VEC + e];
+      }
     }
   }
-  if (i >= total) return;
+  if (lane != 0 || i >= total) return;
   if constexpr (VEC == 4) {   // 1x1 with 16-byte aligned operands: slab order == OIHW order
     float4* d = (float4*)(dw + z * dw_gs + i);
     float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -2394,18 +2429,40 @@ static void fill_reduce_desc(ieee_wgrad_reduce_desc* o, const float* slab, float
   o->kind = kind; o->sl_log2 = sl_log2; o->blocks = blocks; o->accumulate = accumulate; o->block_begin = 0; o->reserved_ = 0;
 }
 
+// one described reduction as a launch of its own (the immediate path's kernels and grids)
+static int reduce_launch(const ieee_wgrad_reduce_desc& d, int64_t groups, hipStream_t st) {
+  if (d.kind == 0) return IEEE_OK;
+  dim3 grid((unsigned)d.blocks, (unsigned)groups);
+  if (d.kind == 3) {
+    wgrad_reduce_taps_kernel<<<grid, 256, (size_t)RT_CIB * d.RS * sizeof(float), st>>>(d.slab, d.dw, d.nsplit, d.Co, d.Ci, d.RS, d.slab_gs,
+                                                                                      d.dw_gs, d.accumulate);
+    return launch_status("wgrad_reduce_taps_kernel");
+  }
+  if (d.kind == 1)
+    wgrad_reduce_kernel<4><<<grid, 256, 0, st>>>(d.slab, d.dw, d.nsplit, d.Co, d.Ci, d.RS, d.slab_gs, d.dw_gs, d.accumulate, d.sl_log2);
+  else
+    wgrad_reduce_kernel<1><<<grid, 256, 0, st>>>(d.slab, d.dw, d.nsplit, d.Co, d.Ci, d.RS, d.slab_gs, d.dw_gs, d.accumulate, d.sl_log2);
+  return launch_status("wgrad_reduce_kernel");
+}
+
 // defer != NULL: run the GEMM only and describe the slab reduction in *defer (kind 0: nothing left to do)
 static int wgrad_impl(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
                       int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
                       int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs,
-                      int accumulate, void* stream, ieee_wgrad_reduce_desc* defer, int32_t* tickets = nullptr) {
+                      int accumulate, void* stream, ieee_wgrad_reduce_desc* defer, int32_t* tickets = nullptr,
+                      const ieee_wgrad_reduce_desc* prev = nullptr) {
   IEEE_REQUIRE(dy && x && dw_oihw && work, "conv2d_wgrad: null pointer");
   Dims d;
   IEEE_TRY(check_dims("conv2d_wgrad", N, Hi, Wi, Ci, Co, R, S, stride, pad, &d));
   IEEE_REQUIRE(Co % elem_vec(dtype) == 0, "conv2d_wgrad: Cout must be a multiple of %d", elem_vec(dtype));
+  // the reduction this launch carries as its prologue (wgrad_prologue); kind 0 = none
+  ieee_wgrad_reduce_desc pv;
+  fill_reduce_desc(&pv, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+  if (prev != nullptr && prev->kind != 0) pv = *prev;
   if (const int64_t ssplits = stem_wgrad_splits(dtype, N, Hi, Wi, d.Ho, d.Wo, Ci, Co, R, S, stride, pad)) {
     // the stem: direct form over LDS patches (stem_wgrad_kernel), one slab per STEM_WG_ROWS output rows of an image
     hipStream_t st = (hipStream_t)stream;
+    if (pv.kind != 0) IEEE_TRY(reduce_launch(pv, groups, st));   // (this kernel has no prologue: the pending reduction runs first)
     float* slab = (float*)work;
     const int64_t slab_gs = ssplits * 64 * 256;
     stem_wgrad_kernel<<<dim3((unsigned)ssplits, (unsigned)groups), 256, 12 * 1024 + 16 * 1024, st>>>(
@@ -2519,25 +2576,25 @@ static int wgrad_impl(const void* dy, const void* x, float* dw_oihw, void* work,
     const int wlog = d.Wi == 8 ? 3 : (d.Wi == 16 ? 4 : 5);
     const bool half = d.Co == 64;
 #define IEEE_WP_CASE(W_) \
-    if (half && fold) conv3x3_wgrad_patch_kernel<W_, true, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa); \
-    else if (fold) conv3x3_wgrad_patch_kernel<W_, false, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa); \
-    else if (half) conv3x3_wgrad_patch_kernel<W_, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa); \
-    else conv3x3_wgrad_patch_kernel<W_, false><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa)
+    if (half && fold) conv3x3_wgrad_patch_kernel<W_, true, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa, pv); \
+    else if (fold) conv3x3_wgrad_patch_kernel<W_, false, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa, pv); \
+    else if (half) conv3x3_wgrad_patch_kernel<W_, true><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa, pv); \
+    else conv3x3_wgrad_patch_kernel<W_, false><<<pgrid, 256, std::max((size_t)(64 * 256 + WPatch<W_>::BYTES), f_lds), st>>>((const bf16*)dy, (const bf16*)x, slab, pa, fa, pv)
     if (wlog == 3) { IEEE_WP_CASE(3); } else if (wlog == 4) { IEEE_WP_CASE(4); } else { IEEE_WP_CASE(5); }
 #undef IEEE_WP_CASE
   } else if (dtype == IEEE_F32) {
-    if (slow) conv_wgrad_kernel<float, true><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
-    else conv_wgrad_kernel<float, false><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a);
+    if (slow) conv_wgrad_kernel<float, true><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a, pv);
+    else conv_wgrad_kernel<float, false><<<grid, 256, smem, st>>>((const float*)dy, (const float*)x, slab, a, pv);
   } else if (dtype == IEEE_BF16) {
-    if (slow) conv_wgrad_kernel<bf16, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
-    else if (fold && d.Co <= 64) conv_wgrad_fold_kernel<true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, fa);
-    else if (fold) conv_wgrad_fold_kernel<false><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, fa);
-    else if (pipe == 1 && d.Co <= 64) conv_wgrad_kernel<bf16, false, 1, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
-    else if (pipe == 1) conv_wgrad_kernel<bf16, false, 1><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
-    else if (pipe == 2) conv_wgrad_kernel<bf16, false, 2><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
-    else if (pipe == 3) conv_wgrad_kernel<bf16, false, 3><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
-    else if (pipe == 4) conv_wgrad_kernel<bf16, false, 4><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
-    else conv_wgrad_kernel<bf16, false><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a);
+    if (slow) conv_wgrad_kernel<bf16, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
+    else if (fold && d.Co <= 64) conv_wgrad_fold_kernel<true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, fa, pv);
+    else if (fold) conv_wgrad_fold_kernel<false><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, fa, pv);
+    else if (pipe == 1 && d.Co <= 64) conv_wgrad_kernel<bf16, false, 1, true><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
+    else if (pipe == 1) conv_wgrad_kernel<bf16, false, 1><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
+    else if (pipe == 2) conv_wgrad_kernel<bf16, false, 2><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
+    else if (pipe == 3) conv_wgrad_kernel<bf16, false, 3><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
+    else if (pipe == 4) conv_wgrad_kernel<bf16, false, 4><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
+    else conv_wgrad_kernel<bf16, false><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
   } else {
     IEEE_REQUIRE(false, "conv2d_wgrad: bad dtype %d", dtype);
   }
@@ -2603,11 +2660,68 @@ extern "C" int ieee_conv2d_wgrad_deferred(const void* dy, const void* x, float* 
                     stream, reduce);
 }
 
+extern "C" int ieee_conv2d_wgrad_chained(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
+                                         int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+                                         int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs,
+                                         int accumulate, const ieee_wgrad_reduce_desc* prev, ieee_wgrad_reduce_desc* reduce,
+                                         void* stream) {
+  IEEE_REQUIRE(reduce, "conv2d_wgrad_chained: null descriptor");
+  IEEE_REQUIRE(prev == nullptr || prev->kind == 0 || (const void*)prev->slab != (const void*)work,
+               "conv2d_wgrad_chained: the pending reduction still reads `work` -- alternate between two slab regions");
+  return wgrad_impl(dy, x, dw_oihw, work, dtype, groups, N, Hi, Wi, Ci, Co, R, S, stride, pad, dy_gs, x_gs, dw_gs, accumulate,
+                    stream, reduce, nullptr, prev);
+}
+
+extern "C" int ieee_wgrad_reduce_pending(const ieee_wgrad_reduce_desc* pending, int64_t groups, void* stream) {
+  IEEE_REQUIRE(pending && groups > 0, "wgrad_reduce_pending: bad arguments");
+  return reduce_launch(*pending, groups, (hipStream_t)stream);
+}
+
 extern "C" int ieee_wgrad_reduce_batch(const ieee_wgrad_reduce_desc* device_descs, int64_t n, int64_t total_blocks, int64_t groups,
                                        void* stream) {
   IEEE_REQUIRE(device_descs && n > 0 && total_blocks > 0 && groups > 0, "wgrad_reduce_batch: bad arguments");
   wgrad_reduce_batch_kernel<<<dim3((unsigned)total_blocks, (unsigned)groups), 256, 0, (hipStream_t)stream>>>(device_descs, (int)n);
   return launch_status("wgrad_reduce_batch_kernel");
+}
+
+// explicit-argument forms: the options of ONE call as a struct; nothing stays armed (OneShotArms in the base entry points
+// clears the thread's slots on every return path, and they are set here inside the same call)
+static int arm_extras(const char* who, const ieee_conv_extras* ex) {
+  if (ex == nullptr) return IEEE_OK;
+  IEEE_REQUIRE(ex->reserved_ == 0, "%s: ieee_conv_extras.reserved_ must be 0", who);
+  IEEE_REQUIRE((ex->start == nullptr) == (ex->stop == nullptr), "%s: pass both timing events or none", who);
+  if (ex->totals != nullptr) {
+    IEEE_REQUIRE(ex->replicas >= 1 && ex->replicas <= 64 && (ex->replicas & (ex->replicas - 1)) == 0,
+                 "%s: ieee_conv_extras.replicas must be a power of two <= 64", who);
+    ieee::tl_totals = (long long*)ex->totals;
+    ieee::tl_totals_flag = ex->overflow;
+    ieee::tl_totals_gs = ex->group_stride;
+    ieee::tl_totals_rep = ex->replicas;
+  }
+  ieee::tl_time_start = (hipEvent_t)ex->start;
+  ieee::tl_time_stop = (hipEvent_t)ex->stop;
+  return IEEE_OK;
+}
+
+extern "C" int ieee_conv2d_fwd_ex(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N, int64_t Hi,
+                                  int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride, int64_t pad,
+                                  int64_t x_gs, int64_t w_gs, int64_t y_gs, float* bn_partial, const ieee_conv_extras* extras,
+                                  void* stream) {
+  ieee::OneShotArms disarm;      // (also when the argument check below fails)
+  IEEE_TRY(arm_extras("conv2d_fwd_ex", extras));
+  return ieee_conv2d_fwd(x, w_packed, y, dtype, groups, N, Hi, Wi, Ci, Co, R, S, stride, pad, x_gs, w_gs, y_gs, bn_partial, stream);
+}
+
+extern "C" int ieee_conv2d_dgrad_ex(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
+                                    int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
+                                    int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
+                                    float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
+                                    int bn_mask_bits, int addend_stride, const void* bn_y2, float* bn_partial2,
+                                    const ieee_conv_extras* extras, void* stream) {
+  ieee::OneShotArms disarm;
+  IEEE_TRY(arm_extras("conv2d_dgrad_ex", extras));
+  return ieee_conv2d_dgrad2(dy, w_packed_d, dx, addend, dtype, groups, N, Hi, Wi, Ci, Co, R, S, stride, pad, dy_gs, w_gs, dx_gs,
+                            bn_partial, bn_y, bn_mask, bn_stats, bn_mask_bits, addend_stride, bn_y2, bn_partial2, stream);
 }
 
 /* measurement: the next conv forward / dgrad launch issued by this thread signals `start` when it begins and `stop` when it

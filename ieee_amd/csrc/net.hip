@@ -79,10 +79,21 @@ static int gbuf_sets() {
   return n == 2 ? 2 : 3;
 }
 
-// IEEE_WGRAD_FOLD (default 1): the weight gradients fold their split-K slabs inside the GEMM launch (ieee_conv2d_wgrad_fold):
-// the ~50 wgrad_reduce launches of a step disappear.  0: GEMM + reduction launch (round 5).
+// IEEE_WGRAD_FOLD=1 (default 0): the weight gradients fold their split-K slabs inside their OWN GEMM launch
+// (ieee_conv2d_wgrad_fold: last arriver per output tile).  Parity-green, bit-reproducible, and +0.68 ms per step (LABNOTES R6.1):
+// one reducer per tile is latency-bound.  The default is the chained form below.
 static bool wgrad_fold() {
-  static const bool on = !(getenv("IEEE_WGRAD_FOLD") && atoi(getenv("IEEE_WGRAD_FOLD")) == 0);
+  static const bool on = getenv("IEEE_WGRAD_FOLD") && atoi(getenv("IEEE_WGRAD_FOLD")) != 0;
+  return on;
+}
+// IEEE_WGRAD_CHAIN=1 (default 0): every weight-gradient GEMM runs the slab reduction of the PREVIOUS one as its prologue
+// (ieee_conv2d_wgrad_chained; two alternating slab regions); the last reduction of a backward part is flushed as a launch of
+// its own (wgrad_flush).  Same arithmetic as the reduction launches (bit-identical gradients), 46 launches fewer per step --
+// and +0.18 ms per step (14.24 -> 14.42, 4 interleaved rounds, LABNOTES R6.1): a GEMM workgroup that first walks its share of
+// the reduction (a chain of dependent round trips on ~450 workgroups instead of ~2 000 short-lived ones) holds its LDS and
+// registers that much longer.  The reduction launches stay the default.
+static bool wgrad_chain() {
+  static const bool on = getenv("IEEE_WGRAD_CHAIN") && atoi(getenv("IEEE_WGRAD_CHAIN")) != 0;
   return on;
 }
 static int wgrad_batch_mode() {
@@ -127,6 +138,9 @@ struct Net {
   const void* rtab_ws[RT_SLOTS] = {};
   ConvUnit reduce_unit;   // profiling label of the batched reductions
   size_t tot_begin = 0, tot_end = 0;   // the units' totals are one contiguous region: ONE memset per training forward
+  Tensor slab2;     // second slab region of the chained weight gradients (wgrad_chain): consecutive launches alternate
+  ieee_wgrad_reduce_desc wpend = {};   // the chained reduction that the next weight-gradient launch (or wgrad_flush) still owes
+  int wflip = 0;
   Tensor wtickets;  // arrival tickets of the weight gradients that fold their split-K slabs themselves (ieee_conv2d_wgrad_fold)
   Tensor tickets;   // 2 x 256 int32: arrival tickets of the convs that finalize their BatchNorm themselves (launch / branch stream)
   std::vector<PackDescHost> pack_train, pack_eval;   // all units (train: + dgrad operands)
@@ -142,6 +156,7 @@ struct Net {
   // on the overflow path only).  The kernels of a step set them, ieee_net_bn_overflow reads and clears them on the host after
   // the caller has synchronised with the step -- no launch, no copy, nothing on the queues.
   int* bn_overflow = nullptr;
+  bool totals_off = false;        // ieee_net_set_bn_totals(0): every unit on the per-tile partial-sum path (no range limit)
   bool bwd_totals_fresh = false;  // the backward totals are zero (set by the training forward, cleared by the backward that uses them)
   bool bwd_totals_state = false;  // ... and: those sums went into the unit's fixed-point totals (tot_b), not into bn_partial
   bool stem_a_valid = false;      // "<stem>.a" holds the activation of the LAST forward (a training forward does not write it)
@@ -374,6 +389,7 @@ void Net::plan() {
   // buffer is rewritten two blocks after the side-stream wgrad that reads it was issued (one set stalled the chain)
   for (int i = 0; i < NGBUF; ++i) gbuf[i] = alloc("g" + std::to_string(i), max_act, dt);
   slab = alloc("", max_slab / 4 + 64, IEEE_F32);
+  if (wgrad_chain()) slab2 = alloc("", max_slab / 4 + 64, IEEE_F32);
   max_part = std::max(max_part, (int64_t)12 * B * fdim);   // two [3][2][C][B] sets from ieee_cim_tail_bwd_g
   bnpart = alloc("", max_part + 64, IEEE_F32);
   bncoef = alloc("", 3 * 3 * max_c, IEEE_F32);
@@ -460,7 +476,16 @@ struct Run {
     }
     return IEEE_OK;
   }
-  void prof_begin(int cat, const ConvUnit& u, const char* label = nullptr) {
+  // options of the NEXT ieee_conv2d_fwd_ex / _dgrad_ex call (explicit-argument ABI: nothing is armed inside the library)
+  ieee_conv_extras ex_ = {};
+  const ieee_conv_extras* take_extras(void* totals, int64_t group_stride, int replicas) {
+    ex_.totals = totals; ex_.group_stride = group_stride; ex_.replicas = replicas; ex_.overflow = totals ? n.bn_overflow : nullptr;
+    ex_.reserved_ = 0;
+    return &ex_;
+  }
+  // by_launch: the call that follows is ieee_conv2d_fwd_ex / _dgrad_ex, which can carry the event pair as its own signals
+  void prof_begin(int cat, const ConvUnit& u, const char* label = nullptr, bool by_launch = false) {
+    ex_.start = ex_.stop = nullptr;
     if (!n.profiling) return;
     n.ev_label.push_back(label ? label : (cat ? "wgrad" : "fwd"));
     if (n.ev_used + 2 > n.ev_pool.size()) {
@@ -468,8 +493,8 @@ struct Run {
     }
     // in situ (mode 2), forward / dgrad: the launch itself carries the pair as its start / stop signals -- nothing is added
     // to the queue; otherwise an event record on each side of the call
-    timed_by_launch = n.profiling == 2 && cat == 0;
-    if (timed_by_launch) (void)ieee_conv_profile_events((void*)n.ev_pool[n.ev_used], (void*)n.ev_pool[n.ev_used + 1]);
+    timed_by_launch = n.profiling == 2 && cat == 0 && by_launch;
+    if (timed_by_launch) { ex_.start = (void*)n.ev_pool[n.ev_used]; ex_.stop = (void*)n.ev_pool[n.ev_used + 1]; }
     else (void)hipEventRecord(n.ev_pool[n.ev_used], (hipStream_t)st);
     n.ev_cat.push_back(cat);
     n.ev_name.push_back(u.name + " " + std::to_string(u.Ci_src) + "->" + std::to_string(u.Co) + " k" + std::to_string(u.R_src) +
@@ -481,8 +506,8 @@ struct Run {
   bool timed_by_launch = false;
   void prof_end() {
     if (!n.profiling) return;
-    if (timed_by_launch) (void)ieee_conv_profile_events(nullptr, nullptr);   // (not consumed: the call launched no conv kernel)
-    else (void)hipEventRecord(n.ev_pool[n.ev_used + 1], (hipStream_t)st);
+    if (!timed_by_launch) (void)hipEventRecord(n.ev_pool[n.ev_used + 1], (hipStream_t)st);
+    ex_.start = ex_.stop = nullptr;
     timed_by_launch = false;
     n.ev_used += 2;
   }
@@ -505,7 +530,7 @@ struct Run {
   bool fused_stats = false;
   bool fused_fin = false;    // ... and finalized them too (ieee_conv2d_fwd_bn_train): bn() only applies
   bool frz(const ConvUnit& u) const { return (n.frozen & u.child) != 0; }
-  int totals_rep(const ConvUnit& u) const { return totals_rep_for((u.M(B) + 127) / 128); }
+  int totals_rep(const ConvUnit& u) const { return n.totals_off ? 0 : totals_rep_for((u.M(B) + 127) / 128); }
   bool use_totals(const ConvUnit& u) const {
     // (the kernels fetch gamma / beta / stats as 16-byte loads: slot offsets and modality strides multiples of 4 floats)
     return n.dtype == IEEE_BF16 && totals_rep(u) > 0 && u.Co % 8 == 0 && 256 % (u.Co / 8) == 0 && u.Co / 8 <= 256 &&
@@ -516,19 +541,19 @@ struct Run {
     const int64_t ldf = ieee_conv_packed_ld(n.dtype, u.Ci, u.R, u.S);
     fused_stats = want_stats && n.dtype == IEEE_BF16 && !frz(u);
     fwd_totals = fused_stats && use_totals(u);
-    if (fwd_totals) IEEE_TRY(ieee_conv_next_bn_totals(P(u.tot_f), (int64_t)2 * u.Co, totals_rep(u), n.bn_overflow));
     // (off by default: correct and bit-reproducible, but measured SLOWER -- 15.40 -> 15.91 ms per step: every workgroup of the
     // conv has to drain its output stores before it may take its ticket, which costs the conv more than the launch saves)
     static const bool f_fin = getenv("IEEE_BN_FIN_FUSE") && atoi(getenv("IEEE_BN_FIN_FUSE")) != 0;
     fused_fin = f_fin && fused_stats && !fwd_totals && u.M(B) <= ieee_conv2d_fwd_bn_train_max_rows() && u.Ci % 64 == 0 && u.Co % 8 == 0;
-    prof_begin(0, u);
+    prof_begin(0, u, nullptr, !fused_fin);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     if (fused_fin)
       return ieee_conv2d_fwd_bn_train(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
                                       (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, bnpart_cur, par(u.s_g), par(u.s_b),
                                       gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), n.bn_mom, n.bn_eps, tickets_cur, st);
-    return ieee_conv2d_fwd(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
-                           (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, fused_stats ? bnpart_cur : nullptr, st);
+    return ieee_conv2d_fwd_ex(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
+                              (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, fused_stats ? bnpart_cur : nullptr,
+                              take_extras(fwd_totals ? P(u.tot_f) : nullptr, (int64_t)2 * u.Co, fwd_totals ? totals_rep(u) : 1), st);
   }
   int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training, void* relu_bits = nullptr) {
     if (frz(u)) training = 0;      // frozen child: running statistics, no update (module.eval() in the reference)
@@ -740,10 +765,21 @@ struct Run {
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
     if (u.Ci != u.Ci_src || u.S != u.S_src || u.R != u.R_src) {   // padded stem: gradient of the padded operand, then drop the padding
       const int64_t npad = (int64_t)u.Co * u.Ci * u.R * u.S;
+      IEEE_TRY(wgrad_pending_now());
       IEEE_TRY(ieee_conv2d_wgrad(dy, x, F(u.dwpad), P(n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride,
                                  u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, npad, 0, st));
       return ieee_unpad_weight_grad(F(u.dwpad), grd(u.s_w), 3, u.Co, u.Ci, u.R, u.S, u.Ci_src, u.R_src, u.S_src, npad, gs(u.s_w), 0,
                                     st);
+    }
+    if (wgrad_batch_mode() == 0 && wgrad_chain()) {
+      ieee_wgrad_reduce_desc d;
+      const int rc = ieee_conv2d_wgrad_chained(dy, x, grd(u.s_w), P(n.wflip ? n.slab2 : n.slab), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co,
+                                               u.R, u.S, u.stride, u.pad, u.M(B) * u.Co, (int64_t)B * u.Hi * u.Wi * u.Ci, gs(u.s_w), 0,
+                                               n.wpend.kind != 0 ? &n.wpend : nullptr, &d, st);
+      if (rc != IEEE_OK) return rc;       // (n.wpend stays owed: the backward's error path flushes or drops it)
+      n.wpend = d;
+      if (d.kind != 0) n.wflip ^= 1;
+      return IEEE_OK;
     }
     if (wgrad_batch_mode() == 0 && wgrad_fold() && n.dtype == IEEE_BF16)
       return ieee_conv2d_wgrad_fold(dy, x, grd(u.s_w), P(n.slab), (int32_t*)P(n.wtickets), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co,
@@ -759,7 +795,25 @@ struct Run {
   }
   // The slab reductions of every weight gradient issued since the last flush, as one launch on the stream the weight
   // gradients run on.  slot: which of the step's flush points this is (its descriptor table is cached on the device).
+  // the chained reduction still owed, as a launch of its own on the CURRENT stream `st`
+  int wgrad_pending_now() {
+    if (n.wpend.kind == 0) return IEEE_OK;
+    const ieee_wgrad_reduce_desc d = n.wpend;
+    n.wpend.kind = 0;
+    return ieee_wgrad_reduce_pending(&d, 3, st);
+  }
   int wgrad_flush(int slot) {
+    if (n.wpend.kind != 0) {             // chained form: the last reduction of this group of layers
+      void* main_st = st;
+      const bool on_side = side_enabled();
+      if (on_side) st = (void*)n.side;
+      prof_begin(1, n.reduce_unit, "wgrad_reduce");
+      const int rc = wgrad_pending_now();
+      prof_end();
+      st = main_st;
+      if (on_side) n.side_dirty = true;
+      IEEE_TRY(rc);
+    }
     if (n.rpend.empty()) return IEEE_OK;
     std::vector<ieee_wgrad_reduce_desc> tab;
     tab.swap(n.rpend);
@@ -802,18 +856,19 @@ struct Run {
     const bool fuse2 = fuse && prev_ds != nullptr && ds_sums && !branch_enabled(2);
     fused_bwd = fuse;
     n.bwd_totals_state = fuse && !fuse2 && use_totals(*prev) && !frz(*prev);
-    if (n.bwd_totals_state) IEEE_TRY(ieee_conv_next_bn_totals(P(prev->tot_b), (int64_t)2 * prev->Co, totals_rep(*prev), n.bn_overflow));
     if (fuse2) ds_sums_of = prev_ds;     // (consumed, and cleared, by that unit's bn_bwd in the next block)
     will_write(dx);
-    prof_begin(0, u, "dgrad");
+    prof_begin(0, u, "dgrad", true);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
-    return ieee_conv2d_dgrad2(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
+    const ieee_conv_extras* ex = n.bwd_totals_state ? take_extras(P(prev->tot_b), (int64_t)2 * prev->Co, totals_rep(*prev))
+                                                    : take_extras(nullptr, 0, 1);
+    return ieee_conv2d_dgrad_ex(dy, P(u.wd), dx, addend, n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
                               u.M(B) * u.Co, u.Ci * ldd, (int64_t)B * u.Hi * u.Wi * u.Ci, fuse ? bnpart_cur : nullptr,
                               fuse ? P(prev->y) : nullptr,
                               (fuse && prev_mask_tensor) ? (prev->abits.numel ? P(prev->abits) : P(prev->a)) : nullptr,
                               (fuse && !prev_mask_tensor) ? F(prev->stats) : nullptr,
                               (fuse && prev_mask_tensor && prev->abits.numel) ? 1 : 0, addend_stride,
-                              fuse2 ? P(prev_ds->y) : nullptr, fuse2 ? (float*)(ws + n.bnpart2.off) : nullptr, st);
+                              fuse2 ? P(prev_ds->y) : nullptr, fuse2 ? (float*)(ws + n.bnpart2.off) : nullptr, ex, st);
   }
   // The gradient a stride-2 1x1 (downsample) conv sends to its input touches only the pixels with even row and column:
   // kept compact, [B, Ho, Wo, Ci], it is a dense 1x1 stride-1 dgrad over the output grid (the lean plain-matrix path) and the
@@ -829,10 +884,11 @@ struct Run {
     fused_bwd = false;
     n.bwd_totals_state = false;
     will_write(dx);
-    prof_begin(0, d, "dgrad");
+    prof_begin(0, d, "dgrad", true);
     struct G { Run* r; ~G() { r->prof_end(); } } guard{this};
-    return ieee_conv2d_dgrad(dy, P(d.wd), dx, nullptr, n.dtype, 3, B, d.Ho, d.Wo, d.Ci, d.Co, 1, 1, 1, 0, d.M(B) * d.Co,
-                             d.Ci * ldd, d.M(B) * d.Ci, nullptr, nullptr, nullptr, nullptr, 0, 1, st);
+    return ieee_conv2d_dgrad_ex(dy, P(d.wd), dx, nullptr, n.dtype, 3, B, d.Ho, d.Wo, d.Ci, d.Co, 1, 1, 1, 0, d.M(B) * d.Co,
+                                d.Ci * ldd, d.M(B) * d.Ci, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr,
+                                take_extras(nullptr, 0, 1), st);
   }
   // grouped fp32 GEMM over the 3 modalities with uniform strides
   int gemm3(const float* A, int64_t a_gs, const float* Bm, int64_t b_gs, float* C, int64_t c_gs, const float* bias,
@@ -1102,6 +1158,7 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
                         "its gradients are incomplete -- run the step again");
   }
   if (part <= 0) {
+    N.wpend.kind = 0;   // (a failed backward may have left a chained reduction owed: its gradients are recomputed now)
     // a SECOND backward over the same forward (e.g. two loss terms differentiated one after the other) must not add to
     // the first one's totals: zero them again (the forward's totals were consumed by its BatchNorm passes)
     if (dt == IEEE_BF16 && (totals_tiles() > 0 || wgrad_fold())) {
@@ -1567,10 +1624,16 @@ extern "C" int ieee_net_set_frozen(void* handle, int mask) {
 extern "C" int ieee_net_bn_overflow(void* handle, int* out4) {
   Net* n = as_net(handle);
   IEEE_REQUIRE(n && out4, "net_bn_overflow: null pointer");
-  for (int i = 0; i < 4; ++i) {
-    out4[i] = n->bn_overflow != nullptr ? ((volatile int*)n->bn_overflow)[i] : 0;
-    if (n->bn_overflow != nullptr) ((volatile int*)n->bn_overflow)[i] = 0;
-  }
+  // read AND clear in one atomic exchange per word: with deferred summaries the host runs steps ahead of the device, and
+  // a kernel of a later step may set a word between a separate read and clear -- that report would be lost
+  for (int i = 0; i < 4; ++i) out4[i] = n->bn_overflow != nullptr ? __atomic_exchange_n(&n->bn_overflow[i], 0, __ATOMIC_ACQ_REL) : 0;
+  return IEEE_OK;
+}
+
+extern "C" int ieee_net_set_bn_totals(void* handle, int on) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n, "net_set_bn_totals: null handle");
+  n->totals_off = !on;
   return IEEE_OK;
 }
 

@@ -79,6 +79,8 @@ class _SlotDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, key):
         slot, indices = key
+        if slot < 0:                           # _SlotSampler's end-of-pass marker: nothing to decode, it only travels in order
+            return {'end_of_pass': True}
         if self.view is None:
             self.view = self.ring.numpy()
         items = [self.base[i] for i in indices]
@@ -104,7 +106,12 @@ class _SlotSampler(object):
     one.  With an iterator per epoch the pipeline drains and refills at every boundary: one 50-60 ms stall per epoch, measured
     (scripts/loader_probe.py: the single longest wait of every 40-step window, 3-4 steps of GPU time).  The next epoch's order
     is then drawn ~2 x workers batches EARLY, from the same generators in the same order -- the sequence of batches is the
-    reference sampler's as long as nothing else consumes python's / numpy's global generators in between."""
+    reference sampler's as long as nothing else consumes python's / numpy's global generators in between.
+    A pass ends where the inner batch sampler ENDS, not after len() batches: RandomIdentitySampler's length is an upper bound
+    (it stops once fewer than P identities have a group left, data/sampler.py), so every pass is followed by an END marker
+    (slot -1) that travels through the workers in order and tells the consumer where the epoch stops (`epoch_items`) -- the
+    epoch boundaries, the optimizer steps per epoch and which pass a batch comes from are the non-continuous loader's."""
+    END = (-1, [])
 
     def __init__(self, batches, slots, continuous=False):
         self.batches, self.slots, self.k, self.continuous = batches, slots, 0, continuous
@@ -116,11 +123,23 @@ class _SlotSampler(object):
                 yield (self.k % self.slots, list(idx))
                 self.k += 1
                 n += 1
-            if not self.continuous or n == 0:
+            if not self.continuous:
+                return
+            yield self.END
+            if n == 0:
                 return
 
     def __len__(self):
         return len(self.batches)
+
+
+def epoch_items(it):
+    """the items of ONE pass out of a continuous index stream: everything up to the next end-of-pass marker (which is
+    consumed); a stream that ends without one ends the epoch too"""
+    for item in it:
+        if isinstance(item, dict) and item.get('end_of_pass'):
+            return
+        yield item
 
 
 def _identity(x):
@@ -310,19 +329,19 @@ class DeviceLoader(object):
             th.join(timeout=5.0)          # (normally immediate; if it is still inside the DataLoader the next __iter__ waits for it)
 
     def _epoch_source(self):
-        """the decoded batches of ONE epoch.  Continuous ring path: exactly len(self) items of the one iterator that lives
-        across epochs (an epoch the consumer abandoned half way is dropped: fresh iterator, fresh draw of the order)"""
+        """the decoded batches of ONE epoch.  Continuous ring path: the items up to the sampler's end-of-pass marker out of the
+        one iterator that lives across epochs (an epoch the consumer abandoned half way is dropped: fresh iterator, fresh draw
+        of the order)"""
         if self.ring is None or not getattr(self, "_continuous", False):
             return iter(self.loader)
 
         def one_epoch():
             if self._it is None or self._epoch_pos != 0:
                 self._it = iter(self.loader)
-            n = len(self._slot_sampler)
             self._epoch_pos = 0
-            for k in range(n):
+            for k, item in enumerate(epoch_items(self._it)):      # up to the sampler's REAL end of pass (its marker)
                 self._epoch_pos = k + 1          # (a consumer that stops here leaves a position != 0 behind)
-                yield next(self._it)
+                yield item
             self._epoch_pos = 0
         return one_epoch()
 

@@ -571,11 +571,12 @@ class _FusedStepMixin(object):
         done.record(torch.cuda.current_stream(small.device))
 
         net = getattr(self, "_step_net", None)
+        step_idx = self._steps_done = getattr(self, "_steps_done", 0) + 1      # 1-based index of this engine's train steps
 
         def read():
             done.synchronize()
             slot[1] = None
-            self._check_bn_range(net)
+            self._check_bn_range(net, step_idx)
             v = host.numpy().copy()
             hl, ha = v[:18], v[18:36]
             lR, lN, lT = float(hl[0:6].sum()), float(hl[6:12].sum()), float(hl[12:18].sum())
@@ -587,25 +588,39 @@ class _FusedStepMixin(object):
         slot[1] = DeferredSummary(keys, read)
         return slot[1]
 
-    def _check_bn_range(self, net):
+    def _check_bn_range(self, net, step=None):
         """The bf16 train step keeps its BatchNorm sums as int64 fixed-point totals (include/ieee_amd.h,
         ieee_conv_next_bn_totals): bit-reproducible, but with a RANGE (forward sum y^2 up to 2.7e11 per channel, backward sums up
         to 4.2e6) that torch's fp32 batch_norm (reference: torchreid/models/resnet.py:164-184) does not have.  The kernels
         clamp and report instead of wrapping; this is where the report reaches the caller -- at the step's (possibly deferred)
-        summary read, on the host, without a launch or a copy.  A clamped tile means the statistics of that step were wrong:
-        raise.  A total beyond half the range is still exact: warn once."""
+        summary read, on the host, without a launch or a copy.  A clamped tile means the statistics of that step (and of the
+        steps already queued behind it) were not fp32 BatchNorm's: DEGRADE, then warn -- the executor is switched to the
+        per-tile partial-sum path (fp32 sums, no range: the reference's semantics at any magnitude, ieee_net_set_bn_totals) for
+        every step from here on and training continues; IEEE_BN_STRICT=1 raises instead.  A total beyond half the range is
+        still exact: warn once."""
         if net is None:
             return
         f_clamp, b_clamp, f_half, b_half = net.bn_overflow()
         if f_clamp or b_clamp:
             which = " and ".join(w for w, on in (("forward (sum y, sum y^2 of a conv output)", f_clamp),
                                                  ("backward (sum g, sum g*y)", b_clamp)) if on)
-            raise _lib.IeeeAmdError(
-                "BatchNorm statistics left the range of the fixed-point totals in the %s pass of a recent step (or were NaN): "
-                "the int64 totals hold sum y^2 up to 2.7e11 and backward sums up to 4.2e6 per channel; beyond that a tile sum is "
-                "clamped, so the statistics -- and the parameters updated from them -- are not what fp32 BatchNorm gives. "
-                "Activations / gradients of that size mean the run is diverging; to train through it anyway set "
-                "IEEE_BN_TOTALS_TILES=0 (per-tile partial sums, no range limit) and restart from the last checkpoint." % which)
+            msg = ("BatchNorm statistics left the range of the fixed-point totals in the %s pass of a recent step (or were NaN): "
+                   "the int64 totals hold sum y^2 up to 2.7e11 and backward sums up to 4.2e6 per channel; beyond that a tile sum is "
+                   "clamped, so the statistics -- and the parameters updated from them -- are not what fp32 BatchNorm gives. "
+                   "Activations / gradients of that size usually mean the run is diverging." % which)
+            import os
+            if os.environ.get("IEEE_BN_STRICT", "0") == "1":
+                raise _lib.IeeeAmdError(msg + "  (IEEE_BN_STRICT=1: raising; IEEE_BN_TOTALS_TILES=0 selects the per-tile "
+                                              "partial-sum path, which has no range limit, from the start.)")
+            import warnings
+            net.set_bn_totals(False)
+            self.model._bn_totals_off = True               # executors built later (another batch shape) start degraded too
+            warnings.warn("ieee_amd: %s  Detected at the summary read of step %s (the steps queued since -- at most %d -- used the "
+                          "clamped statistics too).  Switched to the per-tile partial-sum path (fp32 sums, no range limit; about "
+                          "0.2 ms per step slower) for every following step; restart from the last checkpoint with "
+                          "IEEE_BN_TOTALS_TILES=0 if those steps matter, or set IEEE_BN_STRICT=1 to raise here instead."
+                          % (msg, "?" if step is None else step, self._RING - 1), RuntimeWarning)
+            return
         if (f_half or b_half) and not getattr(self, "_bn_range_warned", False):
             import warnings
             self._bn_range_warned = True

@@ -76,6 +76,14 @@ class IEEE3modalPart(nn.Module):
             # MFMA end to end: logits / features within 1e-3 of the reference's CPU path) is compute_dtype=torch.float32
             # or IEEE_COMPUTE_DTYPE=fp32 for unchanged callers
             import os
+            if "IEEE_COMPUTE_DTYPE" not in os.environ:
+                # a caller who only swapped the import leaves the reference's fp32 arithmetic without having said so: say it once
+                import warnings
+                warnings.warn("ieee_amd: IEEE3modalPart built without compute_dtype runs in the bf16 SPEED mode (bf16 storage, fp32 "
+                              "accumulate: BASELINE config 2); the reference's fp32 arithmetic -- logits / features within 1e-3 -- is "
+                              "the PARITY mode: build_model(..., compute_dtype=torch.float32) or IEEE_COMPUTE_DTYPE=fp32.  Pass "
+                              "compute_dtype=torch.bfloat16 (or set IEEE_COMPUTE_DTYPE=bf16) to choose the speed mode silently.",
+                              RuntimeWarning, stacklevel=3)
             env = os.environ.get("IEEE_COMPUTE_DTYPE", "bf16").lower()
             if env not in ("bf16", "fp32", "float32", "bfloat16"):
                 raise ValueError("IEEE_COMPUTE_DTYPE must be bf16 or fp32, got %r" % env)
@@ -295,6 +303,8 @@ class IEEE3modalPart(nn.Module):
             self._nets.clear()       # one live workspace at a time
             net = NativeNet(self, batch, height, width, self.compute_dtype)
             net.set_frozen(getattr(self, "_frozen_mask", 0))
+            if getattr(self, "_bn_totals_off", False):      # the range guard degraded this model (engine._check_bn_range)
+                net.set_bn_totals(False)
             self._nets[key] = net
         return net
 

@@ -228,6 +228,20 @@ int ieee_conv2d_wgrad_deferred(const void* dy, const void* x, float* dw_oihw, vo
                       ieee_wgrad_reduce_desc* reduce, void* stream);
 int ieee_wgrad_reduce_batch(const ieee_wgrad_reduce_desc* device_descs, int64_t n, int64_t total_blocks, int64_t groups,
                             void* stream);
+/* CHAINED weight gradients (round 6): ieee_conv2d_wgrad_deferred whose launch also runs the reduction `prev` -- the
+ * descriptor an EARLIER deferred / chained call on the SAME stream returned; NULL or kind 0: none -- as its PROLOGUE: every
+ * workgroup of this GEMM takes a share of that reduction's grid before its own k-loop.  The kernel boundary between the two
+ * launches is the only synchronisation (no tickets, no fences), the arithmetic is the reduction launch's (bit-identical
+ * gradients), and the ~50 reduction launches of a backward pass disappear from the stream.  Rules: `work` of consecutive
+ * chained calls must alternate between two regions (prev's slabs are read while this call's are written; checked); `prev` is
+ * always taken care of when the call returns IEEE_OK (a form without a prologue -- the stem -- launches it first); the LAST
+ * descriptor of a chain is run by ieee_wgrad_reduce_pending before anything reads that gradient.  Host-side structs, passed
+ * by value to the kernels: nothing is uploaded. */
+int ieee_conv2d_wgrad_chained(const void* dy, const void* x, float* dw_oihw, void* work, int dtype, int64_t groups,
+                      int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S,
+                      int64_t stride, int64_t pad, int64_t dy_gs, int64_t x_gs, int64_t dw_gs, int accumulate,
+                      const ieee_wgrad_reduce_desc* prev, ieee_wgrad_reduce_desc* reduce, void* stream);
+int ieee_wgrad_reduce_pending(const ieee_wgrad_reduce_desc* pending, int64_t groups, void* stream);
 
 
 /* ---- BatchNorm2d (+ residual, + ReLU) over NHWC maps [M][C] ------------------ */
@@ -284,7 +298,32 @@ int ieee_bn2d_bwd_ev(const void* dout, const void* out_mask, const void* y, void
  * `replicas` (a power of two <= 64; 1 = plain) spreads the adders: totals[replica][group][2][C] (group_stride = 2 * C), row
  * tile t adds to replica t % replicas, and the BatchNorm passes add the replicas up in their prologue -- same-address atomics
  * retire at ~23 ns each, so a launch of 1 024 row tiles pays +24 us with one copy and +3 us with eight. */
-int ieee_conv_next_bn_totals(void* totals, int64_t group_stride, int replicas, int* overflow);
+int ieee_conv_next_bn_totals(void* totals, int64_t group_stride, int replicas, int* overflow);   /* DEPRECATED: see ieee_conv_extras */
+/* EXPLICIT-ARGUMENT forms (round 6; SURVEY.md section 8b: "stateless, re-entrant, all work on the caller-supplied stream").
+ * ieee_conv_next_bn_totals / ieee_conv_profile_events change what the NEXT conv call of the thread does -- hidden per-thread
+ * state a binding cannot express as one call.  ieee_conv2d_fwd_ex / ieee_conv2d_dgrad_ex take the same options as one struct
+ * (NULL = none) and leave nothing behind; the executor calls these.  The two arming entry points stay as thin deprecated
+ * wrappers over the same mechanism (they are disarmed on every return path of the next conv call, as before).
+ *   totals / group_stride / replicas / overflow : as ieee_conv_next_bn_totals (totals NULL = per-tile partials in bn_partial)
+ *   start / stop : hipEvent_t pair (timing enabled) the launch carries as its own start / stop signals, or NULL, NULL */
+typedef struct ieee_conv_extras {
+  void* totals;
+  int64_t group_stride;
+  int32_t replicas;
+  int32_t reserved_;        /* 0 */
+  int* overflow;
+  void* start;
+  void* stop;
+} ieee_conv_extras;
+int ieee_conv2d_fwd_ex(const void* x, const void* w_packed, void* y, int dtype, int64_t groups, int64_t N, int64_t Hi,
+                       int64_t Wi, int64_t Ci, int64_t Co, int64_t R, int64_t S, int64_t stride, int64_t pad, int64_t x_gs,
+                       int64_t w_gs, int64_t y_gs, float* bn_partial, const ieee_conv_extras* extras, void* stream);
+int ieee_conv2d_dgrad_ex(const void* dy, const void* w_packed_d, void* dx, const void* addend, int dtype,
+                         int64_t groups, int64_t N, int64_t Hi, int64_t Wi, int64_t Ci, int64_t Co, int64_t R,
+                         int64_t S, int64_t stride, int64_t pad, int64_t dy_gs, int64_t w_gs, int64_t dx_gs,
+                         float* bn_partial, const void* bn_y, const void* bn_mask, const float* bn_stats,
+                         int bn_mask_bits, int addend_stride, const void* bn_y2, float* bn_partial2,
+                         const ieee_conv_extras* extras, void* stream);
 int ieee_bn2d_fwd_totals(const void* y, const void* residual, void* out, int dtype, int64_t groups, int64_t M,
                          int64_t C, int64_t act_gs, const float* gamma, const float* beta, int64_t param_gs,
                          float* running_mean, float* running_var, int64_t buf_gs, float* stats, const void* totals,
@@ -549,6 +588,11 @@ int ieee_net_set_frozen(void* handle, int mask);
  * sum.  Non-zero: they are NOT what torch's fp32 batch_norm (torchreid/models/resnet.py:164-184) would have computed; train
  * with IEEE_BN_TOTALS_TILES=0 (per-tile partial sums, no range limit) from the last good checkpoint. */
 int ieee_net_bn_overflow(void* handle, int* out4);
+/* on = 0: from the next forward on, every BatchNorm of this executor takes the per-tile partial-sum path (ieee_bn2d_fwd /
+ * ieee_bn2d_bwd: fp32 sums without a range, as the reference's fp32 nn.BatchNorm2d, torchreid/models/resnet.py:151,164-184;
+ * +104 finalize launches per step); on = 1: fixed-point totals again where IEEE_BN_TOTALS_TILES allows.  What the engine does
+ * when ieee_net_bn_overflow reports a clamped tile: degrade, warn, keep training (IEEE_BN_STRICT=1: raise instead). */
+int ieee_net_set_bn_totals(void* handle, int on);
 /* Inference cache: after an eval-mode ieee_net_forward the workspace holds the packed weights and every BatchNorm's
  * scale / shift; the next eval forward on the same workspace reuses them (no packing launch, no finalize launches)
  * unless ieee_net_eval_cache(handle, 0) was called in between.  The CALLER must call it whenever parameters or

@@ -63,3 +63,29 @@ def test_loading_the_library_brings_torch_in_first():
             "from ieee_amd import _lib; _lib.load(); assert 'torch' in sys.modules; print('ok')" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """the ctypes mirrors of the header's structs (ieee_conv_extras of the explicit-argument conv calls, ieee_wgrad_reduce_desc
+    of the deferred / chained weight gradients) against what a C compiler makes of include/ieee_amd.h: size and every offset"""
+    import subprocess
+    from ieee_amd import _lib
+    fields = {"ieee_conv_extras": [f[0] for f in _lib.ConvExtras._fields_],
+              "ieee_wgrad_reduce_desc": [f[0] for f in _lib.WgradReduceDesc._fields_]}
+    lines = []
+    for st, names in fields.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (st, st))
+        lines += ['printf(" %%zu", offsetof(%s, %s));' % (st, f) for f in names]
+        lines.append('printf("\\n");')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ieee_amd.h"\nint main(void) {\n%s\nreturn 0; }\n' % "\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    mirrors = {"ieee_conv_extras": _lib.ConvExtras, "ieee_wgrad_reduce_desc": _lib.WgradReduceDesc}
+    assert len(out) == 2
+    for line in out:
+        name, size, *offs = line.split()
+        cls = mirrors[name]
+        assert ctypes.sizeof(cls) == int(size), name
+        assert [getattr(cls, f).offset for f in fields[name]] == [int(o) for o in offs], name

@@ -183,3 +183,23 @@ def test_part_runs_follow_frozen_parameters():
     for p in m.parameters():
         p.requires_grad = True
     assert merged(union(m.part_runs())) == merged(m.trainable_runs()) and len(merged(m.trainable_runs())) >= 1
+
+
+def test_default_arithmetic_is_announced_once_per_construction(monkeypatch):
+    """a caller who only swaps the import gets the bf16 speed mode: build_model says so (RuntimeWarning naming
+    compute_dtype=torch.float32 as the parity mode) unless the mode was chosen by keyword or by IEEE_COMPUTE_DTYPE"""
+    import warnings
+    monkeypatch.delenv("IEEE_COMPUTE_DTYPE", raising=False)
+    with pytest.warns(RuntimeWarning, match=r"bf16 SPEED mode.*compute_dtype=torch.float32"):
+        m = build_model("ieee3modalPart", num_classes=5, loss="margin", pretrained=False, device="cpu")
+    assert m.compute_dtype == torch.bfloat16
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert build_model("ieee3modalPart", num_classes=5, loss="margin", pretrained=False, device="cpu",
+                           compute_dtype=torch.bfloat16).compute_dtype == torch.bfloat16
+        assert build_model("ieee3modalPart", num_classes=5, loss="margin", pretrained=False, device="cpu",
+                           compute_dtype=torch.float32).compute_dtype == torch.float32
+        monkeypatch.setenv("IEEE_COMPUTE_DTYPE", "bf16")
+        assert build_model("ieee3modalPart", num_classes=5, loss="margin", pretrained=False, device="cpu").compute_dtype == torch.bfloat16
+        monkeypatch.setenv("IEEE_COMPUTE_DTYPE", "fp32")
+        assert build_model("ieee3modalPart", num_classes=5, loss="margin", pretrained=False, device="cpu").compute_dtype == torch.float32

@@ -418,6 +418,57 @@ def test_deferred_wgrad_with_one_batched_reduction_is_bit_identical(dtype):
         assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_chained_wgrad_runs_the_previous_reduction_as_its_prologue_bit_identical(dtype):
+    """ieee_conv2d_wgrad_chained: every launch folds the slabs of the PREVIOUS layer before its own GEMM (two alternating slab
+    regions), the last descriptor is flushed by ieee_wgrad_reduce_pending.  Same kernels' arithmetic as the immediate
+    ieee_conv2d_wgrad -> the same bits, for every reduction form, with and without `accumulate`, and a refused call when the
+    pending reduction still reads the region handed in as `work`."""
+    import ctypes
+    from ieee_amd import _lib as L
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(12)
+    dt = L.IEEE_BF16 if dtype == torch.bfloat16 else L.IEEE_F32
+    #        N   H   W   Ci   Co   R  stride pad
+    layers = [(8, 16, 8, 256, 64, 1, 1, 0), (8, 16, 8, 64, 64, 3, 1, 1), (8, 16, 8, 512, 512, 3, 1, 1), (16, 8, 8, 1024, 256, 1, 1, 0),
+              (2, 16, 8, 256, 512, 1, 2, 0), (3, 5, 7, 64, 128, 3, 1, 1), (2, 70, 134, 4, 64, 8, 2, 0), (8, 32, 16, 8, 64, 7, 2, 3),
+              (64, 32, 16, 64, 256, 1, 1, 0), (64, 16, 8, 2048, 2048, 1, 1, 0), (64, 16, 8, 256, 256, 3, 1, 1)]
+    G = 3
+    big = max(lib.ieee_conv2d_wgrad_workspace_bytes(dt, G, N, (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1, Ci, Co, R, R)
+              for (N, H, W, Ci, Co, R, st, pad) in layers)
+    regions = [torch.empty(big, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    flip, pend, keep, want, kinds = 0, None, [], [], set()
+    for (N, H, W, Ci, Co, R, stride, pad) in layers:
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+        x = torch.randn(G, N, H, W, Ci, generator=g).cuda().to(dtype)
+        dy = torch.randn(G, N, Ho, Wo, Co, generator=g).cuda().to(dtype)
+        args = (dt, G, N, H, W, Ci, Co, R, R, stride, pad, dy[0].numel(), x[0].numel(), Co * Ci * R * R)
+        for acc in (0, 1):
+            base = torch.randn(G, Co, Ci, R, R, generator=g).cuda()
+            ref, out = base.clone(), base.clone()
+            work0 = torch.empty(big, dtype=torch.uint8, device="cuda")
+            L.check(lib.ieee_conv2d_wgrad(L.ptr(dy), L.ptr(x), L.ptr(ref), L.ptr(work0), *args, acc, L.stream()))
+            d = L.WgradReduceDesc()
+            if pend is not None:       # the region the pending reduction reads must not be handed in again
+                rc = lib.ieee_conv2d_wgrad_chained(L.ptr(dy), L.ptr(x), L.ptr(out), L.ptr(regions[flip ^ 1]), *args, acc,
+                                                   ctypes.addressof(pend), ctypes.addressof(d), L.stream())
+                assert rc != 0 and b"alternate" in lib.ieee_last_error()
+            L.check(lib.ieee_conv2d_wgrad_chained(L.ptr(dy), L.ptr(x), L.ptr(out), L.ptr(regions[flip]), *args, acc,
+                                                  ctypes.addressof(pend) if pend is not None else None, ctypes.addressof(d),
+                                                  L.stream()))
+            kinds.add(d.kind)
+            pend = d if d.kind != 0 else None
+            if d.kind != 0:
+                flip ^= 1
+            keep.append((x, dy, out)); want.append(ref)
+    if pend is not None:
+        L.check(lib.ieee_wgrad_reduce_pending(ctypes.addressof(pend), G, L.stream()))
+    torch.cuda.synchronize()
+    assert ({0, 1, 2, 3} if dtype == torch.bfloat16 else {1, 2}) <= kinds, kinds
+    for i, ((x, dy, out), ref) in enumerate(zip(keep, want)):
+        assert torch.equal(out, ref), "layer %d" % (i // 2)
+
+
 @pytest.mark.parametrize("Ci,Co,R,H,W,REP", [(64, 256, 1, 16, 8, 1), (128, 128, 3, 16, 8, 1), (256, 64, 1, 12, 10, 1), (64, 256, 1, 16, 8, 8),
                                              (128, 128, 3, 16, 8, 4)])
 def test_batchnorm_sums_as_fixed_point_totals_equal_the_partial_sum_path(Ci, Co, R, H, W, REP):

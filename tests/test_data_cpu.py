@@ -71,6 +71,55 @@ def test_identity_sampler_batches_hold_k_consecutive_samples_per_identity():
         smp.RandomIdentitySampler(data, batch_size=2, num_instances=4)
 
 
+class _TinyBase(object):
+    """dataset stand-in for the ring path: three 4 x 4 'images' per sample that carry the sample's index"""
+
+    def __init__(self, data):
+        self.data = data
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, i):
+        img = np.full((4, 4, 3), i % 251, dtype=np.uint8)
+        return {'img': [img, img, img], 'pid': self.data[i][1], 'camid': self.data[i][2], 'impath': str(i), 'timeid': 0}
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_continuous_index_stream_ends_every_epoch_where_the_sampler_ends(workers):
+    """RandomIdentitySampler's len() is an UPPER bound: a pass stops once fewer than P identities have a group left.  The
+    prefetching loader's one-index-stream-across-epochs mode must cut its epochs where the sampler's passes really end (an
+    end-of-pass marker travels through the workers), not after len() batches -- else an epoch borrows its tail from the next
+    pass and the boundary drifts.  Here: an identity distribution whose passes are SHORTER than len(); three epochs of the
+    continuous stream (through a DataLoader, workers prefetching across the boundary) against the per-epoch iteration."""
+    from torch.utils.data import BatchSampler, DataLoader
+    from ieee_amd.data import loader as L
+    data = _source(n_pid=13, per=(5, 5, 5, 5, 29))          # passes of 5, 4, 6 batches under a len() of 8
+    s = smp.RandomIdentitySampler(data, batch_size=12, num_instances=4)
+    batches = BatchSampler(s, 12, True)
+    random.seed(4); np.random.seed(4)
+    want = [[list(b) for b in batches] for _ in range(3)]
+    assert all(0 < len(e) < len(batches) for e in want), ([len(e) for e in want], len(batches))   # the case the advisor describes
+    assert len(set(len(e) for e in want)) > 1               # ... and the passes differ in length from epoch to epoch
+    slots = 9
+    ring = torch.zeros((slots, 3, 12, 4, 4, 3), dtype=torch.uint8).share_memory_()
+    sampler = L._SlotSampler(batches, slots, continuous=True)
+    dl = DataLoader(L._SlotDataset(_TinyBase(data), ring), batch_size=None, sampler=sampler, num_workers=workers,
+                    collate_fn=L._identity, persistent_workers=workers > 0,
+                    multiprocessing_context=L._worker_context(workers) if workers else None)
+    random.seed(4); np.random.seed(4)
+    it = iter(dl)
+    got = []
+    for epoch in range(3):
+        got.append([[int(p) for p in item['impath']] for item in L.epoch_items(it)])
+    assert got == want
+    # the non-continuous form of the same sampler: one pass per iteration, no marker
+    random.seed(4); np.random.seed(4)
+    plain = [[idx for _, idx in L._SlotSampler(batches, slots, continuous=False)] for _ in range(3)]
+    assert plain == want
+    del it, dl
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/torchreid"), reason="reference tree not present")
 def test_identity_sampler_reproduces_the_reference_sequence():
     from oracle.ref_import import import_reference

@@ -124,3 +124,35 @@ def test_prefetched_loader_yields_the_same_batches_bit_for_bit(tmp_path):
     del it
     again = [b['pid'].clone() for b in train]
     assert len(again) == len(train) and sorted(torch.cat(again).tolist()) == sorted(torch.cat([p for p, _, _ in seen[2][:len(train)]]).tolist())
+
+
+def test_continuous_loader_keeps_the_samplers_epoch_boundaries(tmp_path, monkeypatch):
+    """identities with unequal image counts: a RandomIdentitySampler pass ends BEFORE len() batches.  The prefetching loader
+    (one index stream across epochs) must end its epochs exactly there -- same number of steps per epoch and the same batches,
+    epoch by epoch, as the per-epoch iterator (IEEE_LOADER_CONTINUOUS=0)."""
+    import random
+    from PIL import Image
+    from ieee_amd import data as D
+    rng = np.random.RandomState(5)
+    counts = {3: 4, 9: 4, 20: 16, 31: 4, 40: 8, 41: 4, 57: 4}
+    names = ["%06d_cam%d_0_%02d.jpg" % (pid, 1 + k % 4, k) for pid, c in counts.items() for k in range(c)]
+    for split in ("train_171", "test"):
+        for mod in ("RGB", "NI", "TI"):
+            d = os.path.join(str(tmp_path), "RGBNT201", split, mod)
+            os.makedirs(d)
+            for nme in names:
+                Image.fromarray(rng.randint(0, 256, size=(32, 16, 3)).astype(np.uint8), "RGB").save(os.path.join(d, nme), quality=90)
+    ds = D.RGBNT201(root=str(tmp_path))
+    seen = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("IEEE_LOADER_CONTINUOUS", mode)
+        random.seed(6); np.random.seed(6); torch.manual_seed(6)
+        train, _, _ = D.build_loaders(ds, 256, 128, "random_flip", batch_size_train=8, workers=2, prefetch=2)
+        assert getattr(train, "_continuous", False) == (mode == "1")
+        seen[mode] = [[b['pid'].tolist() for b in train] for _ in range(4)]
+        upper = len(train)
+        del train
+    assert seen["0"] == seen["1"]
+    lens = [len(e) for e in seen["0"]]
+    print("batches per epoch:", lens, "len(loader):", upper)
+    assert all(0 < n <= upper for n in lens) and any(n < upper for n in lens)      # the passes really are shorter than len()

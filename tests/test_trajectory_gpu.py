@@ -211,10 +211,55 @@ def test_bf16_trajectory_at_config2_batch_64():
     assert abs(b16["mAP"] - ref["mAP"]) <= 1e-3 + abs(ctl["mAP"] - ref["mAP"]), (b16["mAP"], ref["mAP"], ctl["mAP"])
 
 
-def test_engine_raises_when_batchnorm_sums_leave_the_fixed_point_range():
+def test_engine_degrades_to_partial_sums_when_batchnorm_sums_leave_the_fixed_point_range(monkeypatch):
     """The range guard end to end: a layer1 convolution whose weights are blown up by 1e5 produces sum y^2 far beyond the 2.7e11
-    the int64 totals hold; the kernels clamp and report, and the engine raises when it reads that step's summary -- instead of
-    training on wrapped statistics (the reference's fp32 batch_norm, torchreid/models/resnet.py:164-184, has no such range)."""
+    the int64 totals hold; the kernels clamp and report, and the engine -- when it reads that step's summary -- switches the
+    executor to the per-tile partial-sum path (fp32 sums without a range: the reference's fp32 batch_norm,
+    torchreid/models/resnet.py:164-184), warns with the step index, and KEEPS TRAINING: the following steps report nothing and
+    give the loss of a model that never used the totals.  IEEE_BN_STRICT=1 raises instead."""
+    import warnings
+    from ieee_amd import _lib
+    from ieee_amd.engine import Image3MEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    from tests.util_trajectory import _DM, make_train_set
+
+    def fresh():
+        st = {k: v.clone() for k, v in tamed_state(171).items()}
+        m = build_model("ieee3modalPart", num_classes=171, loss="margin", pretrained=False, compute_dtype=torch.bfloat16)
+        m.load_state_dict(st)
+        m.train()
+        eng = Image3MEngine(_DM(171, [], {}), m, build_optimizer(m, optim="sgd", lr=0.0, weight_decay=0.0, momentum=0.0), margin=1,
+                            use_gpu=True)
+        return m, eng
+    xs, pids, cams = make_train_set(2, 4, 21, 0.5)
+    batch = {"img": xs, "pid": pids, "camid": cams, "impath": "", "timeid": pids * 0}
+    m, eng = fresh()
+    assert np.isfinite(float(eng.forward_backward(batch)["loss"]))          # a healthy step: nothing reported
+    with torch.no_grad():
+        dict(m._param_items)["backbone.1.layer1.0.conv2.weight"].mul_(1e5)
+    with pytest.warns(RuntimeWarning, match=r"left the range of the fixed-point totals.*summary read of step 2.*partial-sum path"):
+        eng.forward_backward(batch)
+    assert m.native_net(8, 256, 128).bn_overflow() == (0, 0, 0, 0)          # read and cleared by the engine
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                      # the fallback path has no range: silent from here on
+        after = [float(eng.forward_backward(batch)["loss"]) for _ in range(3)]
+    assert m.native_net(8, 256, 128).bn_overflow() == (0, 0, 0, 0)
+    # the same blown-up model on an executor that never used the totals (what IEEE_BN_TOTALS_TILES=0 selects): same numbers
+    m2, eng2 = fresh()
+    m2._bn_totals_off = True
+    with torch.no_grad():
+        dict(m2._param_items)["backbone.1.layer1.0.conv2.weight"].mul_(1e5)
+    ref = [float(eng2.forward_backward(batch)["loss"]) for _ in range(3)]
+    assert all(np.isfinite(after)) and np.allclose(after, ref, rtol=1e-6, atol=0), (after, ref)
+    # a net of another batch shape built after the report starts degraded too
+    assert m._bn_totals_off is True
+
+
+def test_engine_raises_under_bn_strict_when_batchnorm_sums_leave_the_fixed_point_range(monkeypatch):
+    """IEEE_BN_STRICT=1: the round-5 behaviour -- the engine raises when it reads the summary of a step whose BatchNorm sums
+    were clamped (eager and deferred summaries)."""
+    monkeypatch.setenv("IEEE_BN_STRICT", "1")
     from ieee_amd import _lib
     from ieee_amd.engine import Image3MEngine
     from ieee_amd.models import build_model
