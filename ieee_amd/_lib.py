@@ -67,6 +67,13 @@ class ConvExtras(ctypes.Structure):
                 ("overflow", c_void_p), ("start", c_void_p), ("stop", c_void_p)]
 
 
+class SgemmSet(ctypes.Structure):
+    """struct ieee_sgemm_set of include/ieee_amd.h (ieee_sgemm_grouped_pair_ws): one uniform problem set of a pair"""
+    _fields_ = [("groups", c_int64), ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p),
+                ("M", c_int64), ("N", c_int64), ("K", c_int64), ("sam", c_int64), ("sak", c_int64), ("sbn", c_int64),
+                ("sbk", c_int64), ("ldc", c_int64), ("alpha", c_float), ("relu", ctypes.c_int32), ("accumulate", ctypes.c_int32)]
+
+
 class IeeeAmdError(RuntimeError):
     pass
 

@@ -33,6 +33,7 @@ class NativeNet:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=model._flat_params.device)
         self.model = model
         self._eval_key = None
+        self._shadow_set = False
 
     def __del__(self):
         try:
@@ -57,7 +58,15 @@ class NativeNet:
         # torch's version counters see every in-place op on the views, `_native_epoch` counts the native writers
         key = (m._flat_params._version, m._flat_buffers._version, m._native_epoch)
         if training:
+            # the 1x1 convolutions' forward operands straight from the optimizer's bf16 shadow of the parameters (when one is kept)
+            use = getattr(m, "_shadow_enabled", False) and self.dtype == torch.bfloat16
+            sh = m.fresh_shadow() if use else None
+            if use or self._shadow_set:
+                _lib.check(self.lib.ieee_net_set_shadow(self.handle, _lib.ptr(sh)))
+                self._shadow_set = use
             m._native_epoch += 1                      # running statistics are updated by the native forward
+            if use and m._shadow_key is not None:     # (that bump is not a parameter write: the shadow stays current)
+                m._shadow_key = (m._shadow_key[0], m._native_epoch)
         elif key != self._eval_key:
             _lib.check(self.lib.ieee_net_eval_cache(self.handle, 0))
         _lib.check(self.lib.ieee_net_forward(self.handle, _lib.ptr(self.workspace), _lib.ptr(xs[0]), _lib.ptr(xs[1]),

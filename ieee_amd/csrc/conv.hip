@@ -1063,37 +1063,43 @@ static bool patch_eligible(const GatherGeom& g, int M) {
 // contiguous 256-byte run per 16 lanes: conflict-free with no swizzle and no address arithmetic in the loop.  The packed
 // weights (64 x 256 bf16 = 32 KB) never enter LDS: each wave keeps its B fragments of all 8 k-steps in registers.
 // No barrier inside the k-loop.  Same staged epilogue (BatchNorm sums / folded eval BatchNorm) as the GEMM kernel.
-template <int MODE>
+// WALK > 1 (round 6): the workgroup is persistent over WALK consecutive tiles (2 * WALK output rows of one image).  The 32 KB of
+// packed weights -- 64 KB of L2 -> register traffic per workgroup, six times the 10.7 KB patch -- are fetched ONCE instead of
+// once per two output rows, and the next tile's patch lands (second patch region) under this tile's MFMAs and staged epilogue.
+// LDS: epilogue staging 18 KB + 2 x 11 KB = 40 KB: still 4 workgroups per CU.
+constexpr int STEM_EPI_BYTES = 128 * (64 * 2 + 16), STEM_PATCH_BYTES = 11 * 1024;
+template <int MODE, int WALK = 1>
 __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const bf16* __restrict__ src, const bf16* __restrict__ w,
                                                            bf16* __restrict__ dst, float* __restrict__ bn_partial,
                                                            ConvArgs a, BwdStats bs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int tm, tn;
-  tile_map_xy(a.tiles_m, 1, a.group, tm, tn);
-  const int m0 = tm * 128;
+  int tg, tn;
+  tile_map_xy(a.tiles_m / WALK, 1, a.group, tg, tn);
   const int z = blockIdx.y;
   src += z * a.src_gs;
   w += z * a.w_gs;
   dst += z * a.dst_gs;
-  StagedStoreEpi<bf16, MODE, 0> epi{0, dst, nullptr, MODE == 1 ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
-                                    nullptr, nullptr, (MODE == 3 && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
-  if constexpr (MODE == 3) epi.relu = bs.relu;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int Hp = a.g.Hs, Wp = a.g.Ws, tiles_per_img = a.g.Ho >> 1;
-  const int img = tm / tiles_per_img, oh0 = (tm - img * tiles_per_img) * 2;
   const int rowb = Wp * 8;                                   // bytes per input row (4 bf16 channels per pixel)
   const int patch_bytes = 10 * rowb;
-  const char* pbase = (const char*)src + ((int64_t)(img * Hp + 2 * oh0) * Wp) * 8;
   const int ninstr = (patch_bytes + 1023) >> 10;
+  // WALK == 1: the patch shares the staging region (it is consumed before the epilogue stages); else two regions behind it
+  auto patch_at = [&](int rep) -> char* { return WALK == 1 ? smem : smem + STEM_EPI_BYTES + (rep & 1) * STEM_PATCH_BYTES; };
+  auto fetch_patch = [&](int tm, char* dstp) {
+    const int img = tm / tiles_per_img, oh0 = (tm - img * tiles_per_img) * 2;
+    const char* pbase = (const char*)src + ((int64_t)(img * Hp + 2 * oh0) * Wp) * 8;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int j = wave_u + 4 * k;
-    if (j < ninstr) {
-      const unsigned off = (unsigned)min(j * 1024 + lane * 16, patch_bytes - 16);   // the tail lanes re-read the last chunk
-      glds16_s(off, pbase, smem + j * 1024);
+    for (int k = 0; k < 4; ++k) {
+      const int j = wave_u + 4 * k;
+      if (j < ninstr) {
+        const unsigned off = (unsigned)min(j * 1024 + lane * 16, patch_bytes - 16);   // the tail lanes re-read the last chunk
+        glds16_s(off, pbase, dstp + j * 1024);
+      }
     }
-  }
+  };
+  fetch_patch(tg * WALK, patch_at(0));
   // B fragments of all 8 k-steps: lane (n = lane & 15, k-chunk lane >> 4) of n-fragment j
   bf16x8 fb[8][2];
 #pragma unroll
@@ -1101,25 +1107,34 @@ __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const bf16* __restric
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       fb[ks][j] = __builtin_bit_cast(bf16x8, *(const uint4*)(w + (int64_t)(wn * 32 + j * 16 + (lane & 15)) * a.ldw + ks * 32 + (lane >> 4) * 8));
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const unsigned abase = (unsigned)(2 * wm * rowb + (lane & 15) * 16 + (lane >> 4) * 16);
-  wait_vmcnt<0>();
-  __syncthreads();
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    bf16x8 fa[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(smem + abase + ks * rowb + i * 256));
+#pragma unroll 1
+  for (int rep = 0; rep < WALK; ++rep) {
+    const int tm = tg * WALK + rep;
+    StagedStoreEpi<bf16, MODE, 0> epi{0, dst, nullptr, MODE == 1 ? bn_partial + (int64_t)z * a.tiles_m * 2 * a.N : nullptr, a.N, a.M, a.N, tm, a.tiles_m,
+                                      nullptr, nullptr, (MODE == 3 && bs.stats) ? bs.stats + z * bs.stats_gs : nullptr};
+    if constexpr (MODE == 3) epi.relu = bs.relu;
+    f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fb[ks][j], fa[i], acc[i][j]);
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wait_vmcnt<0>();                      // this tile's patch has landed (and the previous tile's stores have left)
+    __syncthreads();                      // ... for every wave; the other patch region was last read a tile ago
+    if (WALK > 1 && rep + 1 < WALK) fetch_patch(tm + 1, patch_at(rep + 1));
+    const char* patch = patch_at(rep);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      bf16x8 fa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(patch + abase + ks * rowb + i * 256));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fb[ks][j], fa[i], acc[i][j]);
+    }
+    epi.template finish<128, 64, 4, 2>(acc, smem, tm * 128, 0);
   }
-  epi.template finish<128, 64, 4, 2>(acc, smem, m0, 0);
 }
 
 // the shapes the direct stem covers: 8x8 / stride 2 / no padding over 4 channels, 64 output channels, 64 output columns
@@ -2060,10 +2075,15 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   }
   if constexpr (sizeof(T) == 2) {
     if (!slow && stem_eligible(a.g, N, ldw, mode, addend)) {
-      dim3 sgrid(a.tiles_m, groups);
-      const size_t ssm = 128 * (64 * 2 + 16);      // staged epilogue (18 KB) > patch (11 KB) > BN-sum scratch
+      // IEEE_STEM_WALK (default 4, or 1): tiles per persistent workgroup -- the training forms only (mode 0 / 1)
+      static const int f_walk = getenv("IEEE_STEM_WALK") ? atoi(getenv("IEEE_STEM_WALK")) : 4;
+      const bool walk = f_walk == 4 && mode != 3 && a.tiles_m % 4 == 0 && (a.g.Ho >> 1) % 4 == 0;
+      dim3 sgrid(walk ? a.tiles_m / 4 : a.tiles_m, groups);
+      const size_t ssm = walk ? STEM_EPI_BYTES + 2 * STEM_PATCH_BYTES : STEM_EPI_BYTES;   // staged epilogue (18 KB) > patch (11 KB) > BN-sum scratch
       if (mode == 3) launch_timed(stem_conv_kernel<3>, sgrid, ssm, st, src, w, dst, (float*)nullptr, a, bs);
+      else if (mode == 1 && walk) launch_timed(stem_conv_kernel<1, 4>, sgrid, ssm, st, src, w, dst, bn_partial, a, bs);
       else if (mode == 1) launch_timed(stem_conv_kernel<1>, sgrid, ssm, st, src, w, dst, bn_partial, a, bs);
+      else if (walk) launch_timed(stem_conv_kernel<0, 4>, sgrid, ssm, st, src, w, dst, (float*)nullptr, a, bs);
       else launch_timed(stem_conv_kernel<0>, sgrid, ssm, st, src, w, dst, (float*)nullptr, a, bs);
       return launch_status("stem_conv_kernel");
     }

@@ -328,6 +328,10 @@ __global__ __launch_bounds__(256) void rank_bucket_fill_kernel(const int32_t* __
 // hist[slot], slot = 1 + cell + #{match keys < key} being monotone in the key, the removed entries are then
 // subtracted from the slots they were counted in, and the rank of match i is the inclusive prefix sum at
 // 1 + cell_i + i.  A query that does not fit writes first_out = -2 and is left to rank_query_kernel.
+// DBG (measurement only, IEEE_RANK_DBG; wrong results): 1 = the per-element LDS histogram add is replaced by a register
+// sum (what the atomics cost), 2 = the per-element cell-table read is skipped (slot = 1 + cell: what the lookups cost),
+// 3 = both.  LABNOTES R6.5 uses them to split the kernel's LDS-conflict share between the two accesses.
+template <int DBG = 0>
 __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distmat, int64_t ldd, int num_g,
                                                               const int32_t* q_pids, const int32_t* g_pids,
                                                               const int32_t* q_camids, const int32_t* g_camids,
@@ -434,6 +438,7 @@ __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distm
     if (d > dmax) return -1;
     if (d < dmin) return 0;
     const uint32_t c = rank_cell(d, dmin, scale);
+    if constexpr (DBG == 2 || DBG == 3) return (int)(1 + c);
     const uint32_t ci = cellinfo[c];
     uint32_t lo = ci & 0xffffu;
     if (ci >> 16) {
@@ -449,6 +454,7 @@ __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distm
   uint32_t below = 0;
   auto visit = [&](float d, int k) {
     const int sl = slot_of(d, k);
+    if constexpr (DBG == 1 || DBG == 3) { below += (uint32_t)sl; return; }
     if (sl > 0) atomicAdd(&hist[sl], 1u);
     else if (sl == 0) ++below;
   };
@@ -871,9 +877,12 @@ static int rank_impl(const float* distmat, int64_t ldd, int64_t num_q, int64_t n
     rank_bucket_fill_kernel<<<cdiv(num_g, 256), 256, 0, st>>>(g_pids, (int)num_g, cursor, idx);
     IEEE_TRY(launch_status("rank_bucket"));
   }
-  if (!general_only)
-    rank_query_fast_kernel<<<(int)num_q, 256, 0, st>>>(distmat, ldd, (int)num_g, q_pids, g_pids, q_camids, g_camids,
-                                                       ap, first_pos, start, idx);
+  static const int f_dbg = getenv("IEEE_RANK_DBG") ? atoi(getenv("IEEE_RANK_DBG")) : 0;    // measurement only (see the kernel)
+  if (!general_only) {
+#define IEEE_RQF(D_) rank_query_fast_kernel<D_><<<(int)num_q, 256, 0, st>>>(distmat, ldd, (int)num_g, q_pids, g_pids, q_camids, g_camids, ap, first_pos, start, idx)
+    if (f_dbg == 1) IEEE_RQF(1); else if (f_dbg == 2) IEEE_RQF(2); else if (f_dbg == 3) IEEE_RQF(3); else IEEE_RQF(0);
+#undef IEEE_RQF
+  }
   rank_query_kernel<<<(int)num_q, 256, 0, st>>>(distmat, ldd, (int)num_g, q_pids, g_pids, q_camids, g_camids, ap,
                                                 first_pos, general_only ? 0 : 1);
   rank_finalize_kernel<<<1, 256, 0, st>>>(ap, first_pos, (int)num_q, (int)max_rank, summary);

@@ -30,13 +30,12 @@ struct SgemmArgs {
 // 64x64 tile, BK = 32, fp32 MFMA 16x16x4.  Operand tiles are fetched as two 16-byte vectors per thread along
 // whichever axis is contiguous (vec_* = 1: k contiguous, 2: row contiguous, 0: scalar fallback for unaligned or
 // generic strides) and kept one k-tile ahead in registers.
-__global__ __launch_bounds__(256) void sgemm_grouped_kernel(SgemmArgs a) {
-  __shared__ float As[2][64][33];
-  __shared__ float Bs[2][64][33];
-  const int g = blockIdx.z / a.splitk, ks = blockIdx.z - g * a.splitk;
+typedef float SgemmStage[64][33];
+__device__ __forceinline__ void sgemm_tile(const SgemmArgs& a, int bx, int by, int bz, SgemmStage* As, SgemmStage* Bs) {
+  const int g = bz / a.splitk, ks = bz - g * a.splitk;
   const float* A = (const float*)a.A.p[g];
   const float* B = (const float*)a.B.p[g];
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = by * 64, n0 = bx * 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   const int kbeg = ks * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
   const int ktiles = (kend - kbeg + 31) / 32;
@@ -130,7 +129,7 @@ __global__ __launch_bounds__(256) void sgemm_grouped_kernel(SgemmArgs a) {
     __syncthreads();
   }
   if (a.splitk > 1) {
-    float* S = a.slab + (int64_t)blockIdx.z * a.M * a.N;
+    float* S = a.slab + (int64_t)bz * a.M * a.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -166,10 +165,31 @@ __global__ __launch_bounds__(256) void sgemm_grouped_kernel(SgemmArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void sgemm_splitk_reduce_kernel(SgemmArgs a) {
-  const int g = blockIdx.y;
+__global__ __launch_bounds__(256) void sgemm_grouped_kernel(SgemmArgs a) {
+  __shared__ float As[2][64][33];
+  __shared__ float Bs[2][64][33];
+  sgemm_tile(a, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// TWO uniform problem sets in ONE launch (round 6): the independent GEMM pairs of a head phase -- dW and dX of one Linear /
+// 1x1 conv, the reduce_layer applied to the global vector and to the parts -- were two launches of 8-25 us each on the
+// latency-bound head chain.  Blocks [0, blocks0) work on set 0, the rest on set 1; each set keeps its own shapes, strides,
+// pointer tables and split-K plan, so every output has the bits of the separate launch.
+struct PairDims { int gx0, gy0, blocks0, gx1, gy1; };
+__global__ __launch_bounds__(256) void sgemm_grouped2_kernel(SgemmArgs a0, SgemmArgs a1, PairDims d) {
+  __shared__ float As[2][64][33];
+  __shared__ float Bs[2][64][33];
+  int b = blockIdx.x;
+  if (b < d.blocks0) {
+    sgemm_tile(a0, b % d.gx0, (b / d.gx0) % d.gy0, b / (d.gx0 * d.gy0), As, Bs);
+  } else {
+    b -= d.blocks0;
+    sgemm_tile(a1, b % d.gx1, (b / d.gx1) % d.gy1, b / (d.gx1 * d.gy1), As, Bs);
+  }
+}
+
+__device__ __forceinline__ void sgemm_splitk_reduce_one(const SgemmArgs& a, int g, int64_t i) {
   const int64_t mn = (int64_t)a.M * a.N;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= mn) return;
   const float* S = a.slab + (int64_t)g * a.splitk * mn + i;
   float s = 0.f;
@@ -182,6 +202,20 @@ __global__ __launch_bounds__(256) void sgemm_splitk_reduce_kernel(SgemmArgs a) {
   if (a.accumulate) v += *c;
   if (a.relu) v = fmaxf(v, 0.f);
   *c = v;
+}
+__global__ __launch_bounds__(256) void sgemm_splitk_reduce_kernel(SgemmArgs a) {
+  sgemm_splitk_reduce_one(a, blockIdx.y, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// the split-K reductions of a pair (a set without split-K has rblocks = 0): blocks [0, groups0 * rb0) belong to set 0
+struct PairReduceDims { int rb0, blocks0, rb1; };
+__global__ __launch_bounds__(256) void sgemm_splitk_reduce2_kernel(SgemmArgs a0, SgemmArgs a1, PairReduceDims d) {
+  int b = blockIdx.x;
+  if (b < d.blocks0) {
+    sgemm_splitk_reduce_one(a0, b / d.rb0, (int64_t)(b % d.rb0) * blockDim.x + threadIdx.x);
+  } else {
+    b -= d.blocks0;
+    sgemm_splitk_reduce_one(a1, b / d.rb1, (int64_t)(b % d.rb1) * blockDim.x + threadIdx.x);
+  }
 }
 
 // zero up to MAXG float spans in one launch (hipMemsetAsync splits every odd-sized span into 3 kernels)
@@ -584,8 +618,11 @@ __device__ __forceinline__ void sgd_one(float& w, float g, float& buf, float lr,
 }
 // 16 bytes per lane when the three buffers allow it (20 B/param of traffic: the 4-byte form needed 4x the memory
 // instructions); per-element arithmetic is identical in both forms
+// shadow (may be NULL; round 6): the bf16 image of the UPDATED parameters, element for element (+2 B/param of writes).  A 1x1
+// convolution's forward GEMM operand Wf[co][ci] IS that image of its OIHW weight, so the executor reads it straight from
+// there and the once-per-step weight packing loses those tensors (64 % of the conv parameters: 4 B read + 2 B written each).
 __global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                    int64_t n, float lr, float momentum, float wd, int nesterov, int vec) {
+                                    int64_t n, float lr, float momentum, float wd, int nesterov, int vec, bf16* __restrict__ shadow) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
   int64_t done = 0;
   if (vec) {
@@ -600,6 +637,7 @@ __global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restri
       sgd_one(w.w, gg.w, b.w, lr, momentum, wd, nesterov);
       if (momentum != 0.f) ((float4*)buf)[i] = b;
       ((float4*)p)[i] = w;
+      if (shadow != nullptr) ((uint2*)shadow)[i] = make_uint2(Vec16<bf16>::pk(w.x, w.y), Vec16<bf16>::pk(w.z, w.w));
     }
     done = n4 << 2;
   }
@@ -608,6 +646,7 @@ __global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restri
     sgd_one(w, g[i], b, lr, momentum, wd, nesterov);
     if (momentum != 0.f) buf[i] = b;
     p[i] = w;
+    if (shadow != nullptr) shadow[i] = (bf16)w;
   }
 }
 
@@ -632,14 +671,61 @@ static bool aligned16(const void* const* tab, int groups) {
   return true;
 }
 
+static int sgemm_fill(SgemmArgs& a, int64_t groups, const void* const* A, const void* const* B, void* const* C,
+                      const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak, int64_t sbn,
+                      int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate, void* work, int64_t work_bytes);
+
 extern "C" int ieee_sgemm_grouped_ws(int64_t groups, const void* const* A, const void* const* B, void* const* C,
                                      const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak,
                                      int64_t sbn, int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate,
                                      void* work, int64_t work_bytes, void* stream) {
+  SgemmArgs a;
+  IEEE_TRY(sgemm_fill(a, groups, A, B, C, bias, M, N, K, sam, sak, sbn, sbk, ldc, alpha, relu, accumulate, work, work_bytes));
+  dim3 grid(cdiv(N, 64), cdiv(M, 64), (unsigned)(groups * a.splitk));
+  sgemm_grouped_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  IEEE_TRY(launch_status("sgemm_grouped_kernel"));
+  if (a.splitk > 1) {
+    sgemm_splitk_reduce_kernel<<<dim3(cdiv(M * N, 256), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(a);
+    return launch_status("sgemm_splitk_reduce_kernel");
+  }
+  return IEEE_OK;
+}
+
+extern "C" int ieee_sgemm_grouped_pair_ws(const ieee_sgemm_set* s0, const ieee_sgemm_set* s1, void* work, int64_t work_bytes,
+                                          void* stream) {
+  IEEE_REQUIRE(s0 && s1, "sgemm_grouped_pair: null problem set");
+  // each set plans its split-K against HALF of the workspace: a caller that doubles the workspace it gave the single calls
+  // gets exactly their plans, hence their bits
+  const int64_t half = work ? (work_bytes / 2) & ~(int64_t)255 : 0;
+  SgemmArgs a0, a1;
+  IEEE_TRY(sgemm_fill(a0, s0->groups, s0->A, s0->B, s0->C, s0->bias, s0->M, s0->N, s0->K, s0->sam, s0->sak, s0->sbn, s0->sbk, s0->ldc,
+                      s0->alpha, s0->relu, s0->accumulate, work, half));
+  IEEE_TRY(sgemm_fill(a1, s1->groups, s1->A, s1->B, s1->C, s1->bias, s1->M, s1->N, s1->K, s1->sam, s1->sak, s1->sbn, s1->sbk, s1->ldc,
+                      s1->alpha, s1->relu, s1->accumulate, work ? (char*)work + half : nullptr, half));
+  PairDims d;
+  d.gx0 = cdiv(s0->N, 64); d.gy0 = cdiv(s0->M, 64); d.blocks0 = d.gx0 * d.gy0 * (int)(s0->groups * a0.splitk);
+  d.gx1 = cdiv(s1->N, 64); d.gy1 = cdiv(s1->M, 64);
+  const int blocks1 = d.gx1 * d.gy1 * (int)(s1->groups * a1.splitk);
+  sgemm_grouped2_kernel<<<dim3((unsigned)(d.blocks0 + blocks1)), 256, 0, (hipStream_t)stream>>>(a0, a1, d);
+  IEEE_TRY(launch_status("sgemm_grouped2_kernel"));
+  if (a0.splitk > 1 || a1.splitk > 1) {
+    PairReduceDims r;
+    r.rb0 = a0.splitk > 1 ? cdiv(s0->M * s0->N, 256) : 1;
+    r.blocks0 = a0.splitk > 1 ? r.rb0 * (int)s0->groups : 0;
+    r.rb1 = a1.splitk > 1 ? cdiv(s1->M * s1->N, 256) : 1;
+    const int rblocks1 = a1.splitk > 1 ? r.rb1 * (int)s1->groups : 0;
+    sgemm_splitk_reduce2_kernel<<<dim3((unsigned)(r.blocks0 + rblocks1)), 256, 0, (hipStream_t)stream>>>(a0, a1, r);
+    return launch_status("sgemm_splitk_reduce2_kernel");
+  }
+  return IEEE_OK;
+}
+
+static int sgemm_fill(SgemmArgs& a, int64_t groups, const void* const* A, const void* const* B, void* const* C,
+                      const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak, int64_t sbn,
+                      int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate, void* work, int64_t work_bytes) {
   IEEE_REQUIRE(groups >= 1 && groups <= MAXG, "sgemm_grouped: groups %ld out of range [1,%d]", (long)groups, MAXG);
   IEEE_REQUIRE(A && B && C, "sgemm_grouped: null pointer table");
   IEEE_REQUIRE(M > 0 && N > 0 && K > 0, "sgemm_grouped: empty problem");
-  SgemmArgs a;
   fill_tab(&a.A, A, (int)groups);
   fill_tab(&a.B, B, (int)groups);
   fill_tab(&a.C, (const void* const*)C, (int)groups);
@@ -664,13 +750,6 @@ extern "C" int ieee_sgemm_grouped_ws(int64_t groups, const void* const* A, const
   a.kchunk = (int)(cdiv(cdiv(K, splitk), 32) * 32);
   a.splitk = (int)cdiv(K, a.kchunk);
   a.slab = (float*)work;
-  dim3 grid(cdiv(N, 64), cdiv(M, 64), (unsigned)(groups * a.splitk));
-  sgemm_grouped_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  IEEE_TRY(launch_status("sgemm_grouped_kernel"));
-  if (a.splitk > 1) {
-    sgemm_splitk_reduce_kernel<<<dim3(cdiv(M * N, 256), (unsigned)groups), 256, 0, (hipStream_t)stream>>>(a);
-    return launch_status("sgemm_splitk_reduce_kernel");
-  }
   return IEEE_OK;
 }
 
@@ -859,14 +938,21 @@ extern "C" int ieee_adam_step(float* params, const float* grads, float* exp_avg,
   return launch_status("adam_kernel");
 }
 
-extern "C" int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
-                                      float momentum, float weight_decay, int nesterov, void* stream) {
+extern "C" int ieee_sgd_nesterov_step_shadow(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
+                                             float momentum, float weight_decay, int nesterov, void* shadow_bf16, void* stream) {
   IEEE_REQUIRE(params && grads && (momentum == 0.f || momentum_buf), "sgd_nesterov_step: null pointer");
   if (n <= 0) return IEEE_OK;
-  const int vec = (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) & 15) == 0 ? 1 : 0;
+  // (the shadow is addressed like the parameters: element i at shadow + i; the 16-byte form needs its 8-byte stores aligned)
+  const int vec = ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) & 15) == 0 && ((uintptr_t)shadow_bf16 & 7) == 0) ? 1 : 0;
   sgd_nesterov_kernel<<<ewb(vec ? (n + 3) / 4 : n), 256, 0, (hipStream_t)stream>>>(params, grads, momentum_buf, n, lr,
-                                                                                   momentum, weight_decay, nesterov, vec);
+                                                                                   momentum, weight_decay, nesterov, vec,
+                                                                                   (bf16*)shadow_bf16);
   return launch_status("sgd_nesterov_kernel");
+}
+
+extern "C" int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
+                                      float momentum, float weight_decay, int nesterov, void* stream) {
+  return ieee_sgd_nesterov_step_shadow(params, grads, momentum_buf, n, lr, momentum, weight_decay, nesterov, nullptr, stream);
 }
 
 // ---- bf16 gradient exchange (IEEE_DP_GRAD_DTYPE=bf16: 219 MB over xGMI per step instead of 438) ---------------------

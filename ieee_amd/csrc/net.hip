@@ -56,6 +56,7 @@ struct ConvUnit {
   Tensor abits;                    // bf16 block outputs: the ReLU mask of `a` as packed bits (bn_apply writes it, the next block's conv1 dgrad reads it)
   bool want_bits = false;
   bool need_dgrad = true;
+  bool shadow_ok = false;          // 1x1, unpadded rows, 16-byte aligned slots: the forward operand can be read from the bf16 shadow
   int child = IEEE_FROZEN_BACKBONE;   // which freezable child of the model owns this unit (ieee_net_set_frozen bits)
   int64_t M(int B) const { return (int64_t)B * Ho * Wo; }
 };
@@ -149,6 +150,12 @@ struct Net {
   // caller's stream runs the stem, layer1 and layer2; pack_late = those descriptors with their own block numbering
   std::vector<PackDescHost> pack_late;
   int pack_late_first = 0, pack_late_unit = 0, pack_blocks_early = 0, pack_blocks_late = 0;
+  // The same tables WITHOUT the forward operands of the 1x1 convs (ieee_net_set_shadow): with a bf16 shadow of the parameter
+  // buffer kept current by the optimizer (ieee_sgd_nesterov_step_shadow) those GEMM operands ARE the shadow -- Wf[co][ci] is
+  // the OIHW weight itself -- and the training forward reads them there: 61.6 M of the 95.7 M conv parameters leave the pack.
+  std::vector<PackDescHost> pack_train_s, pack_late_s;
+  int pack_blocks_train_s = 0, pack_late_first_s = 0, pack_blocks_early_s = 0, pack_blocks_late_s = 0;
+  const void* shadow = nullptr;   // bf16 [numel of params], element i = bf16(params[i]); nullptr: every operand is packed
   hipEvent_t pack_ev[2] = {nullptr, nullptr};
   const void* pack_uploaded_ws = nullptr;
   bool fused_bwd_state = false;   // survives between the staged ieee_net_backward_part calls
@@ -432,14 +439,14 @@ void Net::plan() {
   dH = alloc("dH", 3 * 2 * Bq * hid, IEEE_F32);
   davgmax = alloc("davgmax", 3 * 2 * Bq * fdim, IEEE_F32);
   remwork = alloc("", 3 * Bq + 64, IEEE_F32);
-  gemm_work = alloc("", (int64_t)8 << 20, IEEE_F32);   // split-K slabs of the head GEMMs (32 MiB)
+  gemm_work = alloc("", (int64_t)16 << 20, IEEE_F32);  // split-K slabs of the head GEMMs: 2 x 32 MiB (one half per set of a pair)
   tickets = alloc("", 512, IEEE_F32);
   rtab = alloc("", (int64_t)RT_SLOTS * RT_MAX * sizeof(ieee_wgrad_reduce_desc) / 4, IEEE_F32);
   reduce_unit = ConvUnit();
   reduce_unit.name = "wgrad_reduce_batch";
   reduce_unit.Ci = reduce_unit.Co = reduce_unit.R = reduce_unit.stride = reduce_unit.pad = 0;
   reduce_unit.Hi = reduce_unit.Wi = reduce_unit.Ho = reduce_unit.Wo = 0;
-  packtab = alloc("", (int64_t)(5 * units.size() + 8) * sizeof(PackDescHost) / 4, IEEE_F32);
+  packtab = alloc("", (int64_t)(9 * units.size() + 8) * sizeof(PackDescHost) / 4, IEEE_F32);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -551,8 +558,10 @@ struct Run {
       return ieee_conv2d_fwd_bn_train(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
                                       (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, bnpart_cur, par(u.s_g), par(u.s_b),
                                       gs(u.s_g), buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), n.bn_mom, n.bn_eps, tickets_cur, st);
-    return ieee_conv2d_fwd_ex(in, P(u.wf), P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
-                              (int64_t)B * u.Hi * u.Wi * u.Ci, u.Co * ldf, u.M(B) * u.Co, fused_stats ? bnpart_cur : nullptr,
+    const bool sh = use_shadow && u.shadow_ok;     // Wf[co][ci] of a 1x1 conv = the bf16 image of its OIHW weight
+    const void* wf = sh ? (const void*)((const uint16_t*)n.shadow + n.slot_off[u.s_w]) : P(u.wf);
+    return ieee_conv2d_fwd_ex(in, wf, P(u.y), n.dtype, 3, B, u.Hi, u.Wi, u.Ci, u.Co, u.R, u.S, u.stride, u.pad,
+                              (int64_t)B * u.Hi * u.Wi * u.Ci, sh ? gs(u.s_w) : u.Co * ldf, u.M(B) * u.Co, fused_stats ? bnpart_cur : nullptr,
                               take_extras(fwd_totals ? P(u.tot_f) : nullptr, (int64_t)2 * u.Co, fwd_totals ? totals_rep(u) : 1), st);
   }
   int bn(const ConvUnit& u, const void* residual, void* out, int relu, int training, void* relu_bits = nullptr) {
@@ -897,9 +906,40 @@ struct Run {
     const void* a[3]; const void* b[3]; void* c[3]; const void* bi[3];
     for (int m = 0; m < 3; ++m) { a[m] = A + m * a_gs; b[m] = Bm + m * b_gs; c[m] = C + m * c_gs; bi[m] = bias ? bias + m * bias_gs : nullptr; }
     return ieee_sgemm_grouped_ws(3, a, b, c, bias ? bi : nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 1.0f, relu, acc,
-                                 P(n.gemm_work), (int64_t)n.gemm_work.numel * 4, st);
+                                 P(n.gemm_work), (int64_t)n.gemm_work.numel * 2, st);   // (half of gemm_work: what a pair's set gets)
+  }
+  // IEEE_HEAD_PAIRS (default 1): the independent GEMM pairs of a head phase go out as ONE launch (ieee_sgemm_grouped_pair_ws);
+  // 0: two launches.  Same bits either way (every set keeps its own split-K plan against gemm_work's first half).
+  static bool head_pairs() {
+    static const bool on = !(getenv("IEEE_HEAD_PAIRS") && atoi(getenv("IEEE_HEAD_PAIRS")) == 0);
+    return on;
+  }
+  struct Set3 {                 // a 3-modality problem set with uniform strides (gemm3's arguments)
+    const void* a[3]; const void* b[3]; void* c[3]; const void* bi[3];
+    ieee_sgemm_set s;
+  };
+  static void set3(Set3& o, const float* A, int64_t a_gs, const float* Bm, int64_t b_gs, float* C, int64_t c_gs, const float* bias,
+                   int64_t bias_gs, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk,
+                   int64_t ldc, int relu, int acc) {
+    for (int m = 0; m < 3; ++m) { o.a[m] = A + m * a_gs; o.b[m] = Bm + m * b_gs; o.c[m] = C + m * c_gs; o.bi[m] = bias ? bias + m * bias_gs : nullptr; }
+    o.s = ieee_sgemm_set{3, o.a, o.b, o.c, bias ? o.bi : nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 1.0f, relu, acc};
+  }
+  static ieee_sgemm_set setg(int64_t groups, const void* const* A, const void* const* B, void* const* C, int64_t M, int64_t N,
+                             int64_t K, int64_t sam, int64_t sak, int64_t sbn, int64_t sbk, int64_t ldc, int acc) {
+    return ieee_sgemm_set{groups, A, B, C, nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 1.0f, 0, acc};
+  }
+  // two independent problem sets: one launch, or (IEEE_HEAD_PAIRS=0) the two separate ones -- both plan against half of gemm_work
+  int gemm_pair(const ieee_sgemm_set& s0, const ieee_sgemm_set& s1) {
+    const int64_t bytes = (int64_t)n.gemm_work.numel * 4;
+    if (head_pairs()) return ieee_sgemm_grouped_pair_ws(&s0, &s1, P(n.gemm_work), bytes, st);
+    const int64_t half = (bytes / 2) & ~(int64_t)255;
+    for (const ieee_sgemm_set* s : {&s0, &s1})
+      IEEE_TRY(ieee_sgemm_grouped_ws(s->groups, s->A, s->B, s->C, s->bias, s->M, s->N, s->K, s->sam, s->sak, s->sbn, s->sbk, s->ldc,
+                                     s->alpha, s->relu, s->accumulate, P(n.gemm_work), half, st));
+    return IEEE_OK;
   }
   bool late_pack_pending = false;
+  bool use_shadow = false;     // this (training) forward reads the 1x1 forward operands from n.shadow
   int forward(const float* xr, const float* xn, const float* xt, int training, float* logits_out, float* feats_out) {
     const int rc = forward_impl(xr, xn, xt, training, logits_out, feats_out);
     if (rc != IEEE_OK && training)   // an aborted fused-finalize launch may have left arrival tickets behind
@@ -933,25 +973,39 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
     char* tab_dev = ws + N.packtab.off;
     const size_t bytes_eval = N.pack_eval.size() * sizeof(PackDescHost);
     const size_t bytes_train = N.pack_train.size() * sizeof(PackDescHost);
+    const size_t bytes_late = N.pack_late.size() * sizeof(PackDescHost);
+    const size_t bytes_train_s = N.pack_train_s.size() * sizeof(PackDescHost);
     if (N.pack_uploaded_ws != (const void*)ws) {
       IEEE_HIP(hipMemcpyAsync(tab_dev, N.pack_eval.data(), bytes_eval, hipMemcpyHostToDevice, (hipStream_t)st));
       IEEE_HIP(hipMemcpyAsync(tab_dev + bytes_eval, N.pack_train.data(), bytes_train, hipMemcpyHostToDevice, (hipStream_t)st));
-      IEEE_HIP(hipMemcpyAsync(tab_dev + bytes_eval + bytes_train, N.pack_late.data(), N.pack_late.size() * sizeof(PackDescHost),
-                              hipMemcpyHostToDevice, (hipStream_t)st));
+      IEEE_HIP(hipMemcpyAsync(tab_dev + bytes_eval + bytes_train, N.pack_late.data(), bytes_late, hipMemcpyHostToDevice, (hipStream_t)st));
+      if (bytes_train_s)
+        IEEE_HIP(hipMemcpyAsync(tab_dev + bytes_eval + bytes_train + bytes_late, N.pack_train_s.data(), bytes_train_s,
+                                hipMemcpyHostToDevice, (hipStream_t)st));
+      if (!N.pack_late_s.empty())
+        IEEE_HIP(hipMemcpyAsync(tab_dev + bytes_eval + bytes_train + bytes_late + bytes_train_s, N.pack_late_s.data(),
+                                N.pack_late_s.size() * sizeof(PackDescHost), hipMemcpyHostToDevice, (hipStream_t)st));
       N.pack_uploaded_ws = ws;
     }
+    // the 1x1 forward operands come from the optimizer's bf16 shadow: the tables without them
+    use_shadow = training && dt == IEEE_BF16 && N.shadow != nullptr;
+    const char* t_train = use_shadow ? tab_dev + bytes_eval + bytes_train + bytes_late : tab_dev + bytes_eval;
+    const char* t_late = use_shadow ? tab_dev + bytes_eval + bytes_train + bytes_late + bytes_train_s : tab_dev + bytes_eval + bytes_train;
+    const int64_t n_train = use_shadow ? (int64_t)N.pack_train_s.size() : (int64_t)N.pack_train.size();
+    const int64_t n_late = use_shadow ? (int64_t)N.pack_late_s.size() : (int64_t)N.pack_late.size();
+    const int64_t n_early = use_shadow ? N.pack_late_first_s : N.pack_late_first;
+    const int b_train = use_shadow ? N.pack_blocks_train_s : N.pack_blocks_train, b_late = use_shadow ? N.pack_blocks_late_s : N.pack_blocks_late,
+              b_early = use_shadow ? N.pack_blocks_early_s : N.pack_blocks_early;
     static const bool pack_async = !(getenv("IEEE_PACK_ASYNC") && atoi(getenv("IEEE_PACK_ASYNC")) == 0);
-    if (training && pack_async && side_enabled() && !N.pack_late.empty()) {
+    if (training && pack_async && side_enabled() && n_late > 0) {
       IEEE_HIP(hipEventRecord(N.pack_ev[0], (hipStream_t)st));   // parameters (and the tables) are final here
       IEEE_HIP(hipStreamWaitEvent(N.side, N.pack_ev[0], 0));
-      IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev + bytes_eval + bytes_train, (int64_t)N.pack_late.size(),
-                                     N.pack_blocks_late, dt, (void*)N.side));
+      IEEE_TRY(ieee_pack_all_weights(N.params, ws, t_late, n_late, b_late, dt, (void*)N.side));
       IEEE_HIP(hipEventRecord(N.pack_ev[1], N.side));
       late_pack_pending = true;
-      IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev + bytes_eval, (int64_t)N.pack_late_first, N.pack_blocks_early, dt, st));
+      if (n_early > 0) IEEE_TRY(ieee_pack_all_weights(N.params, ws, t_train, n_early, b_early, dt, st));
     } else if (training)
-      IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev + bytes_eval, (int64_t)N.pack_train.size(), N.pack_blocks_train,
-                                     dt, st));
+      IEEE_TRY(ieee_pack_all_weights(N.params, ws, t_train, n_train, b_train, dt, st));
     else if (!(eval_cached = (N.eval_cache_valid && N.eval_cache_ws == (const void*)ws && !N.profiling)))
       IEEE_TRY(ieee_pack_all_weights(N.params, ws, tab_dev, (int64_t)N.pack_eval.size(), N.pack_blocks_eval, dt, st));
     if (training) N.eval_cache_valid = false;     // the step that follows changes parameters and running statistics
@@ -1068,9 +1122,12 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
   }
   // reduce_layer applied twice: global vector first, then the 6 parts (two running-stat updates)  :449-455
   const int R = N.rdim, PB = N.parts * B;
-  IEEE_TRY(gemm3(F(N.Gp), BC, par(N.s_rw), gs(N.s_rw), F(N.Zg), (int64_t)B * R, nullptr, 0, B, R, C, C, 1, C, 1, R, 0, 0));
-  IEEE_TRY(gemm3(F(N.Pp), (int64_t)PB * C, par(N.s_rw), gs(N.s_rw), F(N.Zp), (int64_t)PB * R, nullptr, 0, PB, R, C, C, 1,
-                 C, 1, R, 0, 0));
+  {
+    Set3 g, p;
+    set3(g, F(N.Gp), BC, par(N.s_rw), gs(N.s_rw), F(N.Zg), (int64_t)B * R, nullptr, 0, B, R, C, C, 1, C, 1, R, 0, 0);
+    set3(p, F(N.Pp), (int64_t)PB * C, par(N.s_rw), gs(N.s_rw), F(N.Zp), (int64_t)PB * R, nullptr, 0, PB, R, C, C, 1, C, 1, R, 0, 0);
+    IEEE_TRY(gemm_pair(g.s, p.s));
+  }
   {
     const void *x1[3], *x2[3], *ga[3], *be[3];
     void *o1[3], *o2[3], *rm[3], *rv[3], *s1[3], *s2[3];
@@ -1309,11 +1366,8 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
         dp2[g] = F(N.dpart2) + (int64_t)m * PB * R + i * R;
       }
     // classifier: dW = dlogits^T feat, db = colsum, dfeat += dlogits W
-    IEEE_TRY(ieee_sgemm_grouped_ws(18, dl, fe, dw, nullptr, NC, D, B, 1, NC, 1, R, D, 1.0f, 0, 0, P(N.gemm_work),
-                                   (int64_t)N.gemm_work.numel * 4, st));
+    IEEE_TRY(gemm_pair(setg(18, dl, fe, dw, NC, D, B, 1, NC, 1, R, D, 0), setg(18, dl, w, dfc, B, D, NC, NC, 1, 1, D, R, 1)));
     IEEE_TRY(ieee_colsum_grouped(18, dl, db, B, NC, NC, 0, st));
-    IEEE_TRY(ieee_sgemm_grouped_ws(18, dl, w, dfc, nullptr, B, D, NC, NC, 1, 1, D, R, 1.0f, 0, 1, P(N.gemm_work),
-                                   (int64_t)N.gemm_work.numel * 4, st));
     // fc: BN1d+ReLU backward, then Linear backward
     const int fz = (N.frozen / IEEE_FROZEN_FC_R) & 7;
     if (fz == 0 || fz == 7) {
@@ -1323,13 +1377,11 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
         IEEE_TRY(ieee_rowbn_bwd(6, (const void* const*)dfc + 6 * m, fe + 6 * m, xs + 6 * m, ga + 6 * m, sv + 6 * m, dx + 6 * m,
                                 dg + 6 * m, dbe + 6 * m, B, D, R, R, D, D, (fz >> m) & 1 ? 3 : 1, 0, st));
     }
-    IEEE_TRY(ieee_sgemm_grouped_ws(18, dfr, pp, dwf, nullptr, D, R, B, 1, D, 1, (int64_t)N.parts * R, R, 1.0f, 0, 0, P(N.gemm_work),
-                                   (int64_t)N.gemm_work.numel * 4, st));
-    IEEE_TRY(ieee_colsum_grouped(18, dfr, dbf, B, D, D, 0, st));
     const void* wf[18];
     for (int g = 0; g < 18; ++g) wf[g] = par(N.s_fcw[g]);
-    IEEE_TRY(ieee_sgemm_grouped_ws(18, dfr, wf, dp2, nullptr, B, R, D, D, 1, 1, R, (int64_t)N.parts * R, 1.0f, 0, 0, P(N.gemm_work),
-                                   (int64_t)N.gemm_work.numel * 4, st));
+    IEEE_TRY(gemm_pair(setg(18, dfr, pp, dwf, D, R, B, 1, D, 1, (int64_t)N.parts * R, R, 0),
+                       setg(18, dfr, wf, dp2, B, R, D, D, 1, 1, R, (int64_t)N.parts * R, 0)));
+    IEEE_TRY(ieee_colsum_grouped(18, dfr, dbf, B, D, D, 0, st));
   }
   // REM backward
   bool have_dglob = false;
@@ -1337,15 +1389,17 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
     IEEE_TRY(ieee_rem_bwd(F(N.dpart2), F(N.rr), par(N.s_rem_param), gs(N.s_rem_param), F(N.dr), grd(N.s_rem_param),
                           gs(N.s_rem_param), F(N.remwork), B, N.parts, R, 0, st));
     // conv_part: dW = dr^T glob, db = colsum(dr), dglob = dr W
-    IEEE_TRY(gemm3(F(N.dr), (int64_t)B * R, F(N.glob), (int64_t)B * R, grd(N.s_rem_pw), gs(N.s_rem_pw), nullptr, 0, R, R, B,
-                   1, R, 1, R, R, 0, 0));
+    {
+      Set3 dw_, dx_;
+      set3(dw_, F(N.dr), (int64_t)B * R, F(N.glob), (int64_t)B * R, grd(N.s_rem_pw), gs(N.s_rem_pw), nullptr, 0, R, R, B, 1, R, 1, R, R, 0, 0);
+      set3(dx_, F(N.dr), (int64_t)B * R, par(N.s_rem_pw), gs(N.s_rem_pw), F(N.dglob), (int64_t)B * R, nullptr, 0, B, R, R, R, 1, 1, R, R, 0, 0);
+      IEEE_TRY(gemm_pair(dw_.s, dx_.s));
+    }
     {
       const void* x[3]; void* o[3];
       for (int m = 0; m < 3; ++m) { x[m] = F(N.dr) + (int64_t)m * B * R; o[m] = grd(N.s_rem_pb + m); }
       IEEE_TRY(ieee_colsum_grouped(3, x, o, B, R, R, 0, st));
     }
-    IEEE_TRY(gemm3(F(N.dr), (int64_t)B * R, par(N.s_rem_pw), gs(N.s_rem_pw), F(N.dglob), (int64_t)B * R, nullptr, 0, B, R, R,
-                   R, 1, 1, R, R, 0, 0));
     have_dglob = true;
     // conv_query receives exact zeros; conv_value receives no gradient at all
     void* zp[6];
@@ -1371,13 +1425,17 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
     if (have_dglob) IEEE_TRY(ieee_rowbn_bwd(3, d2, o2, x2, ga, s2, dx2, dg, db, B, R, R, R, R, R, rl, 1, st));
   }
   // reduce conv: dWr = dZp^T Pp (+ dZg^T Gp); dPp = dZp Wr; dGp = dZg Wr
-  IEEE_TRY(gemm3(F(N.dZp), (int64_t)PB * R, F(N.Pp), (int64_t)PB * C, grd(N.s_rw), gs(N.s_rw), nullptr, 0, R, C, PB, 1, R, 1,
-                 C, C, 0, 0));
-  IEEE_TRY(gemm3(F(N.dZp), (int64_t)PB * R, par(N.s_rw), gs(N.s_rw), F(N.dPp), (int64_t)PB * C, nullptr, 0, PB, C, R, R, 1, 1,
-                 C, C, 0, 0));
-  if (have_dglob) {
-    IEEE_TRY(gemm3(F(N.dZg), (int64_t)B * R, F(N.Gp), BC, grd(N.s_rw), gs(N.s_rw), nullptr, 0, R, C, B, 1, R, 1, C, C, 0, 1));
-    IEEE_TRY(gemm3(F(N.dZg), (int64_t)B * R, par(N.s_rw), gs(N.s_rw), F(N.dGp), BC, nullptr, 0, B, C, R, R, 1, 1, C, C, 0, 0));
+  {
+    Set3 dw_, dx_;
+    set3(dw_, F(N.dZp), (int64_t)PB * R, F(N.Pp), (int64_t)PB * C, grd(N.s_rw), gs(N.s_rw), nullptr, 0, R, C, PB, 1, R, 1, C, C, 0, 0);
+    set3(dx_, F(N.dZp), (int64_t)PB * R, par(N.s_rw), gs(N.s_rw), F(N.dPp), (int64_t)PB * C, nullptr, 0, PB, C, R, R, 1, 1, C, C, 0, 0);
+    IEEE_TRY(gemm_pair(dw_.s, dx_.s));
+  }
+  if (have_dglob) {     // (dWr accumulates onto the parts' term: this pair stays behind the one above)
+    Set3 dw_, dx_;
+    set3(dw_, F(N.dZg), (int64_t)B * R, F(N.Gp), BC, grd(N.s_rw), gs(N.s_rw), nullptr, 0, R, C, B, 1, R, 1, C, C, 0, 1);
+    set3(dx_, F(N.dZg), (int64_t)B * R, par(N.s_rw), gs(N.s_rw), F(N.dGp), BC, nullptr, 0, B, C, R, R, 1, 1, C, C, 0, 0);
+    IEEE_TRY(gemm_pair(dw_.s, dx_.s));
   } else {
     IEEE_HIP(hipMemsetAsync(P(N.dGp), 0, sizeof(float) * (size_t)3 * BC, (hipStream_t)st));
   }
@@ -1390,16 +1448,20 @@ int Run::backward_head(const float* dlogits, const float* dfeats) {
       IEEE_TRY(ieee_cim_tail_bwd_datt(F(N.dPp), P(ur.y), F(ur.stats), F(N.datt), dt, B, Hh_, Ww, C, N.parts, st));
       IEEE_TRY(ieee_sigmoid_bwd(F(N.datt), F(N.att), F(N.datt), 3 * BC, st));   // in place: datt -> dz
       // W2: dW2 = dz^T Hs ; dHs = dz W2
-      IEEE_TRY(gemm3(F(N.datt), BC, F(N.Hs), (int64_t)B * N.hid, grd(N.s_ca2), gs(N.s_ca2), nullptr, 0, C, N.hid, B, 1, C, 1,
-                     N.hid, N.hid, 0, 0));
-      IEEE_TRY(gemm3(F(N.datt), BC, par(N.s_ca2), gs(N.s_ca2), F(N.dHs), (int64_t)B * N.hid, nullptr, 0, B, N.hid, C, C, 1, 1,
-                     N.hid, N.hid, 0, 0));
+      {
+        Set3 dw_, dx_;
+        set3(dw_, F(N.datt), BC, F(N.Hs), (int64_t)B * N.hid, grd(N.s_ca2), gs(N.s_ca2), nullptr, 0, C, N.hid, B, 1, C, 1, N.hid, N.hid, 0, 0);
+        set3(dx_, F(N.datt), BC, par(N.s_ca2), gs(N.s_ca2), F(N.dHs), (int64_t)B * N.hid, nullptr, 0, B, N.hid, C, C, 1, 1, N.hid, N.hid, 0, 0);
+        IEEE_TRY(gemm_pair(dw_.s, dx_.s));
+      }
       IEEE_TRY(ieee_ca_mix_bwd(F(N.dHs), F(N.Hh), F(N.dH), B, N.hid, st));
       // W1: dW1 = dH^T avgmax ; davgmax = dH W1
-      IEEE_TRY(gemm3(F(N.dH), 2 * (int64_t)B * N.hid, F(N.avgmax), 2 * BC, grd(N.s_ca1), gs(N.s_ca1), nullptr, 0, N.hid, C,
-                     2 * B, 1, N.hid, 1, C, C, 0, 0));
-      IEEE_TRY(gemm3(F(N.dH), 2 * (int64_t)B * N.hid, par(N.s_ca1), gs(N.s_ca1), F(N.davgmax), 2 * BC, nullptr, 0, 2 * B, C,
-                     N.hid, N.hid, 1, 1, C, C, 0, 0));
+      {
+        Set3 dw_, dx_;
+        set3(dw_, F(N.dH), 2 * (int64_t)B * N.hid, F(N.avgmax), 2 * BC, grd(N.s_ca1), gs(N.s_ca1), nullptr, 0, N.hid, C, 2 * B, 1, N.hid, 1, C, C, 0, 0);
+        set3(dx_, F(N.dH), 2 * (int64_t)B * N.hid, par(N.s_ca1), gs(N.s_ca1), F(N.davgmax), 2 * BC, nullptr, 0, 2 * B, C, N.hid, N.hid, 1, 1, C, C, 0, 0);
+        IEEE_TRY(gemm_pair(dw_.s, dx_.s));
+      }
     }
     // scratch of the CIM backward: with three buffer sets it lives in the set that block 13 uses, so that block 15 (set 0,
     // which only has to hold dF) does not start by waiting for the two CIM weight gradients that read g1 / g2
@@ -1514,6 +1576,8 @@ extern "C" int ieee_net_bind(void* handle, float* params, float* grads, float* b
         const bool conv1 = mode == 0 && u.R == 1 && u.S == 1 && ld == u.Ci && u.Ci == u.Ci_src && (u.Co * ld) % vec == 0 &&
                            d.src_off % 4 == 0 && d.src_gs % 4 == 0;
         d.pad_ = tiled ? 1 : (k3 ? (mode == 0 ? 2 : 3) : (conv1 ? 4 : 0));
+        if (training && mode == 0)
+          n->units[ui].shadow_ok = conv1 && es == 2 && d.src_off % 8 == 0 && d.src_gs % 8 == 0;
         blocks += tiled ? (u.Co / 64) * (u.Ci / 64)
                         : (k3 ? (mode == 0 ? cdiv(u.Co * (u.Ci / 64), 4) : (u.Co / 32) * (u.Ci / 32))
                               : (conv1 ? cdiv(rows * ld, 256 * vec) : cdiv(rows * ld, 256)));
@@ -1543,6 +1607,33 @@ extern "C" int ieee_net_bind(void* handle, float* params, float* grads, float* b
       n->pack_late.push_back(d);
     }
     n->pack_blocks_late = n->pack_blocks_train - n->pack_blocks_early;
+  }
+  {   // the training tables without the operands the bf16 shadow provides (same early / late split, blocks renumbered)
+    n->pack_train_s.clear();
+    n->pack_late_s.clear();
+    int blocks = 0;
+    n->pack_late_first_s = -1;
+    for (size_t i = 0; i < n->pack_train.size(); ++i) {
+      const PackDescHost& src = n->pack_train[i];
+      const int nblk = (i + 1 < n->pack_train.size() ? n->pack_train[i + 1].block_begin : n->pack_blocks_train) - src.block_begin;
+      if ((int)i == n->pack_late_first) { n->pack_late_first_s = (int)n->pack_train_s.size(); n->pack_blocks_early_s = blocks; }
+      bool from_shadow = false;
+      if (src.mode == 0 && src.pad_ == 4)
+        for (const ConvUnit& u : n->units) if (n->slot_off[u.s_w] == src.src_off && u.shadow_ok) from_shadow = true;
+      if (from_shadow) continue;
+      PackDescHost d = src;
+      d.block_begin = blocks;
+      blocks += nblk;
+      n->pack_train_s.push_back(d);
+    }
+    n->pack_blocks_train_s = blocks;
+    if (n->pack_late_first_s < 0) { n->pack_late_first_s = (int)n->pack_train_s.size(); n->pack_blocks_early_s = blocks; }
+    for (size_t i = n->pack_late_first_s; i < n->pack_train_s.size(); ++i) {
+      PackDescHost d = n->pack_train_s[i];
+      d.block_begin -= n->pack_blocks_early_s;
+      n->pack_late_s.push_back(d);
+    }
+    n->pack_blocks_late_s = n->pack_blocks_train_s - n->pack_blocks_early_s;
   }
   n->pack_uploaded_ws = nullptr;
   return IEEE_OK;
@@ -1627,6 +1718,14 @@ extern "C" int ieee_net_bn_overflow(void* handle, int* out4) {
   // read AND clear in one atomic exchange per word: with deferred summaries the host runs steps ahead of the device, and
   // a kernel of a later step may set a word between a separate read and clear -- that report would be lost
   for (int i = 0; i < 4; ++i) out4[i] = n->bn_overflow != nullptr ? __atomic_exchange_n(&n->bn_overflow[i], 0, __ATOMIC_ACQ_REL) : 0;
+  return IEEE_OK;
+}
+
+extern "C" int ieee_net_set_shadow(void* handle, const void* shadow_bf16) {
+  Net* n = as_net(handle);
+  IEEE_REQUIRE(n && n->bound, "net_set_shadow: network not bound to parameters");
+  IEEE_REQUIRE(((uintptr_t)shadow_bf16 & 15) == 0, "net_set_shadow: the shadow must be 16-byte aligned");
+  n->shadow = shadow_bf16;
   return IEEE_OK;
 }
 

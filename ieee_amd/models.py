@@ -292,6 +292,35 @@ class IEEE3modalPart(nn.Module):
             self._grad_parts = parts
         return self._grad_parts
 
+    # ---- bf16 shadow of the flat parameter buffer (FusedSGD keeps it current; NativeNet hands it to the executor) ----
+    _flat_shadow = None
+    _shadow_key = None
+    _shadow_enabled = False
+
+    def shadow_buffer(self):
+        """bf16 [numel of _flat_params]: element i = bf16(_flat_params[i]) whenever `_shadow_key` equals the parameters' current
+        (torch version counter, native writer count)"""
+        if self._flat_shadow is None or self._flat_shadow.device != self._flat_params.device:
+            self._flat_shadow = torch.empty(self._flat_params.numel(), dtype=torch.bfloat16, device=self._flat_params.device)
+            self._shadow_key = None
+        return self._flat_shadow
+
+    def shadow_is_current(self):
+        """called by the optimizer when it has just written every trainable parameter together with its shadow element"""
+        if self._shadow_enabled and self._flat_shadow is not None and self._shadow_key is not None:
+            self._shadow_key = (self._flat_params._version, self._native_epoch)
+
+    def fresh_shadow(self):
+        """the shadow, brought up to date if anything but the shadow-writing optimizer has touched the parameters since (a
+        load_state_dict, a replica sync, an in-place edit: torch's version counter; another native writer: _native_epoch)"""
+        sh = self.shadow_buffer()
+        key = (self._flat_params._version, self._native_epoch)
+        if self._shadow_key != key:
+            with torch.no_grad():
+                sh.copy_(self._flat_params)          # round-to-nearest-even, as the packing kernels convert
+            self._shadow_key = key
+        return sh
+
     def native_net(self, batch, height, width):
         _lib.require_gpu()
         if self._flat_params.device.type != "cuda":

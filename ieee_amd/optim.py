@@ -17,6 +17,11 @@ class FusedSGD(torch.optim.Optimizer):
         defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, dampening=0)
         super(FusedSGD, self).__init__(list(model.parameters()), defaults)
         self._buf = None
+        # the update also writes the bf16 image of the new parameters (ieee_sgd_nesterov_step_shadow): the bf16 training forward
+        # then reads the 1x1 convolutions' GEMM operands from that shadow instead of packing them (IEEE_SGD_SHADOW=0: off)
+        import os
+        model._shadow_enabled = os.environ.get("IEEE_SGD_SHADOW", "1") != "0" and getattr(model, "compute_dtype", None) == torch.bfloat16
+        self._parts_done = set()
 
     def momentum_buffer(self):
         if self._buf is None or self._buf.device != self.model._flat_params.device:
@@ -30,22 +35,31 @@ class FusedSGD(torch.optim.Optimizer):
         buf = self.momentum_buffer()
         m._native_epoch += 1                      # parameters change behind torch's version counters
         self._opt_called = True                   # what torch's schedulers look at to order step() calls (step_part too)
+        shadow = m.shadow_buffer() if getattr(m, "_shadow_enabled", False) else None
         for a, b in runs:
-            _lib.check(lib.ieee_sgd_nesterov_step(_lib.ptr(m._flat_params[a:b]), _lib.ptr(m._flat_grads[a:b]),
-                                                  _lib.ptr(buf[a:b]), b - a, float(g['lr']), float(g['momentum']),
-                                                  float(g['weight_decay']), 1 if g['nesterov'] else 0,
-                                                  _lib.stream()))
+            _lib.check(lib.ieee_sgd_nesterov_step_shadow(_lib.ptr(m._flat_params[a:b]), _lib.ptr(m._flat_grads[a:b]),
+                                                         _lib.ptr(buf[a:b]), b - a, float(g['lr']), float(g['momentum']),
+                                                         float(g['weight_decay']), 1 if g['nesterov'] else 0,
+                                                         _lib.ptr(shadow[a:b]) if shadow is not None else None, _lib.stream()))
 
     @torch.no_grad()
     def step(self, closure=None):
         """uses the gradients the native backward left in the model's flat gradient buffer"""
         self._update(self.model.trainable_runs())
+        self.model.shadow_is_current()
 
     @torch.no_grad()
     def step_part(self, part):
         """the same update restricted to the parameters whose gradients are final after staged-backward part `part`
         (model.part_runs()); the five parts together are exactly step().  Runs on the current stream."""
-        self._update(self.model.part_runs()[part])
+        parts = self.model.part_runs()
+        self._update(parts[part])
+        if part == 0:
+            self._parts_done = set()
+        self._parts_done.add(part)
+        if len(self._parts_done) == len(parts):   # every trainable parameter (and its shadow element) has been written
+            self._parts_done = set()
+            self.model.shadow_is_current()
 
     def zero_grad(self, set_to_none=True):
         for p in self.model.parameters():
@@ -95,6 +109,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.model = model
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
         super(FusedAdam, self).__init__(list(model.parameters()), defaults)
+        model._shadow_enabled = False              # (the bf16 parameter shadow is FusedSGD's: every operand is packed here)
         self._m = self._v = self._vmax = None
         self._step = 0
 

@@ -430,6 +430,23 @@ int ieee_sgemm_grouped_ws(int64_t groups, const void* const* A, const void* cons
                           const void* const* bias, int64_t M, int64_t N, int64_t K, int64_t sam, int64_t sak,
                           int64_t sbn, int64_t sbk, int64_t ldc, float alpha, int relu, int accumulate, void* work,
                           int64_t work_bytes, void* stream);
+/* TWO uniform problem sets in ONE launch (round 6): the independent GEMM pairs of a head phase -- dW and dX of one nn.Linear /
+ * 1x1 conv (ieee3modalPart.py:54-56, 396-424, 484-511 through autograd), the reduce_layer applied to the global vector and
+ * to the six parts (:449-455) -- each set described as ieee_sgemm_grouped's arguments.  Every output has the bits of the
+ * separate ieee_sgemm_grouped_ws call made with HALF of `work_bytes` (each set plans its split-K against its half of `work`).
+ * The two sets must not write overlapping outputs. */
+typedef struct ieee_sgemm_set {
+  int64_t groups;
+  const void* const* A;
+  const void* const* B;
+  void* const* C;
+  const void* const* bias;      /* may be NULL */
+  int64_t M, N, K, sam, sak, sbn, sbk, ldc;
+  float alpha;
+  int32_t relu, accumulate;
+} ieee_sgemm_set;
+int ieee_sgemm_grouped_pair_ws(const ieee_sgemm_set* s0, const ieee_sgemm_set* s1, void* work, int64_t work_bytes,
+                               void* stream);
 /* zero `count` (<= IEEE_MAX_GROUPS) float spans in one launch */
 int ieee_zero_spans(int64_t count, void* const* ptrs, const int64_t* floats, void* stream);
 int ieee_colsum_grouped(int64_t groups, const void* const* X, void* const* out, int64_t M, int64_t N,
@@ -476,6 +493,13 @@ int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, float* dfeats
                           int64_t B, int64_t D, float margin, float grad_scale, void* stream);
 /* torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov) as configured by the reference
  * (torchreid/optim/optimizer.py:130-138) over a flat fp32 range */
+/* The same update that ALSO writes the bf16 image of the updated parameters (round-to-nearest-even, the conversion the weight
+ * packing uses) to shadow_bf16[i], i in [0, n) -- the slice of a bf16 SHADOW of the flat parameter buffer (may be NULL: plain
+ * update).  With ieee_net_set_shadow the training forward reads the GEMM operands of the 1x1 convolutions straight from that
+ * shadow (Wf[co][ci] of a 1x1 conv is its OIHW weight), so the once-per-step weight packing loses 64 % of the conv parameters;
+ * costs 2 B/param of optimizer writes.  Reference: torchreid/optim/optimizer.py:130-138 (torch.optim.SGD, nesterov). */
+int ieee_sgd_nesterov_step_shadow(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
+                                  float momentum, float weight_decay, int nesterov, void* shadow_bf16, void* stream);
 int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
                            float momentum, float weight_decay, int nesterov, void* stream);
 /* Gradient exchange in bf16 ("219 MB in bf16"; opt-in, IEEE_DP_GRAD_DTYPE=bf16): the slice of the flat
@@ -593,6 +617,11 @@ int ieee_net_bn_overflow(void* handle, int* out4);
  * +104 finalize launches per step); on = 1: fixed-point totals again where IEEE_BN_TOTALS_TILES allows.  What the engine does
  * when ieee_net_bn_overflow reports a clamped tile: degrade, warn, keep training (IEEE_BN_STRICT=1: raise instead). */
 int ieee_net_set_bn_totals(void* handle, int on);
+/* shadow_bf16: a bf16 buffer with one element per element of the bound parameter buffer, element i = bf16(params[i]), that the
+ * CALLER keeps current (ieee_sgd_nesterov_step_shadow, or a plain conversion after any other write) -- every bf16 TRAINING
+ * forward issued while it is set reads the forward operands of the 1x1 convolutions from it instead of packing them.  NULL
+ * (the default): every operand is packed from the fp32 parameters at the start of the forward.  Inference is not affected. */
+int ieee_net_set_shadow(void* handle, const void* shadow_bf16);
 /* Inference cache: after an eval-mode ieee_net_forward the workspace holds the packed weights and every BatchNorm's
  * scale / shift; the next eval forward on the same workspace reuses them (no packing launch, no finalize launches)
  * unless ieee_net_eval_cache(handle, 0) was called in between.  The CALLER must call it whenever parameters or

@@ -71,7 +71,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     import subprocess
     from ieee_amd import _lib
     fields = {"ieee_conv_extras": [f[0] for f in _lib.ConvExtras._fields_],
-              "ieee_wgrad_reduce_desc": [f[0] for f in _lib.WgradReduceDesc._fields_]}
+              "ieee_wgrad_reduce_desc": [f[0] for f in _lib.WgradReduceDesc._fields_],
+              "ieee_sgemm_set": [f[0] for f in _lib.SgemmSet._fields_]}
     lines = []
     for st, names in fields.items():
         lines.append('printf("%s %%zu", sizeof(%s));' % (st, st))
@@ -82,8 +83,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
-    mirrors = {"ieee_conv_extras": _lib.ConvExtras, "ieee_wgrad_reduce_desc": _lib.WgradReduceDesc}
-    assert len(out) == 2
+    mirrors = {"ieee_conv_extras": _lib.ConvExtras, "ieee_wgrad_reduce_desc": _lib.WgradReduceDesc, "ieee_sgemm_set": _lib.SgemmSet}
+    assert len(out) == 3
     for line in out:
         name, size, *offs = line.split()
         cls = mirrors[name]

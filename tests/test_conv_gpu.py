@@ -137,6 +137,47 @@ def test_padded_stem_equals_7x7_conv(dtype, form):
         torch.testing.assert_close(dw[i].cpu(), refs[i][2], **wtol)
 
 
+@pytest.mark.parametrize("N,H", [(2, 32), (3, 16), (3, 24), (1, 4)])
+def test_direct_stem_persistent_over_four_tiles(N, H):
+    """the direct stem kernel at the executor's width (W = 128 -> 64 output columns): bf16, 8x8 / stride 2 over the
+    border-padded 4-channel image, with the fused BatchNorm sums.  H = 32 / 16: the workgroup walks 4 tiles (8 output rows)
+    with the weights in registers and the next patch prefetched; H = 24 / 4 (6 tiles / 1 tile per image: not a multiple of 4): the
+    one-tile-per-workgroup form.  Against torch's fp32 conv on the bf16-rounded operands, and the per-tile sums against
+    the stored output."""
+    from ieee_amd import _lib as L
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(17)
+    rt = lambda t: t.to(torch.bfloat16).float()
+    G, W, Co = 3, 128, 64
+    x = rt(torch.randn(G, N, 3, H, W, generator=g))
+    w = rt(torch.randn(G, Co, 3, 7, 7, generator=g) * 0.1)
+    xs = [x[i].contiguous().cuda() for i in range(G)]
+    Hp, Wp = H + 6, W + 6
+    xp = torch.empty((G, N, Hp, Wp, 4), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.ieee_nchw_to_nhwc3(L.ptr(xs[0]), L.ptr(xs[1]), L.ptr(xs[2]), L.ptr(xp), L.IEEE_BF16, N, 3, H, W, 4, 3, L.stream()))
+    ld = lib.ieee_conv_packed_ld(L.IEEE_BF16, 4, 8, 8)
+    wp = torch.empty(G, Co, ld, device="cuda", dtype=torch.bfloat16)
+    wd = w.cuda().contiguous()
+    L.check(lib.ieee_pack_conv_weight_padded(L.ptr(wd), L.ptr(wp), L.IEEE_BF16, 0, G, Co, 3, 7, 7, 4, 8, 8, Co * 3 * 49, Co * ld, L.stream()))
+    Ho, Wo = H // 2, W // 2
+    rb = lib.ieee_conv2d_fwd_stats_rblocks(N, Ho, Wo)
+    for stats in (False, True):
+        y = torch.full((G, N, Ho, Wo, Co), 9.0, device="cuda", dtype=torch.bfloat16)
+        part = torch.zeros(G, 2, Co, rb, device="cuda")
+        L.check(lib.ieee_conv2d_fwd(L.ptr(xp), L.ptr(wp), L.ptr(y), L.IEEE_BF16, G, N, Hp, Wp, 4, Co, 8, 8, 2, 0, xp[0].numel(), Co * ld,
+                                    y[0].numel(), L.ptr(part) if stats else None, L.stream()))
+        for i in range(G):
+            ref = torch.nn.functional.conv2d(x[i], w[i], None, 2, 3).permute(0, 2, 3, 1)
+            torch.testing.assert_close(y[i].float().cpu(), ref, rtol=2e-2, atol=3e-2)
+        if stats:
+            yf = y.float().view(G, -1, Co)
+            torch.testing.assert_close(part[:, 0].sum(-1), yf.sum(1), rtol=1e-4, atol=2e-2)
+            torch.testing.assert_close(part[:, 1].sum(-1), (yf * yf).sum(1), rtol=1e-4, atol=2e-2)
+            # per tile (128 rows = 2 output rows), not only in total: a walking workgroup must file each tile's sums under its own index
+            tiles = yf.view(G, rb, 128, Co)
+            torch.testing.assert_close(part[:, 0].permute(0, 2, 1), tiles.sum(2), rtol=1e-4, atol=2e-2)
+
+
 def test_fused_bn_partials_in_conv_epilogues():
     """bf16: the forward epilogue's per-tile BN sums (sum y, sum y^2) and the dgrad epilogue's BN-backward sums
     (sum g, sum g*y with the three mask sources) against direct sums over the tensors the kernels stored"""

@@ -181,6 +181,50 @@ def test_multi_stream_step_is_bitwise_reproducible():
     assert all(l == l for l in finals[0][3])          # no NaN
 
 
+def test_optimizer_shadow_feeds_the_forward_the_bits_of_the_packed_operands():
+    """FusedSGD writes the bf16 image of the updated parameters beside them (ieee_sgd_nesterov_step_shadow) and the bf16
+    training forward reads the 1x1 convolutions' GEMM operands from that shadow instead of packing them: the conversion is
+    the packing's, so 6 steps end in BIT-IDENTICAL parameters / momentum / running statistics / losses with the shadow on
+    and off -- including a step after somebody else wrote parameters (an in-place edit, a load_state_dict: the shadow is
+    refreshed from torch's version counter) and a second forward without an optimizer step in between."""
+    from ieee_amd.engine import Image3MEngine
+    from ieee_amd.models import build_model
+    from ieee_amd.optim import build_optimizer
+    from tests.util_model import generated_state, images
+    B = 8
+    pids = torch.arange(B) // 4
+    batches = [{"img": images(B, 40 + i), "pid": pids, "camid": pids * 0, "impath": "", "timeid": pids * 0} for i in range(2)]
+    finals = []
+    for shadow in (False, True):
+        m = build_model("ieee3modalPart", num_classes=C, loss="margin", pretrained=False, compute_dtype=torch.bfloat16)
+        state = generated_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, 9)
+        m.load_state_dict(state)
+        opt = build_optimizer(m, optim="sgd", lr=1e-2, weight_decay=5e-4, momentum=0.9)
+        assert m._shadow_enabled is True            # FusedSGD + bf16 model: on by default
+        m._shadow_enabled = shadow
+        eng = Image3MEngine(FakeDM(), m, opt, margin=1, use_gpu=True)
+        m.train()
+        losses = [float(eng.forward_backward(batches[i % 2])["loss"]) for i in range(2)]
+        if shadow:
+            assert m._shadow_key == (m._flat_params._version, m._native_epoch)          # kept current by the optimizer
+            torch.cuda.synchronize()
+            assert torch.equal(m._flat_shadow, m._flat_params.to(torch.bfloat16))
+        with torch.no_grad():
+            dict(m._param_items)["backbone.0.layer3.1.conv1.weight"].mul_(1.5)          # a 1x1 conv the forward reads from the shadow
+        losses += [float(eng.forward_backward(batches[i % 2])["loss"]) for i in range(2)]
+        m.load_state_dict({k: v * 0.5 if k.endswith("layer4.0.conv3.weight") else v for k, v in m.state_dict().items()})
+        out = m([x.cuda() for x in batches[0]["img"]])                                   # a training forward without a step behind it
+        losses.append(float(sum(o.float().abs().sum() for o in out[3:])))
+        losses += [float(eng.forward_backward(batches[i % 2])["loss"]) for i in range(2)]
+        torch.cuda.synchronize()
+        finals.append((m._flat_params.clone(), m._flat_buffers.clone(), opt.momentum_buffer().clone(), losses))
+        del eng, opt, m
+    assert finals[0][3] == finals[1][3], (finals[0][3], finals[1][3])
+    for a, b in zip(finals[0][:3], finals[1][:3]):
+        assert torch.equal(a, b)
+    assert all(l == l for l in finals[0][3])
+
+
 def test_eval_cache_follows_parameter_changes():
     """consecutive eval forwards reuse the packed weights / BN scale-shift; any change of parameters or running
     statistics (torch in-place ops, load_state_dict, a train step, invalidate_eval_cache after a .data write) must

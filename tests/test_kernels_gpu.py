@@ -452,6 +452,47 @@ def test_fused_sgd_matches_torch_sgd():
 
 
 @pytest.mark.gpu
+def test_sgemm_pair_launch_has_the_bits_of_the_two_separate_launches():
+    """ieee_sgemm_grouped_pair_ws: dW and dX of a Linear (different shapes, strides, group counts, one with split-K, one
+    accumulating) as ONE launch against the two ieee_sgemm_grouped_ws calls planned against half of the workspace"""
+    from ieee_amd import _lib as L
+    lib = L.require_gpu()
+    g = torch.Generator().manual_seed(8)
+
+    def tab(ts):
+        return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    cases = []
+    # (groups, M, N, K): a long-K few-tile set (split-K) paired with a short-K many-tile one; 18-group sets; a ragged one
+    for (G0, M0, N0, K0), (G1, M1, N1, K1) in [((3, 512, 2048, 384), (3, 384, 2048, 512)), ((18, 171, 128, 64), (18, 64, 128, 171)),
+                                               ((3, 70, 130, 2084), (5, 33, 65, 31))]:
+        A0, B0 = torch.randn(G0, M0, K0, generator=g).cuda(), torch.randn(G0, N0, K0, generator=g).cuda()
+        A1, B1 = torch.randn(G1, K1, M1, generator=g).cuda(), torch.randn(G1, N1, K1, generator=g).cuda()     # A1 stored [K][M]
+        C0i, C1i = torch.randn(G0, M0, N0, generator=g).cuda(), torch.randn(G1, M1, N1, generator=g).cuda()
+        bias1 = torch.randn(G1, N1, generator=g).cuda()
+        work = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+        half = (work.numel() // 2) & ~255
+        sep0, sep1 = C0i.clone(), C1i.clone()
+        L.check(lib.ieee_sgemm_grouped_ws(G0, tab(list(A0)), tab(list(B0)), tab(list(sep0)), None, M0, N0, K0, K0, 1, K0, 1, N0, 1.0, 0, 1,
+                                          L.ptr(work), half, L.stream()))
+        L.check(lib.ieee_sgemm_grouped_ws(G1, tab(list(A1)), tab(list(B1)), tab(list(sep1)), tab(list(bias1)), M1, N1, K1, 1, M1, K1, 1, N1,
+                                          0.5, 1, 0, L.ptr(work), half, L.stream()))
+        torch.cuda.synchronize()
+        p0, p1 = C0i.clone(), C1i.clone()
+        keep = [tab(list(A0)), tab(list(B0)), tab(list(p0)), tab(list(A1)), tab(list(B1)), tab(list(p1)), tab(list(bias1))]
+        s0 = L.SgemmSet(G0, ctypes.addressof(keep[0]), ctypes.addressof(keep[1]), ctypes.addressof(keep[2]), None, M0, N0, K0, K0, 1, K0, 1,
+                        N0, 1.0, 0, 1)
+        s1 = L.SgemmSet(G1, ctypes.addressof(keep[3]), ctypes.addressof(keep[4]), ctypes.addressof(keep[5]), ctypes.addressof(keep[6]),
+                        M1, N1, K1, 1, M1, K1, 1, N1, 0.5, 1, 0)
+        L.check(lib.ieee_sgemm_grouped_pair_ws(ctypes.addressof(s0), ctypes.addressof(s1), L.ptr(work), work.numel(), L.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(p0, sep0) and torch.equal(p1, sep1)
+        ref0 = (A0.double() @ B0.double().transpose(1, 2)) + C0i.double()
+        ref1 = torch.relu(0.5 * (A1.double().transpose(1, 2) @ B1.double().transpose(1, 2)) + bias1.double()[:, None, :])
+        torch.testing.assert_close(p0.double(), ref0, rtol=1e-4, atol=5e-3)
+        torch.testing.assert_close(p1.double(), ref1, rtol=1e-4, atol=5e-3)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("layout", ["nt", "tn", "nn_strided"])
 def test_sgemm_grouped_splitk_matches_matmul(layout):
     """grouped fp32 GEMM (ieee_sgemm_grouped_ws): 16-byte operand loads along either axis, the scalar fallback,

@@ -212,17 +212,18 @@ def test_bf16_trajectory_at_config2_batch_64():
 
 
 def test_engine_degrades_to_partial_sums_when_batchnorm_sums_leave_the_fixed_point_range(monkeypatch):
-    """The range guard end to end: a layer1 convolution whose weights are blown up by 1e5 produces sum y^2 far beyond the 2.7e11
-    the int64 totals hold; the kernels clamp and report, and the engine -- when it reads that step's summary -- switches the
-    executor to the per-tile partial-sum path (fp32 sums without a range: the reference's fp32 batch_norm,
+    """The range guard end to end: a layer1 convolution whose weights are blown up until sum y^2 leaves the 2.7e11 the int64
+    totals hold.  The kernels clamp and report, and the engine -- when it reads that step's summary -- switches the executor to
+    the per-tile partial-sum path (fp32 sums without a range: the reference's fp32 batch_norm,
     torchreid/models/resnet.py:164-184), warns with the step index, and KEEPS TRAINING: the following steps report nothing and
-    give the loss of a model that never used the totals.  IEEE_BN_STRICT=1 raises instead."""
+    give the loss of a model that never used the totals.  (The clamped step itself has run on clamped statistics, as the
+    warning says; with sums a few times beyond the range its results stay finite.  IEEE_BN_STRICT=1 raises instead.)"""
     import warnings
-    from ieee_amd import _lib
     from ieee_amd.engine import Image3MEngine
     from ieee_amd.models import build_model
     from ieee_amd.optim import build_optimizer
     from tests.util_trajectory import _DM, make_train_set
+    monkeypatch.delenv("IEEE_BN_STRICT", raising=False)
 
     def fresh():
         st = {k: v.clone() for k, v in tamed_state(171).items()}
@@ -234,13 +235,28 @@ def test_engine_degrades_to_partial_sums_when_batchnorm_sums_leave_the_fixed_poi
         return m, eng
     xs, pids, cams = make_train_set(2, 4, 21, 0.5)
     batch = {"img": xs, "pid": pids, "camid": cams, "impath": "", "timeid": pids * 0}
+    name = "backbone.1.layer1.0.conv2.weight"
     m, eng = fresh()
     assert np.isfinite(float(eng.forward_backward(batch)["loss"]))          # a healthy step: nothing reported
-    with torch.no_grad():
-        dict(m._param_items)["backbone.1.layer1.0.conv2.weight"].mul_(1e5)
-    with pytest.warns(RuntimeWarning, match=r"left the range of the fixed-point totals.*summary read of step 2.*partial-sum path"):
-        eng.forward_backward(batch)
+    # blow the weight up in steps of 4x until the guard reports (the first reporting scale is 1-4x beyond the range)
+    scale, step_no = 1.0, 1
+    while True:
+        with torch.no_grad():
+            dict(m._param_items)[name].mul_(4.0)
+        scale *= 4.0
+        step_no += 1
+        assert scale < 1e8, "the range guard never reported"
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            eng.forward_backward(batch)
+        hits = [w for w in seen if issubclass(w.category, RuntimeWarning) and "left the range of the fixed-point totals" in str(w.message)]
+        if hits:
+            assert "summary read of step %d" % step_no in str(hits[0].message) and "partial-sum path" in str(hits[0].message)
+            break
+    assert m._bn_totals_off is True                                         # executors built later start degraded too
     assert m.native_net(8, 256, 128).bn_overflow() == (0, 0, 0, 0)          # read and cleared by the engine
+    torch.cuda.synchronize()
+    assert torch.isfinite(m._flat_params).all() and torch.isfinite(m._flat_buffers).all()
     with warnings.catch_warnings():
         warnings.simplefilter("error")                                      # the fallback path has no range: silent from here on
         after = [float(eng.forward_backward(batch)["loss"]) for _ in range(3)]
@@ -249,11 +265,9 @@ def test_engine_degrades_to_partial_sums_when_batchnorm_sums_leave_the_fixed_poi
     m2, eng2 = fresh()
     m2._bn_totals_off = True
     with torch.no_grad():
-        dict(m2._param_items)["backbone.1.layer1.0.conv2.weight"].mul_(1e5)
+        dict(m2._param_items)[name].mul_(scale)
     ref = [float(eng2.forward_backward(batch)["loss"]) for _ in range(3)]
-    assert all(np.isfinite(after)) and np.allclose(after, ref, rtol=1e-6, atol=0), (after, ref)
-    # a net of another batch shape built after the report starts degraded too
-    assert m._bn_totals_off is True
+    assert all(np.isfinite(after)) and np.allclose(after, ref, rtol=1e-6, atol=0), (scale, after, ref)
 
 
 def test_engine_raises_under_bn_strict_when_batchnorm_sums_leave_the_fixed_point_range(monkeypatch):
