@@ -107,11 +107,19 @@ class NativeNet:
 
     def bn_overflow(self):
         """(fwd tile clamped, bwd tile clamped, fwd total beyond half the range, bwd total beyond half the range) reported by
-        the range guard of the fixed-point BatchNorm totals since the last call (ieee_net_bn_overflow: read and clear; the
-        caller has synchronised with the steps it asks about)"""
+        the range guard of the fixed-point BatchNorm totals during the most recent training step (ieee_net_bn_overflow: a
+        blocking read of the device words, which it clears; the caller has synchronised with the step it asks about)"""
         out = (ctypes.c_int * 4)()
         _lib.check(self.lib.ieee_net_bn_overflow(self.handle, out))
         return tuple(out)
+
+    def flags_view(self):
+        """the four int32 range-guard words of this executor as a torch view of the workspace (device memory, zeroed by every
+        training forward; [0] / [1]: a forward / backward BatchNorm tile sum of the step was clamped)"""
+        if getattr(self, "_flags", None) is None:
+            off = int(self.lib.ieee_net_bn_flags_offset(self.handle))
+            self._flags = self.workspace[off:off + 16].view(torch.int32)
+        return self._flags
 
     def set_bn_totals(self, on):
         """on=False: every BatchNorm on the per-tile partial-sum path from the next forward on (ieee_net_set_bn_totals)"""

@@ -189,6 +189,17 @@ template <typename T, int MODE, int VAR = 0> struct StagedStoreEpi {
     constexpr int RPP = 256 / CPRW;                                         // rows per pass of the block
     // (t = index within a 256-thread group: the 512-thread kernel runs two such groups side by side, one per 128-row half)
     const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+#ifdef IEEE_DBG_NOEPI
+    // measurement build only (scripts/experiments/r6_noepi.sh): no epilogue at all -- the upper bound of what hiding the
+    // epilogue of a tile behind the next tile's operand fetch could give (the condition is never true; it keeps the MFMAs)
+    if (m0 < 0) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) *(f32x4*)(smem + ((i * FN + j) * 256 + t) * 16) = acc[i][j];
+    }
+    return;
+#endif
     __syncthreads();   // every wave is done reading the operand stages
 #pragma unroll
     for (int i = 0; i < FM; ++i)

@@ -467,6 +467,9 @@ __global__ __launch_bounds__(256) void rank_query_fast_kernel(const float* distm
       f32x4 d4[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) d4[u] = __builtin_nontemporal_load((const f32x4*)(row + kdone + u * 1024 + t * 4));
+      // (round 6, measured and removed: a two-pass form -- every element's cell and cell-table word first, all LDS reads in
+      // flight together, then the searches and histogram adds -- 1.36 -> 1.87 ms on random distances, 0.97 -> 1.28 with the
+      // matches nearest: 32 more live registers per thread and a second divergent pass cost more than the overlap gives)
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int k = kdone + u * 1024 + t * 4;

@@ -621,8 +621,13 @@ __device__ __forceinline__ void sgd_one(float& w, float g, float& buf, float lr,
 // shadow (may be NULL; round 6): the bf16 image of the UPDATED parameters, element for element (+2 B/param of writes).  A 1x1
 // convolution's forward GEMM operand Wf[co][ci] IS that image of its OIHW weight, so the executor reads it straight from
 // there and the once-per-step weight packing loses those tensors (64 % of the conv parameters: 4 B read + 2 B written each).
+// skip (may be NULL; round 6): the range-guard words of the executor (device memory; [0] / [1] = a forward / backward
+// BatchNorm tile sum of THIS step was clamped).  Once either is set the step's gradients are not the reference's: the update
+// is skipped -- parameters, momentum and shadow stay as they were -- like an overflow step of a loss scaler.
 __global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                    int64_t n, float lr, float momentum, float wd, int nesterov, int vec, bf16* __restrict__ shadow) {
+                                    int64_t n, float lr, float momentum, float wd, int nesterov, int vec, bf16* __restrict__ shadow,
+                                    const int* __restrict__ skip) {
+  if (skip != nullptr && (skip[0] | skip[1]) != 0) return;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
   int64_t done = 0;
   if (vec) {
@@ -938,21 +943,37 @@ extern "C" int ieee_adam_step(float* params, const float* grads, float* exp_avg,
   return launch_status("adam_kernel");
 }
 
-extern "C" int ieee_sgd_nesterov_step_shadow(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
-                                             float momentum, float weight_decay, int nesterov, void* shadow_bf16, void* stream) {
+// running statistics of a clamped forward are not the reference's either: buffers <- backup when flags[0] is set, else
+// backup <- buffers (the state the next step may have to fall back to).  One short launch per step, off the critical path.
+__global__ void guard_buffers_kernel(const int* __restrict__ flags, float* __restrict__ buffers, float* __restrict__ backup, int64_t n) {
+  const bool restore = flags[0] != 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (restore) buffers[i] = backup[i]; else backup[i] = buffers[i];
+  }
+}
+extern "C" int ieee_guard_buffers(const int* flags, float* buffers, float* backup, int64_t n, void* stream) {
+  IEEE_REQUIRE(flags && buffers && backup && n >= 0, "guard_buffers: bad arguments");
+  if (n == 0) return IEEE_OK;
+  guard_buffers_kernel<<<ewb(n), 256, 0, (hipStream_t)stream>>>(flags, buffers, backup, n);
+  return launch_status("guard_buffers_kernel");
+}
+
+extern "C" int ieee_sgd_nesterov_step_ex(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
+                                         float momentum, float weight_decay, int nesterov, void* shadow_bf16,
+                                         const int* skip_flags, void* stream) {
   IEEE_REQUIRE(params && grads && (momentum == 0.f || momentum_buf), "sgd_nesterov_step: null pointer");
   if (n <= 0) return IEEE_OK;
   // (the shadow is addressed like the parameters: element i at shadow + i; the 16-byte form needs its 8-byte stores aligned)
   const int vec = ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) & 15) == 0 && ((uintptr_t)shadow_bf16 & 7) == 0) ? 1 : 0;
   sgd_nesterov_kernel<<<ewb(vec ? (n + 3) / 4 : n), 256, 0, (hipStream_t)stream>>>(params, grads, momentum_buf, n, lr,
                                                                                    momentum, weight_decay, nesterov, vec,
-                                                                                   (bf16*)shadow_bf16);
+                                                                                   (bf16*)shadow_bf16, skip_flags);
   return launch_status("sgd_nesterov_kernel");
 }
 
 extern "C" int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
                                       float momentum, float weight_decay, int nesterov, void* stream) {
-  return ieee_sgd_nesterov_step_shadow(params, grads, momentum_buf, n, lr, momentum, weight_decay, nesterov, nullptr, stream);
+  return ieee_sgd_nesterov_step_ex(params, grads, momentum_buf, n, lr, momentum, weight_decay, nesterov, nullptr, nullptr, stream);
 }
 
 // ---- bf16 gradient exchange (IEEE_DP_GRAD_DTYPE=bf16: 219 MB over xGMI per step instead of 438) ---------------------

@@ -159,10 +159,14 @@ struct Net {
   hipEvent_t pack_ev[2] = {nullptr, nullptr};
   const void* pack_uploaded_ws = nullptr;
   bool fused_bwd_state = false;   // survives between the staged ieee_net_backward_part calls
-  // range guard of the fixed-point totals (conv.hip: tl_totals_flag): 4 ints in HOST memory the device can write (plain stores
-  // on the overflow path only).  The kernels of a step set them, ieee_net_bn_overflow reads and clears them on the host after
-  // the caller has synchronised with the step -- no launch, no copy, nothing on the queues.
-  int* bn_overflow = nullptr;
+  // range guard of the fixed-point totals (conv.hip: tl_totals_flag): 4 ints at the head of the totals region -- DEVICE memory,
+  // zeroed with the totals by every training forward, set by plain stores on the overflow path only ([0] / [1]: a forward /
+  // backward tile sum was clamped, [2] / [3]: a total beyond half the range).  Round 6: they were host-mapped words the host
+  // polled; on the device the SAME step can act on them -- the BatchNorm passes leave the running statistics alone and the
+  // optimizer (ieee_sgd_nesterov_step_ex, skip_flags) leaves parameters and momentum alone once [0] or [1] is set, so a
+  // clamped step is SKIPPED instead of applied -- and the engine reads them with the step's summary (one 16-byte copy).
+  Tensor oflags;
+  const void* last_ws = nullptr;  // workspace of the most recent forward (ieee_net_bn_overflow reads the flags there)
   bool totals_off = false;        // ieee_net_set_bn_totals(0): every unit on the per-tile partial-sum path (no range limit)
   bool bwd_totals_fresh = false;  // the backward totals are zero (set by the training forward, cleared by the backward that uses them)
   bool bwd_totals_state = false;  // ... and: those sums went into the unit's fixed-point totals (tot_b), not into bn_partial
@@ -200,7 +204,6 @@ struct Net {
     if (side) (void)hipStreamDestroy(side);
     for (hipEvent_t e : branch_ev) if (e) (void)hipEventDestroy(e);
     if (side2) (void)hipStreamDestroy(side2);
-    if (bn_overflow) (void)hipHostFree(bn_overflow);
   }
   Tensor Gp, avgmax, amax, Hh, Hs, att, Pp, Zg, Zp, glob, part, sv_g, sv_p, rr, part2, fcraw, sv_fc, featcat, fcall,
       logits, featn, norms;
@@ -376,6 +379,7 @@ void Net::plan() {
     max_c = std::max(max_c, (int64_t)u.Co);
   }
   tot_begin = ws_bytes;
+  oflags = alloc("", 64, IEEE_F32);      // 4 ints (+ padding to the allocation granule), first thing in the region
   for (size_t i = 0; i < units.size(); ++i) {
     ConvUnit& u = units[i];
     // (a run at a smaller batch than the planned one has fewer tiles: it asks for the same number of copies or for one)
@@ -483,10 +487,11 @@ struct Run {
     }
     return IEEE_OK;
   }
+  int* oflags_ptr() const { return (int*)(ws + n.oflags.off); }
   // options of the NEXT ieee_conv2d_fwd_ex / _dgrad_ex call (explicit-argument ABI: nothing is armed inside the library)
   ieee_conv_extras ex_ = {};
   const ieee_conv_extras* take_extras(void* totals, int64_t group_stride, int replicas) {
-    ex_.totals = totals; ex_.group_stride = group_stride; ex_.replicas = replicas; ex_.overflow = totals ? n.bn_overflow : nullptr;
+    ex_.totals = totals; ex_.group_stride = group_stride; ex_.replicas = replicas; ex_.overflow = totals ? oflags_ptr() : nullptr;
     ex_.reserved_ = 0;
     return &ex_;
   }
@@ -570,7 +575,7 @@ struct Run {
       fwd_totals = fused_stats = fused_fin = false;
       return ieee_bn2d_fwd_totals(P(u.y), residual, out, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), par(u.s_b), gs(u.s_g),
                                   buf(u.s_rm), buf(u.s_rv), gs(u.s_rm), F(u.stats), P(u.tot_f), totals_rep(u), n.bn_mom, n.bn_eps, relu, relu_bits,
-                                  n.bn_overflow, st);
+                                  oflags_ptr(), st);
     }
     fwd_totals = false;
     const int64_t rb = (training && fused_fin) ? -1 : ((training && fused_stats) ? ieee_conv2d_fwd_stats_rblocks(B, u.Ho, u.Wo) : 0);
@@ -640,11 +645,11 @@ struct Run {
       ds_totals_ready = ds;
       return ieee_bn2d_bwd_totals_ds(dout, P(u.y), P(ds->y), dy, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g), F(u.stats),
                                      grd(u.s_g), grd(u.s_b), gs(u.s_g), P(u.tot_b), totals_rep(u), P(ds->tot_b), totals_rep(*ds),
-                                     n.bn_overflow, (void*)bn_done, st);
+                                     oflags_ptr(), (void*)bn_done, st);
     }
     if (from_totals)   // the dgrad that produced `dout` added sum g, sum g*y to u.tot_b: finalize + apply in one launch
       return ieee_bn2d_bwd_totals(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
-                                  F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), P(u.tot_b), totals_rep(u), mask_from_y, n.bn_overflow,
+                                  F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), P(u.tot_b), totals_rep(u), mask_from_y, oflags_ptr(),
                                   (void*)bn_done, st);
     return ieee_bn2d_bwd_ev(dout, mask, P(u.y), dy, gout, n.dtype, 3, u.M(B), u.Co, u.M(B) * u.Co, par(u.s_g), gs(u.s_g),
                             F(u.stats), grd(u.s_g), grd(u.s_b), gs(u.s_g), partial, bncoef_cur, 0, mask_from_y, rb,
@@ -1015,11 +1020,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
     if (training && f_fin) IEEE_HIP(hipMemsetAsync(P(N.tickets), 0, 512 * 4, (hipStream_t)st));
   }
   if (training && dt == IEEE_BF16 && (totals_tiles() > 0 || wgrad_fold())) {   // the units' fixed-point BatchNorm totals (forward AND backward) and the fold tickets start at zero
-    if (N.bn_overflow == nullptr) {
-      IEEE_HIP(hipHostMalloc((void**)&N.bn_overflow, 4 * sizeof(int), hipHostMallocMapped));
-      for (int i = 0; i < 4; ++i) N.bn_overflow[i] = 0;
-    }
-    IEEE_HIP(hipMemsetAsync(ws + N.tot_begin, 0, N.tot_end - N.tot_begin, (hipStream_t)st));
+    IEEE_HIP(hipMemsetAsync(ws + N.tot_begin, 0, N.tot_end - N.tot_begin, (hipStream_t)st));   // (the range-guard flags included)
     N.bwd_totals_fresh = true;
   }
   IEEE_TRY(ieee_nchw_to_nhwc3(xr, xn, xt, P(N.x0), dt, B, 3, N.H, N.W, 4, 3, st));
@@ -1166,7 +1167,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
         o[g] = training ? (void*)(F(N.featcat) + (int64_t)m * B * R + i * D) : (void*)(F(N.fcall) + eval_off[m] + i * D);
       }
     IEEE_TRY(ieee_sgemm_grouped_ws(18, a, w, c, bi, B, D, R, (int64_t)N.parts * R, 1, R, 1, D, 1.0f, 0, 0, P(N.gemm_work),
-                                   (int64_t)N.gemm_work.numel * 4, st));
+                                   (int64_t)N.gemm_work.numel * 2, st));
     const int fz = (N.frozen / IEEE_FROZEN_FC_R) & 7;      // per-modality frozen bits of the fc heads
     if (!training || fz == 0 || fz == 7) {
       IEEE_TRY(ieee_rowbn_fwd(18, xs, o, ga, be, rm, rv, sv, B, D, D, training ? R : 3 * R, N.bn_mom, N.bn_eps,
@@ -1194,7 +1195,7 @@ int Run::forward_impl(const float* xr, const float* xn, const float* xt, int tra
         c[g] = logits_out + (int64_t)g * B * NC;
       }
     IEEE_TRY(ieee_sgemm_grouped_ws(18, a, w, c, bi, B, NC, D, R, 1, D, 1, NC, 1.0f, 0, 0, P(N.gemm_work),
-                                   (int64_t)N.gemm_work.numel * 4, st));
+                                   (int64_t)N.gemm_work.numel * 2, st));
   }
   // F.normalize per modality   :519
   IEEE_TRY(ieee_l2norm_fwd(F(N.featcat), F(N.featn), F(N.norms), 3 * (int64_t)B, R, st));
@@ -1219,7 +1220,11 @@ int Run::backward_impl(const float* dlogits, const float* dfeats, int part) {
     // a SECOND backward over the same forward (e.g. two loss terms differentiated one after the other) must not add to
     // the first one's totals: zero them again (the forward's totals were consumed by its BatchNorm passes)
     if (dt == IEEE_BF16 && (totals_tiles() > 0 || wgrad_fold())) {
-      if (!N.bwd_totals_fresh) IEEE_HIP(hipMemsetAsync(ws + N.tot_begin, 0, N.tot_end - N.tot_begin, (hipStream_t)st));
+      // (not the range-guard flags at the head of the region: what the forward reported stays reported)
+      if (!N.bwd_totals_fresh) {
+        const size_t skip = (size_t)N.oflags.numel * 4;
+        IEEE_HIP(hipMemsetAsync(ws + N.tot_begin + skip, 0, N.tot_end - N.tot_begin - skip, (hipStream_t)st));
+      }
       N.bwd_totals_fresh = false;
     }
     IEEE_TRY(backward_head(dlogits, dfeats));
@@ -1646,6 +1651,7 @@ extern "C" int ieee_net_forward(void* handle, void* workspace, const float* x_rg
   IEEE_REQUIRE(workspace && x_rgb && x_ni && x_ti && feats, "net_forward: null pointer");
   IEEE_REQUIRE(!training || logits, "net_forward: training needs the logits output");
   Run r(*n, workspace, stream);
+  n->last_ws = workspace;
   return r.forward(x_rgb, x_ni, x_ti, training, logits, feats);
 }
 
@@ -1715,10 +1721,20 @@ extern "C" int ieee_net_set_frozen(void* handle, int mask) {
 extern "C" int ieee_net_bn_overflow(void* handle, int* out4) {
   Net* n = as_net(handle);
   IEEE_REQUIRE(n && out4, "net_bn_overflow: null pointer");
-  // read AND clear in one atomic exchange per word: with deferred summaries the host runs steps ahead of the device, and
-  // a kernel of a later step may set a word between a separate read and clear -- that report would be lost
-  for (int i = 0; i < 4; ++i) out4[i] = n->bn_overflow != nullptr ? __atomic_exchange_n(&n->bn_overflow[i], 0, __ATOMIC_ACQ_REL) : 0;
+  // the flags of the most recent training forward / backward, read from the device (a blocking 16-byte copy: the caller has
+  // synchronised with the step it asks about) and cleared.  The engine does not call this per step: it reads the same words
+  // with the step's summary (ieee_net_bn_flags_offset).
+  for (int i = 0; i < 4; ++i) out4[i] = 0;
+  if (n->last_ws == nullptr) return IEEE_OK;
+  char* p = (char*)n->last_ws + n->oflags.off;
+  IEEE_HIP(hipMemcpy(out4, p, 4 * sizeof(int), hipMemcpyDeviceToHost));
+  IEEE_HIP(hipMemset(p, 0, 4 * sizeof(int)));
   return IEEE_OK;
+}
+
+extern "C" int64_t ieee_net_bn_flags_offset(void* handle) {
+  Net* n = as_net(handle);
+  return n ? (int64_t)n->oflags.off : -1;
 }
 
 extern "C" int ieee_net_set_shadow(void* handle, const void* shadow_bf16) {

@@ -418,6 +418,23 @@ class _FusedStepMixin(object):
         net = self._step_net = m.native_net(B, H, W)
         pids = pids.to(device=dev, dtype=torch.int64).contiguous()
         m._bump_counters()
+        # Range guard of the bf16 BatchNorm totals, acted on ON THE DEVICE (single GPU, FusedSGD): a step whose sums were clamped
+        # is skipped -- the optimizer launches take the executor's flag words as `skip_flags`, and the running statistics the
+        # forward wrote are put back from a copy (ieee_guard_buffers) -- so that the engine, when it reads the report with the
+        # step's summary, can switch to the partial-sum path and go on from an undamaged state (_check_bn_range).
+        staged = ddp.world_size() > 1 or (os.environ.get("IEEE_FORCE_DP_PATH") == "1" and torch.distributed.is_initialized())
+        guard = (not staged) and isinstance(self.optimizer, FusedSGD) and net.dtype == torch.bfloat16
+        self._step_guarded = guard
+        flags = net.flags_view() if net.dtype == torch.bfloat16 else None
+        self._step_flags = flags
+        if isinstance(self.optimizer, FusedSGD):
+            self.optimizer.skip_flags = flags if guard else None
+        if guard:
+            bk = getattr(self, "_buf_backup", None)
+            if bk is None or bk.shape != m._flat_buffers.shape or bk.device != m._flat_buffers.device or \
+                    self._buf_backup_key != (m._flat_buffers._version, id(m)):
+                bk = self._buf_backup = m._flat_buffers.detach().clone()      # (again after a load_state_dict / a replica sync)
+                self._buf_backup_key = (m._flat_buffers._version, id(m))
         logits, feats = net.forward(imgs, training=True)
         C = logits.shape[2]
         if not hasattr(self, "_scratch") or self._scratch[0].shape != logits.shape:
@@ -438,7 +455,10 @@ class _FusedStepMixin(object):
         else:
             df.zero_()
             out3.zero_()
-        staged = ddp.world_size() > 1 or (os.environ.get("IEEE_FORCE_DP_PATH") == "1" and torch.distributed.is_initialized())
+        def guard_buffers():     # running statistics: back to the copy when the forward clamped, else the copy follows them
+            if guard:
+                _lib.check(lib.ieee_guard_buffers(_lib.ptr(flags), _lib.ptr(m._flat_buffers), _lib.ptr(self._buf_backup),
+                                                  m._flat_buffers.numel(), _lib.stream()))
         if not staged and isinstance(self.optimizer, FusedSGD) and os.environ.get("IEEE_OPT_OVERLAP", "1") != "0":
             # single GPU: parts 0-3 (head, layer4, layer3, layer2 = 90 % of the parameters) are updated on a helper
             # stream while the compute stream still runs the backward of layer1 + stem and the side stream drains the
@@ -453,6 +473,7 @@ class _FusedStepMixin(object):
             net.side_wait(helper)
             net.backward_part_async(dl, df, 4)
             with torch.cuda.stream(helper):
+                guard_buffers()                  # (the forward's flags are final; off the critical path)
                 for part in range(4):
                     self.optimizer.step_part(part)
             net.side_wait()
@@ -514,6 +535,7 @@ class _FusedStepMixin(object):
             main.wait_stream(comm)
             if by_part:
                 return small, out3
+        guard_buffers()
         self.optimizer.step()
         return small, out3
 
@@ -567,16 +589,24 @@ class _FusedStepMixin(object):
             slot[1].resolve()
         host = slot[0]
         host.copy_(small, non_blocking=True)
+        flags, hostf = getattr(self, "_step_flags", None), None
+        if flags is not None:                # the step's range-guard words ride along (16 bytes, same stream, same event)
+            if len(slot) < 3:
+                slot.append(torch.zeros(4, dtype=torch.int32, pin_memory=True))
+            hostf = slot[2]
+            hostf.copy_(flags, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(small.device))
 
         net = getattr(self, "_step_net", None)
         step_idx = self._steps_done = getattr(self, "_steps_done", 0) + 1      # 1-based index of this engine's train steps
+        guarded = getattr(self, "_step_guarded", False)
 
         def read():
             done.synchronize()
             slot[1] = None
-            self._check_bn_range(net, step_idx)
+            if hostf is not None:
+                self._check_bn_range(net, step_idx, tuple(int(v) for v in hostf.tolist()), guarded)
             v = host.numpy().copy()
             hl, ha = v[:18], v[18:36]
             lR, lN, lT = float(hl[0:6].sum()), float(hl[6:12].sum()), float(hl[12:18].sum())
@@ -588,46 +618,51 @@ class _FusedStepMixin(object):
         slot[1] = DeferredSummary(keys, read)
         return slot[1]
 
-    def _check_bn_range(self, net, step=None):
+    def _check_bn_range(self, net, step, flags, guarded):
         """The bf16 train step keeps its BatchNorm sums as int64 fixed-point totals (include/ieee_amd.h,
         ieee_conv_next_bn_totals): bit-reproducible, but with a RANGE (forward sum y^2 up to 2.7e11 per channel, backward sums up
         to 4.2e6) that torch's fp32 batch_norm (reference: torchreid/models/resnet.py:164-184) does not have.  The kernels
-        clamp and report instead of wrapping; this is where the report reaches the caller -- at the step's (possibly deferred)
-        summary read, on the host, without a launch or a copy.  A clamped tile means the statistics of that step (and of the
-        steps already queued behind it) were not fp32 BatchNorm's: DEGRADE, then warn -- the executor is switched to the
-        per-tile partial-sum path (fp32 sums, no range: the reference's semantics at any magnitude, ieee_net_set_bn_totals) for
-        every step from here on and training continues; IEEE_BN_STRICT=1 raises instead.  A total beyond half the range is
-        still exact: warn once."""
+        clamp and report instead of wrapping; `flags` are the step's four report words, copied with its summary.
+        A clamped tile means the statistics of that step were not fp32 BatchNorm's.  `guarded` (single GPU, FusedSGD): the step
+        has been SKIPPED on the device -- the optimizer launches saw the words and left parameters, momentum and shadow alone,
+        the running statistics were put back -- so the engine DEGRADES and goes on: the executor is switched to the per-tile
+        partial-sum path (fp32 sums, no range: the reference's semantics at any magnitude, ieee_net_set_bn_totals) for every
+        following step, with one RuntimeWarning that names the step.  Not guarded (data parallel: a rank-local skip would split
+        the replicas; another optimizer), or IEEE_BN_STRICT=1: raise, as round 5 did.  A total beyond half the range is still
+        exact: warn once."""
         if net is None:
             return
-        f_clamp, b_clamp, f_half, b_half = net.bn_overflow()
+        f_clamp, b_clamp, f_half, b_half = flags
         if f_clamp or b_clamp:
             which = " and ".join(w for w, on in (("forward (sum y, sum y^2 of a conv output)", f_clamp),
                                                  ("backward (sum g, sum g*y)", b_clamp)) if on)
-            msg = ("BatchNorm statistics left the range of the fixed-point totals in the %s pass of a recent step (or were NaN): "
+            msg = ("BatchNorm statistics left the range of the fixed-point totals in the %s pass of step %s (or were NaN): "
                    "the int64 totals hold sum y^2 up to 2.7e11 and backward sums up to 4.2e6 per channel; beyond that a tile sum is "
-                   "clamped, so the statistics -- and the parameters updated from them -- are not what fp32 BatchNorm gives. "
-                   "Activations / gradients of that size usually mean the run is diverging." % which)
+                   "clamped, so the statistics -- and everything computed from them -- are not what fp32 BatchNorm gives. "
+                   "Activations / gradients of that size usually mean the run is diverging." % (which, "?" if step is None else step))
             import os
-            if os.environ.get("IEEE_BN_STRICT", "0") == "1":
-                raise _lib.IeeeAmdError(msg + "  (IEEE_BN_STRICT=1: raising; IEEE_BN_TOTALS_TILES=0 selects the per-tile "
-                                              "partial-sum path, which has no range limit, from the start.)")
-            import warnings
+            if os.environ.get("IEEE_BN_STRICT", "0") == "1" or not guarded:
+                raise _lib.IeeeAmdError(msg + ("  (IEEE_BN_STRICT=1: raising.)" if guarded else "  The update of that step HAS BEEN APPLIED (no "
+                                               "device-side skip in this configuration): restart from the last checkpoint.") +
+                                        "  IEEE_BN_TOTALS_TILES=0 selects the per-tile partial-sum path, which has no range limit, "
+                                        "from the start.")
             net.set_bn_totals(False)
             self.model._bn_totals_off = True               # executors built later (another batch shape) start degraded too
-            warnings.warn("ieee_amd: %s  Detected at the summary read of step %s (the steps queued since -- at most %d -- used the "
-                          "clamped statistics too).  Switched to the per-tile partial-sum path (fp32 sums, no range limit; about "
-                          "0.2 ms per step slower) for every following step; restart from the last checkpoint with "
-                          "IEEE_BN_TOTALS_TILES=0 if those steps matter, or set IEEE_BN_STRICT=1 to raise here instead."
-                          % (msg, "?" if step is None else step, self._RING - 1), RuntimeWarning)
+            if not getattr(self, "_bn_degraded", False):
+                import warnings
+                self._bn_degraded = True
+                warnings.warn("ieee_amd: %s  That step was SKIPPED (parameters, momentum and running statistics are those before it), "
+                              "and so are the steps already queued behind it that clamp as well (at most %d).  Switched to the "
+                              "per-tile partial-sum path (fp32 sums, no range limit; about 0.2 ms per step slower) for every "
+                              "following step; IEEE_BN_STRICT=1 raises here instead." % (msg, self._RING - 1), RuntimeWarning)
             return
         if (f_half or b_half) and not getattr(self, "_bn_range_warned", False):
             import warnings
             self._bn_range_warned = True
             warnings.warn("ieee_amd: a BatchNorm total of the bf16 train step is beyond half the range of its int64 fixed point "
-                          "(%s); the statistics are still exact, but a further doubling of the %s would be clamped and reported as "
-                          "an error (IEEE_BN_TOTALS_TILES=0 selects the unlimited partial-sum path)"
-                          % ("forward" if f_half else "backward", "activations" if f_half else "gradients"))
+                          "(%s); the statistics are still exact, but a further doubling of the %s would be clamped (that step would "
+                          "be skipped and the engine would fall back to the partial-sum path; IEEE_BN_TOTALS_TILES=0 selects it from "
+                          "the start)" % ("forward" if f_half else "backward", "activations" if f_half else "gradients"))
 
     def _generic_allreduce(self, params):
         """autograd path under data parallelism: sum the parameter gradients across ranks (one collective per tensor;

@@ -36,11 +36,15 @@ class FusedSGD(torch.optim.Optimizer):
         m._native_epoch += 1                      # parameters change behind torch's version counters
         self._opt_called = True                   # what torch's schedulers look at to order step() calls (step_part too)
         shadow = m.shadow_buffer() if getattr(m, "_shadow_enabled", False) else None
+        # skip_flags (set by the engine for the duration of a fused step): the executor's range-guard words -- a step whose
+        # BatchNorm sums were clamped leaves parameters, momentum and shadow untouched (include/ieee_amd.h)
+        skip = getattr(self, "skip_flags", None)
         for a, b in runs:
-            _lib.check(lib.ieee_sgd_nesterov_step_shadow(_lib.ptr(m._flat_params[a:b]), _lib.ptr(m._flat_grads[a:b]),
-                                                         _lib.ptr(buf[a:b]), b - a, float(g['lr']), float(g['momentum']),
-                                                         float(g['weight_decay']), 1 if g['nesterov'] else 0,
-                                                         _lib.ptr(shadow[a:b]) if shadow is not None else None, _lib.stream()))
+            _lib.check(lib.ieee_sgd_nesterov_step_ex(_lib.ptr(m._flat_params[a:b]), _lib.ptr(m._flat_grads[a:b]),
+                                                     _lib.ptr(buf[a:b]), b - a, float(g['lr']), float(g['momentum']),
+                                                     float(g['weight_decay']), 1 if g['nesterov'] else 0,
+                                                     _lib.ptr(shadow[a:b]) if shadow is not None else None,
+                                                     _lib.ptr(skip) if skip is not None else None, _lib.stream()))
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -493,13 +493,20 @@ int ieee_margin3m_fwd_bwd(const float* feats, const int64_t* pids, float* dfeats
                           int64_t B, int64_t D, float margin, float grad_scale, void* stream);
 /* torch.optim.SGD(momentum, weight_decay, dampening=0, nesterov) as configured by the reference
  * (torchreid/optim/optimizer.py:130-138) over a flat fp32 range */
-/* The same update that ALSO writes the bf16 image of the updated parameters (round-to-nearest-even, the conversion the weight
- * packing uses) to shadow_bf16[i], i in [0, n) -- the slice of a bf16 SHADOW of the flat parameter buffer (may be NULL: plain
- * update).  With ieee_net_set_shadow the training forward reads the GEMM operands of the 1x1 convolutions straight from that
- * shadow (Wf[co][ci] of a 1x1 conv is its OIHW weight), so the once-per-step weight packing loses 64 % of the conv parameters;
- * costs 2 B/param of optimizer writes.  Reference: torchreid/optim/optimizer.py:130-138 (torch.optim.SGD, nesterov). */
-int ieee_sgd_nesterov_step_shadow(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
-                                  float momentum, float weight_decay, int nesterov, void* shadow_bf16, void* stream);
+/* The same update with two options (either may be NULL; round 6).  Reference: torchreid/optim/optimizer.py:130-138.
+ *  shadow_bf16: ALSO write the bf16 image of the updated parameters (round-to-nearest-even, the conversion the weight packing
+ *    uses) to shadow_bf16[i], i in [0, n) -- the slice of a bf16 SHADOW of the flat parameter buffer.  With ieee_net_set_shadow
+ *    the training forward reads the GEMM operands of the 1x1 convolutions straight from that shadow (Wf[co][ci] of a 1x1 conv
+ *    is its OIHW weight), so the once-per-step weight packing loses 64 % of the conv parameters; 2 B/param of optimizer writes.
+ *  skip_flags: the executor's range-guard words (device memory, ieee_net_bn_flags_offset).  When [0] or [1] is set -- a
+ *    BatchNorm tile sum of THIS step left the fixed-point range, so its gradients are not the reference's -- the launch
+ *    changes nothing: parameters, momentum and shadow stay as they were (the step is skipped, like an overflow step of a loss
+ *    scaler) and training can go on from an undamaged state once the engine has switched to the partial-sum path. */
+int ieee_sgd_nesterov_step_ex(float* params, const float* grads, float* momentum_buf, int64_t n, float lr, float momentum,
+                              float weight_decay, int nesterov, void* shadow_bf16, const int* skip_flags, void* stream);
+/* running statistics under the same guard: flags[0] set (a forward tile sum of this step was clamped) -> buffers[i] =
+ * backup[i], the values before the step; else backup[i] = buffers[i].  One launch per step behind the forward. */
+int ieee_guard_buffers(const int* flags, float* buffers, float* backup, int64_t n, void* stream);
 int ieee_sgd_nesterov_step(float* params, const float* grads, float* momentum_buf, int64_t n, float lr,
                            float momentum, float weight_decay, int nesterov, void* stream);
 /* Gradient exchange in bf16 ("219 MB in bf16"; opt-in, IEEE_DP_GRAD_DTYPE=bf16): the slice of the flat
@@ -605,20 +612,24 @@ int ieee_net_sync_streams(void* handle, void* stream);
 #define IEEE_FROZEN_FC_T 64
 int ieee_net_set_frozen(void* handle, int mask);
 /* Range guard of the fixed-point BatchNorm totals (bf16 training; see ieee_conv_next_bn_totals): out4 receives, and the call
- * CLEARS, the four report words the kernels of the steps since the last call have set -- [0] a forward tile sum was clamped
+ * CLEARS, the four report words the kernels of the MOST RECENT training step have set -- [0] a forward tile sum was clamped
  * to its share of the int64 range (or was NaN), [1] a backward one, [2] / [3] a forward / backward total beyond half the
- * range.  Host-side read of host-visible memory: synchronise with the step first (the Python engine calls it when it reads
- * the step's loss summary); all zero = the statistics of those steps are the partial-sum path's up to the last bit of a float
- * sum.  Non-zero: they are NOT what torch's fp32 batch_norm (torchreid/models/resnet.py:164-184) would have computed; train
- * with IEEE_BN_TOTALS_TILES=0 (per-tile partial sums, no range limit) from the last good checkpoint. */
+ * range.  The words are device memory at the head of the executor's totals region, zeroed by every training forward (round 6:
+ * they were host-mapped words); this call is a blocking 16-byte copy -- synchronise with the step first.  All zero = the
+ * statistics of that step are the partial-sum path's up to the last bit of a float sum.  Non-zero: they are NOT what torch's
+ * fp32 batch_norm (torchreid/models/resnet.py:164-184) would have computed; a step whose words [0] / [1] are set is skipped by
+ * ieee_sgd_nesterov_step_ex(skip_flags) / ieee_guard_buffers, and the engine switches to the partial-sum path. */
 int ieee_net_bn_overflow(void* handle, int* out4);
+/* byte offset of those four int32 words inside the workspace (they are device memory, zeroed by every training forward): the
+ * engine copies them to the host with the step's summary, the optimizer takes them as `skip_flags` */
+int64_t ieee_net_bn_flags_offset(void* handle);
 /* on = 0: from the next forward on, every BatchNorm of this executor takes the per-tile partial-sum path (ieee_bn2d_fwd /
  * ieee_bn2d_bwd: fp32 sums without a range, as the reference's fp32 nn.BatchNorm2d, torchreid/models/resnet.py:151,164-184;
  * +104 finalize launches per step); on = 1: fixed-point totals again where IEEE_BN_TOTALS_TILES allows.  What the engine does
  * when ieee_net_bn_overflow reports a clamped tile: degrade, warn, keep training (IEEE_BN_STRICT=1: raise instead). */
 int ieee_net_set_bn_totals(void* handle, int on);
 /* shadow_bf16: a bf16 buffer with one element per element of the bound parameter buffer, element i = bf16(params[i]), that the
- * CALLER keeps current (ieee_sgd_nesterov_step_shadow, or a plain conversion after any other write) -- every bf16 TRAINING
+ * CALLER keeps current (ieee_sgd_nesterov_step_ex, or a plain conversion after any other write) -- every bf16 TRAINING
  * forward issued while it is set reads the forward operands of the 1x1 convolutions from it instead of packing them.  NULL
  * (the default): every operand is packed from the fp32 parameters at the start of the forward.  Inference is not affected. */
 int ieee_net_set_shadow(void* handle, const void* shadow_bf16);

@@ -66,42 +66,59 @@ def test_no_warning_without_the_hazard(monkeypatch, kw, live):
         eng._warn_forking_loader()
 
 
-# ---- range guard of the fixed-point BatchNorm totals: what the engine does with the executor's report words ----------------
+# ---- range guard of the fixed-point BatchNorm totals: what the engine does with the step's report words ---------------------
 class _FakeNet(object):
-    def __init__(self, words):
-        self.words, self.reads = list(words), 0
+    def __init__(self):
+        self.totals_on = True
 
-    def bn_overflow(self):
-        self.reads += 1
-        w, self.words = tuple(self.words), [0, 0, 0, 0]          # read AND clear, like ieee_net_bn_overflow
-        return w
+    def set_bn_totals(self, on):
+        self.totals_on = bool(on)
+
+
+class _FakeModel(object):
+    _bn_totals_off = False
 
 
 def _fused_engine():
     from ieee_amd.engine import _FusedStepMixin
-    return _FusedStepMixin()
+    eng = _FusedStepMixin()
+    eng.model = _FakeModel()
+    return eng
 
 
-def test_clamped_batchnorm_tile_raises_and_names_the_switch():
+def test_clamped_batchnorm_tile_degrades_when_the_step_was_skipped_and_raises_otherwise(monkeypatch):
     from ieee_amd._lib import IeeeAmdError
-    eng = _fused_engine()
+    monkeypatch.delenv("IEEE_BN_STRICT", raising=False)
+    # not guarded (data parallel / another optimizer: the update has been applied): raise, and name the switch
+    eng, net = _fused_engine(), _FakeNet()
     with pytest.raises(IeeeAmdError, match="IEEE_BN_TOTALS_TILES=0") as e:
-        eng._check_bn_range(_FakeNet([1, 0, 0, 0]))
-    assert "forward" in str(e.value) and "backward (" not in str(e.value)
+        eng._check_bn_range(net, 7, (1, 0, 0, 0), False)
+    assert "forward" in str(e.value) and "backward (" not in str(e.value) and "step 7" in str(e.value) and "HAS BEEN APPLIED" in str(e.value)
     with pytest.raises(IeeeAmdError, match="backward"):
-        eng._check_bn_range(_FakeNet([0, 1, 1, 1]))
+        eng._check_bn_range(net, 8, (0, 1, 1, 1), False)
+    assert net.totals_on and not eng.model._bn_totals_off
+    # guarded (the device skipped the step): switch to the partial-sum path, warn ONCE with the step, go on
+    with pytest.warns(RuntimeWarning, match=r"of step 9.*was SKIPPED.*partial-sum path"):
+        eng._check_bn_range(net, 9, (1, 0, 0, 0), True)
+    assert not net.totals_on and eng.model._bn_totals_off
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        eng._check_bn_range(net, 10, (0, 1, 0, 0), True)         # a step queued behind it that clamped too: skipped as well, no second warning
+    # IEEE_BN_STRICT=1: raise even when the step was skipped
+    monkeypatch.setenv("IEEE_BN_STRICT", "1")
+    with pytest.raises(IeeeAmdError, match="IEEE_BN_STRICT=1"):
+        _fused_engine()._check_bn_range(_FakeNet(), 3, (1, 0, 0, 0), True)
 
 
 def test_half_range_total_warns_once_and_healthy_steps_are_silent():
     eng = _fused_engine()
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        eng._check_bn_range(_FakeNet([0, 0, 0, 0]))
-        eng._check_bn_range(None)                                 # the generic (autograd) step has no executor
+        eng._check_bn_range(_FakeNet(), 1, (0, 0, 0, 0), True)
+        eng._check_bn_range(None, 1, (0, 0, 0, 0), False)          # the generic (autograd) step has no executor
     with pytest.warns(UserWarning, match="beyond half the range"):
-        eng._check_bn_range(_FakeNet([0, 0, 1, 0]))
-    net = _FakeNet([0, 0, 0, 1])
+        eng._check_bn_range(_FakeNet(), 2, (0, 0, 1, 0), True)
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        eng._check_bn_range(net)                                  # warned once per engine
-    assert net.reads == 1 and net.words == [0, 0, 0, 0]
+        eng._check_bn_range(_FakeNet(), 3, (0, 0, 0, 1), True)     # warned once per engine
+

@@ -212,12 +212,13 @@ def test_bf16_trajectory_at_config2_batch_64():
 
 
 def test_engine_degrades_to_partial_sums_when_batchnorm_sums_leave_the_fixed_point_range(monkeypatch):
-    """The range guard end to end: a layer1 convolution whose weights are blown up until sum y^2 leaves the 2.7e11 the int64
-    totals hold.  The kernels clamp and report, and the engine -- when it reads that step's summary -- switches the executor to
-    the per-tile partial-sum path (fp32 sums without a range: the reference's fp32 batch_norm,
-    torchreid/models/resnet.py:164-184), warns with the step index, and KEEPS TRAINING: the following steps report nothing and
-    give the loss of a model that never used the totals.  (The clamped step itself has run on clamped statistics, as the
-    warning says; with sums a few times beyond the range its results stay finite.  IEEE_BN_STRICT=1 raises instead.)"""
+    """The range guard end to end: a layer1 convolution whose weights are blown up by 1e5 produces sum y^2 far beyond the 2.7e11
+    the int64 totals hold.  The kernels clamp and report ON THE DEVICE, and that step is SKIPPED there: the optimizer launches see
+    the report words and leave parameters / momentum alone, the running statistics are put back (a clamped step ends in inf /
+    NaN gradients: applied, it would poison the parameters).  The engine -- when it reads the report with that step's summary --
+    switches the executor to the per-tile partial-sum path (fp32 sums without a range: the reference's fp32 batch_norm,
+    torchreid/models/resnet.py:164-184), warns once with the step index, and KEEPS TRAINING: the following steps report
+    nothing, move the parameters, and give the loss of a model that never used the totals.  IEEE_BN_STRICT=1 raises instead."""
     import warnings
     from ieee_amd.engine import Image3MEngine
     from ieee_amd.models import build_model
@@ -225,49 +226,47 @@ def test_engine_degrades_to_partial_sums_when_batchnorm_sums_leave_the_fixed_poi
     from tests.util_trajectory import _DM, make_train_set
     monkeypatch.delenv("IEEE_BN_STRICT", raising=False)
 
-    def fresh():
+    def fresh(lr):
         st = {k: v.clone() for k, v in tamed_state(171).items()}
         m = build_model("ieee3modalPart", num_classes=171, loss="margin", pretrained=False, compute_dtype=torch.bfloat16)
         m.load_state_dict(st)
         m.train()
-        eng = Image3MEngine(_DM(171, [], {}), m, build_optimizer(m, optim="sgd", lr=0.0, weight_decay=0.0, momentum=0.0), margin=1,
+        eng = Image3MEngine(_DM(171, [], {}), m, build_optimizer(m, optim="sgd", lr=lr, weight_decay=0.0, momentum=0.9), margin=1,
                             use_gpu=True)
         return m, eng
     xs, pids, cams = make_train_set(2, 4, 21, 0.5)
     batch = {"img": xs, "pid": pids, "camid": cams, "impath": "", "timeid": pids * 0}
     name = "backbone.1.layer1.0.conv2.weight"
-    m, eng = fresh()
-    assert np.isfinite(float(eng.forward_backward(batch)["loss"]))          # a healthy step: nothing reported
-    # blow the weight up in steps of 4x until the guard reports (the first reporting scale is 1-4x beyond the range)
-    scale, step_no = 1.0, 1
-    while True:
+    for defer in (False, True):
+        m, eng = fresh(1e-4)
+        eng.defer_summary = defer
+        assert np.isfinite(float(eng.forward_backward(batch)["loss"]))      # a healthy step: nothing reported, parameters move
         with torch.no_grad():
-            dict(m._param_items)[name].mul_(4.0)
-        scale *= 4.0
-        step_no += 1
-        assert scale < 1e8, "the range guard never reported"
-        with warnings.catch_warnings(record=True) as seen:
-            warnings.simplefilter("always")
-            eng.forward_backward(batch)
-        hits = [w for w in seen if issubclass(w.category, RuntimeWarning) and "left the range of the fixed-point totals" in str(w.message)]
-        if hits:
-            assert "summary read of step %d" % step_no in str(hits[0].message) and "partial-sum path" in str(hits[0].message)
-            break
-    assert m._bn_totals_off is True                                         # executors built later start degraded too
-    assert m.native_net(8, 256, 128).bn_overflow() == (0, 0, 0, 0)          # read and cleared by the engine
-    torch.cuda.synchronize()
-    assert torch.isfinite(m._flat_params).all() and torch.isfinite(m._flat_buffers).all()
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")                                      # the fallback path has no range: silent from here on
-        after = [float(eng.forward_backward(batch)["loss"]) for _ in range(3)]
-    assert m.native_net(8, 256, 128).bn_overflow() == (0, 0, 0, 0)
-    # the same blown-up model on an executor that never used the totals (what IEEE_BN_TOTALS_TILES=0 selects): same numbers
-    m2, eng2 = fresh()
-    m2._bn_totals_off = True
-    with torch.no_grad():
-        dict(m2._param_items)[name].mul_(scale)
-    ref = [float(eng2.forward_backward(batch)["loss"]) for _ in range(3)]
-    assert all(np.isfinite(after)) and np.allclose(after, ref, rtol=1e-6, atol=0), (scale, after, ref)
+            dict(m._param_items)[name].mul_(1e5)
+        torch.cuda.synchronize()
+        before = (m._flat_params.clone(), m._flat_buffers.clone(), eng.optimizer.momentum_buffer().clone())
+        with pytest.warns(RuntimeWarning, match=r"left the range of the fixed-point totals.*of step 2.*was SKIPPED.*partial-sum path"):
+            float(eng.forward_backward(batch)["loss"])                      # (deferred: the report surfaces when the summary is looked at)
+        torch.cuda.synchronize()
+        for a, b in zip(before, (m._flat_params, m._flat_buffers, eng.optimizer.momentum_buffer())):
+            assert torch.equal(a, b)                                        # the clamped step changed NOTHING
+        assert m._bn_totals_off is True                                     # executors built later start degraded too
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                                  # the fallback path has no range: silent from here on
+            after = [float(eng.forward_backward(batch)["loss"]) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert m.native_net(8, 256, 128).bn_overflow() == (0, 0, 0, 0)
+        assert torch.isfinite(m._flat_params).all() and torch.isfinite(m._flat_buffers).all()
+        assert not torch.equal(before[0], m._flat_params)                   # ... and training goes on
+        # the same blown-up model on an executor that never used the totals (what IEEE_BN_TOTALS_TILES=0 selects): same numbers
+        m2, eng2 = fresh(1e-4)
+        float(eng2.forward_backward(batch)["loss"])
+        m2._bn_totals_off = True
+        m2._nets.clear()
+        with torch.no_grad():
+            dict(m2._param_items)[name].mul_(1e5)
+        ref = [float(eng2.forward_backward(batch)["loss"]) for _ in range(3)]
+        assert all(np.isfinite(after)) and np.allclose(after, ref, rtol=1e-5, atol=0), (defer, after, ref)
 
 
 def test_engine_raises_under_bn_strict_when_batchnorm_sums_leave_the_fixed_point_range(monkeypatch):
@@ -293,7 +292,8 @@ def test_engine_raises_under_bn_strict_when_batchnorm_sums_leave_the_fixed_point
         dict(m._param_items)["backbone.1.layer1.0.conv2.weight"].mul_(1e5)
     with pytest.raises(_lib.IeeeAmdError, match="left the range of the fixed-point totals"):
         eng.forward_backward(batch)
-    assert m.native_net(8, 256, 128).bn_overflow() == (0, 0, 0, 0)          # read and cleared by the engine
+    f = m.native_net(8, 256, 128).bn_overflow()                             # the step's device words (read and cleared here)
+    assert f[0] == 1 and m.native_net(8, 256, 128).bn_overflow() == (0, 0, 0, 0)
     # deferred summaries (Engine.train's mode): the error surfaces when the summary is looked at
     eng.defer_summary = True
     pending = eng.forward_backward(batch)
