@@ -698,6 +698,7 @@ struct ConvArgs {
   int tiles_m, tiles_n;
   int group;         // m-tiles per group in the grouped tile order
   int64_t src_gs, w_gs, dst_gs;   // per-modality strides (elements)
+  int stagger = 0;   // every second workgroup of an XCD starts `stagger` x ~0.43 us late (see conv_gather_kernel)
 };
 
 // forward and dgrad share this kernel (they differ only in the gather geometry)
@@ -740,10 +741,18 @@ template <class Epi> __device__ __forceinline__ void set_fin(Epi& epi, const Bwd
 // of PIPE stages with PIPE-1 k-tiles in flight (few-workgroup layers, where no co-resident workgroup hides the
 // load latency of a one-tile-deep pipeline); bf16 fast path only.
 template <typename T, int BN, bool SLOW, int MODE, int PIPE = 0, int VAR = 0>
-__global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : (PIPE == 5 ? 3 : 1)))) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
+__global__ __launch_bounds__(256, (BN == 256 ? 2 : (PIPE == 1 ? 4 : ((PIPE == 5 || PIPE == 6) ? 3 : 1)))) void conv_gather_kernel(const T* __restrict__ src, const T* __restrict__ w,
                                                           T* __restrict__ dst, const T* __restrict__ addend,
                                                           float* __restrict__ bn_partial, ConvArgs a, BwdStats bs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // Phase stagger (round 6, IEEE_GATHER_STAGGER): a launch of one or two rounds of identical workgroups runs in LOCKSTEP --
+  // every workgroup of the chip is in its k-loop (L2 -> LDS path saturated, HBM store path idle), then every workgroup is in
+  // its epilogue (the reverse): the measurement build without epilogues shows 15-60 % of such a launch is epilogue time that
+  // nothing overlaps.  Every second workgroup of an XCD therefore starts a fraction of a tile late, so that the two halves
+  // of the co-resident workgroups sit in opposite phases.
+  if (a.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   int tm, tn;
   tile_map_xy(a.tiles_m, a.tiles_n, a.group, tm, tn);
   const int m0 = tm * 128, n0 = tn * BN;
@@ -1995,6 +2004,10 @@ static GatherPlan plan_gather(int M, int N, int ktiles, int groups) {
     if (f_narrow == 1) p.bn = 64;
     if (f_pipe >= 0) p.pipe = f_pipe;
   }
+  // IEEE_GATHER_DUAL (default 0 until measured; gemm_nt_dma, DMA_STAGES == 6): two k-tiles per round trip for the 128 x 64
+  // launches that cannot offer more than 3 workgroups per CU and have a long enough K
+  static const int f_dual = getenv("IEEE_GATHER_DUAL") ? atoi(getenv("IEEE_GATHER_DUAL")) : 0;
+  if (f_dual > 0 && p.bn == 64 && N > 64 && p.pipe == 1 && ktiles >= f_dual && (int64_t)cdiv(M, 128) * cdiv(N, 64) * groups <= 768) p.pipe = 6;
   if (p.bn == 256 && p.pipe != 1) p.pipe = 0;
   if (ktiles < 2 && p.pipe > 1) p.pipe = 0;
   return p;
@@ -2020,10 +2033,16 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   GatherPlan plan{N <= 64 ? 64 : 128, 0};
   if (sizeof(T) == 2 && !slow) plan = plan_gather(M, N, a.ktiles, groups);
   const bool narrow = plan.bn == 64;
+  if (plan.pipe == 6 && (a.g.perm || (bwd && (bwd->addend_s2 || bwd->y2)))) plan.pipe = 1;   // (forms with epilogue variants of their own)
   if (plan.pipe != 1 || plan.bn == 256 || affine || (bn_partial && !bwd)) a.g.perm = 0;   // class-major rows: default pipeline, dgrad modes
   a.tiles_n = cdiv(N, plan.bn);
   dim3 grid(a.tiles_m * a.tiles_n, groups);
-  const int stages = plan.pipe == 5 ? 1 : (plan.pipe ? plan.pipe : (sizeof(T) == 2 ? 1 : 2));   // PIPE 5 = one stage too
+  {   // phase stagger: launches of at most IEEE_GATHER_STAGGER_MAXWG workgroups (default 3072: at most 3 rounds at 4 per CU)
+    static const int f_stag = getenv("IEEE_GATHER_STAGGER") ? atoi(getenv("IEEE_GATHER_STAGGER")) : 0;
+    static const int64_t f_stag_wg = getenv("IEEE_GATHER_STAGGER_MAXWG") ? atoll(getenv("IEEE_GATHER_STAGGER_MAXWG")) : 3072;
+    a.stagger = ((int64_t)grid.x * groups <= f_stag_wg) ? f_stag : 0;
+  }
+  const int stages = plan.pipe == 5 ? 1 : (plan.pipe == 6 ? 2 : (plan.pipe ? plan.pipe : (sizeof(T) == 2 ? 1 : 2)));   // PIPE 5 = one stage too, 6 = two
   size_t smem = (size_t)stages * (128 + plan.bn) * 128;
   {   // the LDS-staged epilogue needs the C tile: bf16 rows padded by 16 B, fp32 rows unpadded
     const size_t bn = plan.bn;
@@ -2086,8 +2105,11 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
   }
   if constexpr (sizeof(T) == 2) {
     if (!slow && stem_eligible(a.g, N, ldw, mode, addend)) {
-      // IEEE_STEM_WALK (default 4, or 1): tiles per persistent workgroup -- the training forms only (mode 0 / 1)
-      static const int f_walk = getenv("IEEE_STEM_WALK") ? atoi(getenv("IEEE_STEM_WALK")) : 4;
+      // IEEE_STEM_WALK=4 (default 1): tiles per persistent workgroup -- the training forms only (mode 0 / 1).  Built and measured
+      // in round 6 (LABNOTES R6.3c): the launch itself got SLOWER inside the step (128.7 -> 161.8 us in a trace pair: 3 072
+      // four-tile chains at 40 KB of LDS instead of 12 288 short workgroups that hide each other's patch and weight latency),
+      // the step moved by -0.02 ms (median of 6 interleaved rounds, inside the noise).  Kept as an option.
+      static const int f_walk = getenv("IEEE_STEM_WALK") ? atoi(getenv("IEEE_STEM_WALK")) : 1;
       const bool walk = f_walk == 4 && mode != 3 && a.tiles_m % 4 == 0 && (a.g.Ho >> 1) % 4 == 0;
       dim3 sgrid(walk ? a.tiles_m / 4 : a.tiles_m, groups);
       const size_t ssm = walk ? STEM_EPI_BYTES + 2 * STEM_PATCH_BYTES : STEM_EPI_BYTES;   // staged epilogue (18 KB) > patch (11 KB) > BN-sum scratch
@@ -2134,6 +2156,7 @@ static int launch_gather(const T* src, const T* w, T* dst, const T* addend, cons
         case 2: IEEE_GATHER_CASE(64, 2); break;
         case 3: IEEE_GATHER_CASE(64, 3); break;
         case 4: IEEE_GATHER_CASE(64, 4); break;
+        case 6: IEEE_GATHER_CASE(64, 6); break;
         default: IEEE_GATHER_CASE(64, 0); break;
       }
     } else {

@@ -489,6 +489,29 @@ __device__ __forceinline__ void gemm_nt_dma(LA& la, LB& lb, Epi& epi, int ktiles
       }
     }
     }
+  } else if constexpr (DMA_STAGES == 6) {
+    // "dual issue" (round 6): TWO k-tiles per round trip in two LDS stages, nothing overlapped inside the workgroup.  For the
+    // launches that offer at most 3 workgroups per CU anyway (the 128 x 64 tiles of layer3's N = 256 GEMMs: 768 workgroups) the
+    // single stage leaves 3 x 24 KB in flight per CU and pays one ~2 us round trip per 64 of K; this form has 3 x 48 KB in flight
+    // and half the round trips and barriers.  (A two-stage RING has ONE tile in flight while it computes the other: the same
+    // 24 KB per workgroup as the single stage.)
+    int kt = 0;
+    issue(0);
+    if (ktiles > 1) { la.next(); lb.next(); issue(1); }
+    while (kt < ktiles) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // both tiles have landed for every wave
+      compute(smem);
+      if (kt + 1 < ktiles) compute(smem + STAGE);
+      kt += 2;
+      if (kt < ktiles) {
+        __builtin_amdgcn_s_barrier();   // every wave is done reading both stages
+        la.next();
+        lb.next();
+        issue(0);
+        if (kt + 1 < ktiles) { la.next(); lb.next(); issue(1); }
+      }
+    }
   } else {
   // prologue: tiles 0 .. DMA_STAGES-2
   int issued = 0;
