@@ -189,7 +189,9 @@ def cpu_baseline_train(seconds_budget=14.0):
            "why_16_threads": "the step's convs at batch 8 are small: beyond ~16 threads torch's CPU kernels lose more to "
                              "synchronisation than they gain (see all_cores)",
            "sample": "%d oracle train steps at batch %d (fp32, torch CPU ops, %d threads of a host with %s physical cores / "
-                     "%d logical CPUs), %.2f s/step" % (n, B, threads, phys, logical, dt)}
+                     "%d logical CPUs), %.2f s/step" % (n, B, threads, phys, logical, dt),
+           "note": "a SMALL-BATCH figure (8 triples per step) beside a 64-triple GPU step: bounded sample, baseline only.  torch's "
+                   "CPU convs at batch 8 do not scale past ~16 threads (all_cores), which says nothing about the host's speed"}
     wide = phys or default_threads
     if wide and wide > threads:
         try:
