@@ -199,3 +199,25 @@ def test_wgrad_fold_hand_off_under_load_and_with_warm_caches():
             assert torch.equal(got, want), "fold: hand-off returned different bits (rep %d)" % rep
     torch.cuda.synchronize()
     assert int(_ops._fold_tickets(big.device).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("env", ["IEEE_GATHER_DUAL=4", "IEEE_GATHER_STAGGER=3", "IEEE_STEM_WALK=4", "IEEE_WGRAD_CHAIN=1", "IEEE_WGRAD_FOLD=1",
+                                 "IEEE_HEAD_PAIRS=0 IEEE_SGD_SHADOW=0"])
+def test_optional_kernel_forms_stay_correct(env):
+    """the kernel forms round 6 built, measured and left OFF (dual-issue k-loop, phase stagger, persistent stem, chained / folded
+    weight-gradient reductions) and the two it switched ON (head pairs, parameter shadow; here switched off) are options of the
+    product: every layer shape of the timed configuration and one engine step must still pass under each.  The switches are read
+    once per process, hence a child interpreter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = dict(os.environ)
+    for kv in env.split():
+        k, v = kv.split("=")
+        child[k] = v
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_config2_gpu.py"), "-k", "conv_kernels_at_config2_shapes or b64_bf16_engine_step or direct_stem",
+                        os.path.join(root, "tests", "test_conv_gpu.py") + "::test_direct_stem_persistent_over_four_tiles"],
+                       cwd=root, env=child, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=570)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
