@@ -2571,7 +2571,7 @@ static int wgrad_impl(const void* dy, const void* x, float* dw_oihw, void* work,
   // each weight gradient alone is a little slower (511 vs 515 TFLOP/s serialized), the step is 0.15 ms faster (15.31 -> 15.16,
   // five interleaved rounds): the dgrad / BatchNorm chain finds free slots sooner.  64 KB (2 per CU) loses (15.4).
   static const size_t f_lds = (size_t)(getenv("IEEE_WGRAD_LDS") ? atoi(getenv("IEEE_WGRAD_LDS")) : 48) * 1024;
-  size_t smem = pipe ? (size_t)pipe * 32 * 1024 : (dtype == IEEE_BF16 ? 32 * 1024 : 64 * 1024);
+  size_t smem = pipe ? (size_t)(pipe == 6 ? 2 : pipe) * 32 * 1024 : (dtype == IEEE_BF16 ? 32 * 1024 : 64 * 1024);
   if (smem < f_lds) smem = f_lds;
   static bool attr_done = false;
   if (!attr_done) {
@@ -2648,6 +2648,7 @@ static int wgrad_impl(const void* dy, const void* x, float* dw_oihw, void* work,
     else if (pipe == 2) conv_wgrad_kernel<bf16, false, 2><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
     else if (pipe == 3) conv_wgrad_kernel<bf16, false, 3><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
     else if (pipe == 4) conv_wgrad_kernel<bf16, false, 4><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
+    else if (pipe == 6) conv_wgrad_kernel<bf16, false, 6><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
     else conv_wgrad_kernel<bf16, false><<<grid, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, slab, a, pv);
   } else {
     IEEE_REQUIRE(false, "conv2d_wgrad: bad dtype %d", dtype);

@@ -605,6 +605,27 @@ __device__ __forceinline__ void gemm_tn_dma(LA& la, LB& lb, Epi& epi, int ktiles
         issue(0);
       }
     }
+  } else if constexpr (DMA_STAGES == 6) {
+    // "dual issue" (see gemm_nt_dma): two k-tiles per round trip in two stages, nothing overlapped inside the workgroup.  The
+    // weight-gradient launches have ~1.75 workgroups per CU by construction (split-K target 448): 56 KB in flight per CU with one
+    // stage, 112 KB with this form.  IEEE_WGRAD_PIPE=6.
+    int kt = 0;
+    if (ktiles > 0) issue(0);
+    if (ktiles > 1) { la.next(); lb.next(); issue(1); }
+    while (kt < ktiles) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      compute(smem);
+      if (kt + 1 < ktiles) compute(smem + STAGE);
+      kt += 2;
+      if (kt < ktiles) {
+        __builtin_amdgcn_s_barrier();
+        la.next();
+        lb.next();
+        issue(0);
+        if (kt + 1 < ktiles) { la.next(); lb.next(); issue(1); }
+      }
+    }
   } else {
   int issued = 0;
   for (; issued < DMA_STAGES - 1 && issued < ktiles; ++issued) {
