@@ -201,11 +201,11 @@ def test_wgrad_fold_hand_off_under_load_and_with_warm_caches():
     assert int(_ops._fold_tickets(big.device).abs().sum()) == 0
 
 
-@pytest.mark.parametrize("env", ["IEEE_GATHER_DUAL=4", "IEEE_GATHER_STAGGER=3", "IEEE_STEM_WALK=4", "IEEE_WGRAD_CHAIN=1", "IEEE_WGRAD_FOLD=1",
-                                 "IEEE_HEAD_PAIRS=0 IEEE_SGD_SHADOW=0"])
+@pytest.mark.parametrize("env", ["IEEE_GATHER_DUAL=4 IEEE_GATHER_STAGGER=3 IEEE_STEM_WALK=4 IEEE_WGRAD_PIPE=6",
+                                 "IEEE_WGRAD_CHAIN=1 IEEE_HEAD_PAIRS=0 IEEE_SGD_SHADOW=0", "IEEE_WGRAD_FOLD=1"])
 def test_optional_kernel_forms_stay_correct(env):
-    """the kernel forms round 6 built, measured and left OFF (dual-issue k-loop, phase stagger, persistent stem, chained / folded
-    weight-gradient reductions) and the two it switched ON (head pairs, parameter shadow; here switched off) are options of the
+    """the kernel forms round 6 built, measured and left OFF (dual-issue k-loops of both GEMM cores, phase stagger, persistent stem,
+    chained / folded weight-gradient reductions) and the two it switched ON (head pairs, parameter shadow; here switched off) are options of the
     product: every layer shape of the timed configuration and one engine step must still pass under each.  The switches are read
     once per process, hence a child interpreter."""
     import os
